@@ -1,0 +1,275 @@
+"""Oracle: mosaic / affine / HSV / flip / mixup compositing (numpy, CPU).
+
+TEST INFRASTRUCTURE - see oracle/__init__.py.  Restates:
+
+* mosaic paste + box filter       kod/data/mosaic.py:11-161
+* affine matrix, box transform    kod/data/augmentations/default.py:111-351
+* flip                            kod/data/augmentations/default.py:386-397
+* mixup                           kod/data/augmentations/default.py:400-408
+* per-sample protocol             kod/data/detection.py:102-156,
+                                  kod/data/augmentations/default.py:440-488
+
+Pinned by golden vectors: mosaic (image + boxes), affine matrices, box
+transform / candidate filter, flip, mixup.
+
+PARITY UNPINNED (third-party arithmetic absent from the reference tree and not
+installed in this image): ``cv2.warpAffine`` (INTER_LINEAR, BORDER_CONSTANT)
+and ``cv2.cvtColor`` BGR<->HSV.  ``warp_affine_u8`` / ``bgr2hsv_u8`` /
+``hsv2bgr_u8`` below restate OpenCV 4.x's published fixed-point algorithms
+(imgwarp.cpp: INTER_BITS=5, INTER_REMAP_COEF_BITS=15, AB_BITS=10;
+color_hsv.cpp: hsv_shift=12 integer tables for u8).
+"""
+from __future__ import annotations
+
+import math
+import random
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------- mosaic
+def _candidates(orig, proc, eps, wh_thr=2.0, ar_thr=20.0, area_thr=0.1):
+    """box_candidates (mosaic.py:11-35, eps 1e-7) / _box_candidates (default.py:195-216, eps 1e-16);
+    both take [4,n] arrays."""
+    w1, h1 = orig[2] - orig[0], orig[3] - orig[1]
+    w2, h2 = proc[2] - proc[0], proc[3] - proc[1]
+    ar = np.maximum(w2 / (h2 + eps), h2 / (w2 + eps))
+    return (w2 > wh_thr) & (h2 > wh_thr) & (w2 * h2 / (w1 * h1 + eps) > area_thr) & (ar < ar_thr)
+
+
+def mosaic_centre(S: int, rnd=random):
+    """mosaic.py:58-62: yc then xc, each int(uniform(S/2, 3S/2)) (border = -S//2)."""
+    border = (-S // 2, -S // 2)
+    yc, xc = (int(rnd.uniform(-x, 2 * S + x)) for x in border)
+    return yc, xc, border
+
+
+def mosaic_rects(i: int, w: int, h: int, xc: int, yc: int, S: int):
+    """Destination (a) / source (b) rectangles of tile i (mosaic.py:71-130)."""
+    if i == 0:
+        a = (max(xc - w, 0), max(yc - h, 0), xc, yc)
+        b = (w - (a[2] - a[0]), h - (a[3] - a[1]), w, h)
+    elif i == 1:
+        a = (xc, max(yc - h, 0), min(xc + w, 2 * S), yc)
+        b = (0, h - (a[3] - a[1]), min(w, a[2] - a[0]), h)
+    elif i == 2:
+        a = (max(xc - w, 0), yc, xc, min(2 * S, yc + h))
+        b = (w - (a[2] - a[0]), 0, w, min(a[3] - a[1], h))
+    else:
+        a = (xc, yc, min(xc + w, 2 * S), min(2 * S, yc + h))
+        b = (0, 0, min(w, a[2] - a[0]), min(a[3] - a[1], h))
+    return a, b
+
+
+def mosaic(samples, S: int, rnd=random):
+    """MosaicAugmentor.__call__ (mosaic.py:51-161); samples = 4 x (u8 HWC, boxes f64, labels)."""
+    yc, xc, border = mosaic_centre(S, rnd)
+    canvas = np.full((2 * S, 2 * S, 3), 114, dtype=np.uint8)
+    bbs, lbs = [], []
+    for i, (img, boxes, labels) in enumerate(samples):
+        h, w = img.shape[:2]
+        a, b = mosaic_rects(i, w, h, xc, yc, S)
+        canvas[a[1]:a[3], a[0]:a[2]] = img[b[1]:b[3], b[0]:b[2]]
+        if len(boxes) > 0:
+            shifted = boxes.copy()
+            shifted[:, [0, 2]] += a[0] - b[0]
+            shifted[:, [1, 3]] += a[1] - b[1]
+        bbs.append(shifted)          # reference quirk: stale boxes re-appended for box-less tiles
+        lbs.append(labels)
+    bb = np.concatenate(bbs, 0)
+    lb = np.concatenate(lbs, 0)
+    keep = _candidates(bb.T, np.clip(bb, 0, 2 * S).T, eps=1e-7)
+    bb = np.clip(bb[keep], 0, 2 * S - 1)
+    return canvas, bb, lb[keep], border, (yc, xc)
+
+
+# ----------------------------------------------------------------------------- affine
+def affine_draws(rng: np.random.Generator, degrees=0.0, translate=0.1, scale=0.5, shear=0.0, perspective=0.0):
+    """get_affine_random_values (default.py:111-140): 8 uniforms in the reference's order."""
+    px = rng.uniform(-perspective, perspective)
+    py = rng.uniform(-perspective, perspective)
+    deg = rng.uniform(-degrees, degrees)
+    sc = rng.uniform(1 - scale, 1 + scale)
+    shx = rng.uniform(-shear, shear)
+    shy = rng.uniform(-shear, shear)
+    tx = rng.uniform(0.5 - translate, 0.5 + translate)
+    ty = rng.uniform(0.5 - translate, 0.5 + translate)
+    return px, py, deg, sc, shx, shy, tx, ty
+
+
+def affine_matrix(draws, w_in: int, h_in: int, border=(0, 0)):
+    """M = T.S.R.P.C (default.py:143-277); R as cv2.getRotationMatrix2D(angle, (0,0), scale)."""
+    px, py, deg, sc, shx, shy, tx, ty = draws
+    w_out, h_out = w_in + 2 * border[1], h_in + 2 * border[0]
+    C = np.eye(3); C[0, 2] = -w_in / 2; C[1, 2] = -h_in / 2
+    P = np.eye(3); P[2, 0] = px; P[2, 1] = py
+    a = math.radians(deg)
+    Rm = np.eye(3)
+    Rm[0, 0] = Rm[1, 1] = sc * math.cos(a)
+    Rm[0, 1] = sc * math.sin(a); Rm[1, 0] = -sc * math.sin(a)
+    Sh = np.eye(3); Sh[0, 1] = math.tan(shx * math.pi / 180); Sh[1, 0] = math.tan(shy * math.pi / 180)
+    T = np.eye(3); T[0, 2] = tx * w_out; T[1, 2] = ty * h_out
+    return T @ Sh @ Rm @ P @ C, (w_out, h_out)
+
+
+def affine_boxes(boxes: np.ndarray, M: np.ndarray, w_out: int, h_out: int, scale: float):
+    """_process_affine_bboxes + _box_candidates (default.py:249-276,323-345), affine case."""
+    n = len(boxes)
+    xy = np.ones((n * 4, 3))
+    xy[:, :2] = boxes[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)
+    xy = (xy @ M.T)[:, :2].reshape(n, 8)
+    x, y = xy[:, [0, 2, 4, 6]], xy[:, [1, 3, 5, 7]]
+    nb = np.concatenate((x.min(1), y.min(1), x.max(1), y.max(1))).reshape(4, n).T
+    nb[:, [0, 2]] = nb[:, [0, 2]].clip(0, w_out - 1)
+    nb[:, [1, 3]] = nb[:, [1, 3]].clip(0, h_out - 1)
+    keep = _candidates(boxes.T * scale, nb.T, eps=1e-16)
+    return nb, keep
+
+
+def flip_boxes(boxes: np.ndarray, width: int):
+    """horizontal_flip (default.py:386-397)."""
+    out = boxes.copy()
+    if len(out):
+        out[:, 2] = width - 1 - boxes[:, 0]
+        out[:, 0] = width - 1 - boxes[:, 2]
+    return out
+
+
+def mixup_blend(im1, im2, r: float):
+    """mixup (default.py:400-408); images are f32 CHW, r is a python/numpy f64 scalar."""
+    return im1 * r + im2 * (1 - r)
+
+
+# ----------------------------------------------------------------------------- OpenCV restatements (unpinned)
+def warp_affine_u8(src: np.ndarray, M23: np.ndarray, w_out: int, h_out: int, border_value: int = 114):
+    """cv2.warpAffine(src, M, (w_out,h_out), INTER_LINEAR, BORDER_CONSTANT) for u8 HWC.
+
+    OpenCV imgwarp.cpp: invert M; per destination pixel X0 = saturate(round((M00*x)*1024)),
+    fixed point AB_BITS=10; coordinates rounded to 1/32 px (INTER_BITS=5); bilinear weights from
+    the 32x32 table in 15-bit integers (sum 32768); result = (sum + 16384) >> 15.
+    """
+    M = np.asarray(M23, dtype=np.float64)
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[1, 1] * D, M[0, 0] * D
+    iM = np.array([[A11, -M[0, 1] * D, 0.0], [-M[1, 0] * D, A22, 0.0]])
+    iM[0, 2] = -iM[0, 0] * M[0, 2] - iM[0, 1] * M[1, 2]
+    iM[1, 2] = -iM[1, 0] * M[0, 2] - iM[1, 1] * M[1, 2]
+    AB_BITS, INTER_BITS = 10, 5
+    AB_SCALE = 1 << AB_BITS
+    INTER_TAB = 1 << INTER_BITS
+    rnd = AB_SCALE // INTER_TAB // 2
+    xs = np.arange(w_out)
+    adelta = np.rint(iM[0, 0] * xs * AB_SCALE).astype(np.int64)        # cvRound = rint (half-even)
+    bdelta = np.rint(iM[1, 0] * xs * AB_SCALE).astype(np.int64)
+    ys = np.arange(h_out)
+    X0 = np.rint((iM[0, 1] * ys + iM[0, 2]) * AB_SCALE).astype(np.int64) + rnd
+    Y0 = np.rint((iM[1, 1] * ys + iM[1, 2]) * AB_SCALE).astype(np.int64) + rnd
+    X = (X0[:, None] + adelta[None, :]) >> (AB_BITS - INTER_BITS)
+    Y = (Y0[:, None] + bdelta[None, :]) >> (AB_BITS - INTER_BITS)
+    sx, sy = X >> INTER_BITS, Y >> INTER_BITS
+    fx, fy = X & (INTER_TAB - 1), Y & (INTER_TAB - 1)
+    tab = _bilinear_tab()
+    wts = tab[fy, fx]                                                  # [h,w,4] int (w00,w01,w10,w11)
+    h, w = src.shape[:2]
+    out = np.empty((h_out, w_out, src.shape[2]), dtype=np.uint8)
+
+    def fetch(yy, xx):
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        v = src[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)].astype(np.int64)
+        v[~ok] = border_value
+        return v
+
+    acc = (fetch(sy, sx) * wts[..., 0:1] + fetch(sy, sx + 1) * wts[..., 1:2]
+           + fetch(sy + 1, sx) * wts[..., 2:3] + fetch(sy + 1, sx + 1) * wts[..., 3:4])
+    out[:] = ((acc + (1 << 14)) >> 15).astype(np.uint8)
+    return out
+
+
+_TAB = None
+
+
+def _bilinear_tab():
+    """OpenCV initInterTab2D(INTER_LINEAR, fixpt=true): 32x32x(2x2) int16 weights summing to 32768."""
+    global _TAB
+    if _TAB is None:
+        n = 32
+        t1 = np.stack((1.0 - np.arange(n) / n, np.arange(n) / n), 1).astype(np.float32)   # [32,2]
+        tab = np.zeros((n, n, 4), dtype=np.int64)
+        for i in range(n):
+            for j in range(n):
+                f = (t1[i][:, None] * t1[j][None, :]).astype(np.float32)                  # [ky,kx]
+                it = np.array([[_sat16(np.rint(float(v) * 32768)) for v in row] for row in f], dtype=np.int64)
+                s = int(it.sum())
+                if s != 32768:                 # OpenCV nudges the largest/smallest central weight
+                    diff = s - 32768
+                    flat = it.reshape(-1)
+                    # ksize=2: candidate window is the whole 2x2 block
+                    if diff < 0:
+                        k = int(np.argmax(flat)); flat[k] -= diff
+                    else:
+                        k = int(np.argmin(flat)); flat[k] -= diff
+                    it = flat.reshape(2, 2)
+                tab[i, j] = it.reshape(-1)
+        _TAB = tab
+    return _TAB
+
+
+def _sat16(v):
+    return int(max(-32768, min(32767, v)))
+
+
+def bgr2hsv_u8(img: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(img, COLOR_BGR2HSV) for u8 (H in [0,180)), OpenCV integer tables (hsv_shift=12)."""
+    b = img[..., 0].astype(np.int64); g = img[..., 1].astype(np.int64); r = img[..., 2].astype(np.int64)
+    v = np.maximum(np.maximum(b, g), r)
+    vmin = np.minimum(np.minimum(b, g), r)
+    diff = v - vmin
+    hsv_shift = 12
+    idx = np.arange(256)
+    sdiv = np.zeros(256, dtype=np.int64); hdiv = np.zeros(256, dtype=np.int64)
+    sdiv[1:] = np.rint((255 << hsv_shift) / idx[1:].astype(np.float64)).astype(np.int64)
+    hdiv[1:] = np.rint((180 << hsv_shift) / (6.0 * idx[1:])).astype(np.int64)
+    vr = (v == r); vg = (v == g)
+    s = (diff * sdiv[v] + (1 << (hsv_shift - 1))) >> hsv_shift
+    h = np.where(vr, g - b, np.where(vg, (b - r) + 2 * diff, (r - g) + 4 * diff))
+    h = (h * hdiv[diff] + (1 << (hsv_shift - 1))) >> hsv_shift
+    h = h + np.where(h < 0, 180, 0)
+    return np.stack((h, s, v), -1).astype(np.uint8)
+
+
+def hsv2bgr_u8(hsv: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(hsv, COLOR_HSV2BGR) for u8: OpenCV converts through float32 (h*(6/180), s/255, v/255)."""
+    h = hsv[..., 0].astype(np.float32); s = hsv[..., 1].astype(np.float32) * np.float32(1 / 255.0)
+    v = hsv[..., 2].astype(np.float32) * np.float32(1 / 255.0)
+    hscale = np.float32(6.0 / 180.0)
+    hh = h * hscale
+    hh = np.where(hh < 0, hh + 6, hh); hh = np.where(hh >= 6, hh - 6, hh)
+    sector = np.floor(hh).astype(np.int64)
+    f = hh - sector.astype(np.float32)
+    sector = np.clip(sector, 0, 5)
+    t0 = v
+    t1 = v * (1 - s)
+    t2 = v * (1 - s * f)
+    t3 = v * (1 - s * (1 - f))
+    tabs = np.stack((t0, t1, t2, t3), -1)
+    sector_data = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    sel = sector_data[sector]                                           # [...,3] -> b,g,r picks
+    bgr = np.take_along_axis(tabs, sel, -1)
+    bgr = np.where(s[..., None] == 0, v[..., None], bgr)
+    return np.clip(np.rint(bgr * 255.0), 0, 255).astype(np.uint8)
+
+
+def hsv_luts(r3: np.ndarray):
+    """augment_hsv LUTs (default.py:376-379); r3 = draws*[h,s,v]+1."""
+    x = np.arange(0, 256, dtype=np.int16)
+    return (((x * r3[0]) % 180).astype(np.uint8), np.clip(x * r3[1], 0, 255).astype(np.uint8),
+            np.clip(x * r3[2], 0, 255).astype(np.uint8))
+
+
+def augment_hsv_u8(img: np.ndarray, r3: np.ndarray) -> np.ndarray:
+    """augment_hsv (default.py:354-383) on an RGB image treated as BGR (reference quirk)."""
+    hsv = bgr2hsv_u8(img)
+    lh, ls, lv = hsv_luts(r3)
+    out = np.stack((lh[hsv[..., 0]], ls[hsv[..., 1]], lv[hsv[..., 2]]), -1)
+    return hsv2bgr_u8(out)

@@ -1,0 +1,140 @@
+"""Seeded synthetic inputs shared by the golden generator, the tests and bench.py.
+
+TEST INFRASTRUCTURE - see oracle/__init__.py.  Pure torch / numpy, no
+reference import: the same call reproduces the same inputs on the GPU box.
+Target statistics follow SURVEY.md 8(d): n ~ U{1..9} boxes per image, class ~
+Zipf(1.01, N=nc) (kod/data/builder.py:110-116), log-uniform box sizes.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def zipf_pmf(nc: int, a: float = 1.01) -> np.ndarray:
+    k = np.arange(1, nc + 1, dtype=np.float64)
+    p = k ** (-a)
+    return p / p.sum()
+
+
+def targets(B: int, size: int, nc: int, seed: int, nmin: int = 1, nmax: int = 9):
+    """List of (boxes f64 [n,4] xyxy px, labels i64 [n])."""
+    rng = np.random.default_rng(seed)
+    pmf = zipf_pmf(nc)
+    out = []
+    for _ in range(B):
+        n = int(rng.integers(nmin, nmax + 1))
+        c = rng.uniform(0, size, (n, 2))
+        wh = np.exp(rng.uniform(np.log(8 * size / 640), np.log(400 * size / 640), (n, 2)))
+        b = np.concatenate((c - wh / 2, c + wh / 2), 1).clip(0, size - 1)
+        ok = ((b[:, 2] - b[:, 0]) > 2) & ((b[:, 3] - b[:, 1]) > 2)
+        b = b[ok]
+        if b.shape[0] == 0:
+            b = np.array([[size * 0.25, size * 0.25, size * 0.75, size * 0.75]])
+        lab = rng.choice(nc, size=b.shape[0], p=pmf)
+        out.append((torch.from_numpy(b.astype(np.float64)), torch.from_numpy(lab.astype(np.int64))))
+    return out
+
+
+def batch(B: int, size: int, nc: int, seed: int):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, size, size, generator=g)
+    return x, targets(B, size, nc, seed)
+
+
+def head_logits(B: int, size: int, nc: int, seed: int, scale: float = 1.0, na: int = 3):
+    """Random head outputs [(box,obj,cls)] x 3 levels, contiguous, fp32."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for s in (8, 16, 32):
+        h = w = size // s
+        out.append((torch.randn(B, na, h, w, 4, generator=g) * scale,
+                    torch.randn(B, na, h, w, 1, generator=g) * scale - 2.0,
+                    torch.randn(B, na, h, w, nc, generator=g) * scale))
+    return out
+
+
+def _t(boxes, labels):
+    return (torch.tensor(boxes, dtype=torch.float64).reshape(-1, 4),
+            torch.tensor(labels, dtype=torch.int64))
+
+
+def assigner_cases():
+    """name -> (image size, [(boxes, labels)])."""
+    cases = {
+        # SURVEY.md Appendix B.1 KAT
+        "kat": (640, [_t([[100, 120, 300, 380]], [1]),
+                      _t([[400, 50, 460, 130], [10, 10, 30, 40]], [7, 3])]),
+        # image without boxes between two with boxes
+        "empty_middle": (640, [_t([[50, 60, 90, 130]], [0]), _t([], []), _t([[300, 310, 420, 400]], [2])]),
+        # centres on exact integers / half cells / image borders (all five offset blocks)
+        "edges": (640, [_t([[8, 8, 24, 24], [0, 0, 16, 16], [600, 600, 639, 639], [316, 316, 324, 324],
+                            [60, 60, 68, 68], [12, 20, 28, 28]], [0, 1, 2, 3, 4, 5])]),
+        # duplicates (same box twice -> duplicate cells)
+        "dups": (640, [_t([[100, 100, 150, 160], [100, 100, 150, 160], [101, 100, 151, 160]], [1, 2, 3])]),
+        # nothing at all
+        "all_empty": (640, [_t([], []), _t([], [])]),
+        # non-640 size
+        "s416": (416, targets(4, 416, 10, seed=5)),
+        "rand640": (640, targets(8, 640, 10, seed=2023)),
+        "mosaic_like": (640, targets(4, 640, 10, seed=9, nmin=10, nmax=36)),
+    }
+    return cases
+
+
+def loss_cases():
+    """name -> (size, nc, B, targets, pos_weight list | None)."""
+    w10 = [float(v) for v in (32567 / np.array([12982, 6918, 2409, 2663, 1837, 1829, 1096, 1009, 941, 883]))]
+    return {
+        "rand64": (64, 10, 2, targets(2, 64, 10, seed=1), None),
+        "rand128_w": (128, 10, 3, targets(3, 128, 10, seed=2, nmin=3, nmax=12), w10),
+        "dups128": (128, 10, 2, [_t([[20, 20, 60, 70], [20, 20, 60, 70], [21, 20, 61, 70]], [1, 2, 3]),
+                                 _t([[10, 30, 100, 90]], [4])], None),
+        "emptyimg128": (128, 10, 2, [_t([], []), _t([[16, 16, 80, 90], [50, 40, 70, 66], [90, 90, 120, 125]],
+                                                   [0, 5, 9])], None),
+        # tiny boxes only: the hl level gets no match -> NaN box/cls loss (loss.py:96)
+        "nan_level128": (128, 10, 1, [_t([[10, 10, 18, 19]], [3])], None),
+        "rand256_nc3": (256, 3, 2, targets(2, 256, 3, seed=4), None),
+    }
+
+
+def network_cases():
+    """name -> (widen, deepen, nc, B, size, seed)."""
+    return {
+        "yv5n_64": (0.25, 0.33, 10, 2, 64, 2023),
+        "yv5s_64": (0.50, 0.33, 10, 2, 64, 7),
+        "yv5s_160": (0.50, 0.33, 10, 2, 160, 2023),
+        "yv5s_640": (0.50, 0.33, 10, 2, 640, 2023),
+    }
+
+
+def decode_cases():
+    """name -> (size, nc, B, seed, logit scale)."""
+    return {"d64": (64, 10, 2, 21, 1.0), "d128_hot": (128, 10, 2, 22, 3.0), "d96_nc1": (96, 1, 1, 23, 2.0)}
+
+
+def source_samples(n: int, S: int, seed: int, nc: int = 10):
+    """n cached-sample-like tuples (u8 HWC image with longest side S, f64 boxes, i64 labels)."""
+    rng = np.random.default_rng(seed)
+    ratios = [(4, 3), (3, 4), (1, 1), (3, 2)]
+    out = []
+    for _ in range(n):
+        rw, rh = ratios[int(rng.integers(0, 4))]
+        w, h = (S, max(2, int(round(S * rh / rw)))) if rw >= rh else (max(2, int(round(S * rw / rh))), S)
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        k = int(rng.integers(1, 6))
+        c = np.stack((rng.uniform(0, w, k), rng.uniform(0, h, k)), 1)
+        wh = np.exp(rng.uniform(np.log(max(3.0, S / 40)), np.log(S * 0.6), (k, 2)))
+        b = np.concatenate((c - wh / 2, c + wh / 2), 1)
+        b[:, [0, 2]] = b[:, [0, 2]].clip(0, w - 1)
+        b[:, [1, 3]] = b[:, [1, 3]].clip(0, h - 1)
+        ok = ((b[:, 2] - b[:, 0]) > 2) & ((b[:, 3] - b[:, 1]) > 2)
+        b = b[ok]
+        if b.shape[0] == 0:
+            b = np.array([[w * 0.25, h * 0.25, w * 0.75, h * 0.75]])
+        out.append((img, b.astype(np.float64), rng.integers(0, nc, b.shape[0]).astype(np.int64)))
+    return out
+
+
+def mosaic_cases():
+    return {"m64_a": (64, 1), "m64_b": (64, 2), "m640": (640, 2023), "m416": (416, 11)}

@@ -1,0 +1,180 @@
+"""The CPU oracle against golden vectors produced by the real reference
+(oracle/gen_golden.py).  This is what pins the oracle; everything here runs on CPU."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import datapath, detection as D, optim as O, synth
+from oracle.network import OracleYolov5, HeadOut, NetOut
+
+
+def _targets(tg):
+    return [D.Target(b, l) for b, l in tg]
+
+
+def test_iou_family(golden):
+    g = golden("iou")
+    b1, b2 = torch.from_numpy(g["b1"]), torch.from_numpy(g["b2"])
+    for kind in ("iou", "giou", "diou", "ciou"):
+        np.testing.assert_array_equal(D.iou_family(b1, b2, kind).numpy(), g[kind])
+    # SURVEY Appendix B.2 known answers
+    np.testing.assert_allclose(g["ciou"][:3], [0.0317460, 0.0836961, 1.0], atol=1e-6)
+    b1g = b1.clone().requires_grad_(True)
+    D.iou_family(b1g, b2, "ciou").sum().backward()
+    np.testing.assert_array_equal(b1g.grad.numpy(), g["ciou_grad_b1"])
+
+
+@pytest.mark.parametrize("case", list(synth.assigner_cases()))
+def test_assigner(golden, case):
+    g = golden("assigner")
+    size, tg = synth.assigner_cases()[case]
+    res = D.assign(size, size, _targets(tg))
+    for lvl, a in zip(("ll", "ml", "hl"), res):
+        p = f"{case}.{lvl}."
+        for k in ("samples", "anchors_idx", "grid_y", "grid_x", "labels", "gt_boxes", "anchors"):
+            np.testing.assert_array_equal(getattr(a, k).numpy(), g[p + k], err_msg=p + k)
+
+
+def test_assigner_kat_values(golden):
+    """SURVEY Appendix B.1 hand-checked values."""
+    g = golden("assigner")
+    assert g["kat.ll.anchors_idx"].tolist() == [0, 1, 1, 2, 2, 0, 1, 1, 2, 2, 1, 2]
+    assert g["kat.hl.grid_x"].tolist() == [6, 13, 6, 13, 6, 5, 12, 5, 12, 5, 6, 13, 6, 13, 6]
+    np.testing.assert_allclose(g["kat.ll.gt_boxes"][0], (0.5, 0.125, 2.5, 3.75))
+
+
+@pytest.mark.parametrize("case", list(synth.loss_cases()))
+def test_loss(golden, case):
+    g = golden("loss")
+    size, nc, B, tg, w = synth.loss_cases()[case]
+    heads = [[t.clone().requires_grad_(True) for t in h] for h in synth.head_logits(B, size, nc, seed=11)]
+    out = NetOut(*[HeadOut(*h) for h in heads])
+    pw = torch.tensor(w) if w is not None else None
+    res = D.yolo_loss(size, size, out, _targets(tg), pos_weight=pw)
+    total = D.train_step_total(res, B)
+    got = np.array([res.localization.item(), res.objectness.item(), res.classification.item(), total.item()])
+    np.testing.assert_array_equal(got, g[case + ".loss"])
+    if not np.isfinite(got[3]):           # a level without matches -> NaN (reference quirk, loss.py:96)
+        assert case in ("nan_level128", "rand64")
+        assert np.isnan(got[0]) and np.isnan(got[2]) and np.isfinite(got[1])
+        return
+    total.backward()
+    for lvl, h in zip(("ll", "ml", "hl"), heads):
+        for nm, t in zip(("box", "obj", "cls"), h):
+            np.testing.assert_array_equal(t.grad.numpy(), g[f"{case}.{lvl}.{nm}.grad"])
+
+
+@pytest.mark.parametrize("case", list(synth.network_cases()))
+def test_network(golden, case):
+    g = golden("network")
+    widen, deepen, nc, B, size, seed = synth.network_cases()[case]
+    torch.manual_seed(seed)
+    net = OracleYolov5(3, nc, widen, deepen).train()
+    names = [k for k, _ in net.named_parameters()]
+    assert names == g[case + ".param_names"].tolist()
+    np.testing.assert_array_equal(
+        np.array([v.double().norm().item() for v in net.parameters()]), g[case + ".param_norms"])
+    x, tg = synth.batch(B, size, nc, seed)
+    res = net(x)
+    lr = D.yolo_loss(size, size, res, _targets(tg))
+    total = D.train_step_total(lr, B)
+    total.backward()
+    got = np.array([lr.localization.item(), lr.objectness.item(), lr.classification.item(), total.item()])
+    np.testing.assert_allclose(got, g[case + ".loss"], rtol=1e-6)
+    gn = np.array([v.grad.double().norm().item() for v in net.parameters()])
+    np.testing.assert_allclose(gn, g[case + ".grad_norms"], rtol=2e-4, atol=1e-7)
+    sd = net.state_dict()
+    rm = [k for k in sd if k.endswith("running_mean")]
+    np.testing.assert_allclose([sd[k].double().norm().item() for k in rm], g[case + ".running_mean_norms"], rtol=1e-5)
+    np.testing.assert_allclose([sd[k.replace("_mean", "_var")].double().norm().item() for k in rm],
+                               g[case + ".running_var_norms"], rtol=1e-5)
+    if size <= 64:
+        for lvl, h in zip(("ll", "ml", "hl"), res):
+            for nm, t in zip(("box", "obj", "cls"), h):
+                np.testing.assert_allclose(t.detach().numpy(), g[f"{case}.{lvl}.{nm}"], rtol=1e-5, atol=1e-6)
+
+
+def test_network_census():
+    """yv5s nc=10 has 7,046,599 params, 360 state_dict keys, 66 convs."""
+    net = OracleYolov5(3, 10, 0.5, 0.33)
+    assert sum(p.numel() for p in net.parameters()) == 7046599
+    assert len(net.state_dict()) == 360
+    assert sum(isinstance(m, torch.nn.Conv2d) for m in net.modules()) == 66
+    b, d, n = O.param_groups(net)
+    assert (len(b), len(d), len(n)) == (66, 66, 57)
+
+
+@pytest.mark.parametrize("case", list(synth.decode_cases()))
+def test_decode_nms(golden, case):
+    g = golden("decode_nms")
+    size, nc, B, seed, scale = synth.decode_cases()[case]
+    heads = synth.head_logits(B, size, nc, seed=seed, scale=scale)
+    det = D.decode(NetOut(*[HeadOut(*h) for h in heads]), size, size)
+    np.testing.assert_array_equal(det.numpy(), g[case + ".det"])
+    for conf, thr in ((0.001, 0.6), (0.25, 0.45)):
+        res = D.nms(det.clone(), conf, thr)
+        assert [r.shape[0] for r in res] == g[f"{case}.nms_{conf}_{thr}.counts"].tolist()
+        np.testing.assert_array_equal(torch.cat(res, 0).numpy(), g[f"{case}.nms_{conf}_{thr}.rows"])
+
+
+def test_optim(golden):
+    g = golden("optim")
+    assert g["group_names"].tolist() == list(O.GROUP_NAMES)
+    np.testing.assert_allclose(g["sch_linear"], [O.sch_linear(e) for e in (0, 1, 150, 299)], rtol=0, atol=0)
+    for st, lr, mom in zip(g["warmup_steps"], g["warmup_lr"], g["warmup_momentum"]):
+        w = O.warmup_values(int(st), int(st) // 220, 660)
+        np.testing.assert_array_equal([w[n][0] for n in O.GROUP_NAMES], lr)
+        np.testing.assert_array_equal([w[n][1] for n in O.GROUP_NAMES], mom)
+    # Appendix B.6 spot values
+    np.testing.assert_allclose(g["warmup_lr"][1], [0.0998636, 1.515e-05, 1.515e-05], rtol=1e-3)
+    # 5-step trajectory
+    sizes, grp = g["traj_sizes"], g["traj_group_of_param"]
+    ps = [torch.from_numpy(c.copy()) for c in np.split(g["traj_p0"], np.cumsum(sizes)[:-1])]
+    bufs = [None] * len(ps)
+    wd = g["group_wd"]
+    for st in range(5):
+        w = O.warmup_values(st, 0, 100)
+        gs = np.split(g["traj_grads"][st], np.cumsum(sizes)[:-1])
+        for i, p in enumerate(ps):
+            lr, mom = w[O.GROUP_NAMES[grp[i]]]
+            bufs[i] = O.sgd_nesterov_step(p, torch.from_numpy(gs[i].copy()), bufs[i], lr, mom, float(wd[grp[i]]))
+    np.testing.assert_allclose(np.concatenate([p.numpy() for p in ps]), g["traj_p5"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", list(synth.mosaic_cases()))
+def test_mosaic(golden, case):
+    g = golden("mosaic")
+    S, seed = synth.mosaic_cases()[case]
+    samples = synth.source_samples(4, S, seed)
+    random.seed(seed)
+    img, bb, lb, border, _ = datapath.mosaic(samples, S)
+    np.testing.assert_array_equal(bb, g[case + ".bboxes"])
+    np.testing.assert_array_equal(lb, g[case + ".labels"])
+    assert list(border) == g[case + ".border"].tolist()
+    np.testing.assert_array_equal(img.astype(np.int64).sum(axis=(1, 2)), g[case + ".image_rowsum"])
+    np.testing.assert_array_equal(img.astype(np.int64).sum(axis=(0, 2)), g[case + ".image_colsum"])
+    if S <= 64:
+        np.testing.assert_array_equal(img, g[case + ".image"])
+
+
+def test_affine_boxes_flip_mixup(golden):
+    g = golden("affine")
+    rng = np.random.default_rng(51)
+    S = 64
+    for i in range(6):
+        draws = datapath.affine_draws(rng)
+        np.testing.assert_array_equal(np.array(draws), g["rand_values"][i])
+        M, (wo, ho) = datapath.affine_matrix(draws, 2 * S, 2 * S, border=(-S // 2, -S // 2))
+        assert [wo, ho] == g["feat_shape_out"].tolist()
+        np.testing.assert_allclose(M, g["matrices"][i], rtol=0, atol=1e-12)
+        nb, keep = datapath.affine_boxes(g["boxes_in"], M, wo, ho, draws[3])
+        np.testing.assert_allclose(nb, g["boxes_out"][i], rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(keep, g["keep"][i])
+    np.testing.assert_array_equal(datapath.flip_boxes(g["boxes_in"][:3], 6), g["flip_boxes"])
+    np.random.seed(2023)
+    r = np.random.beta(32.0, 32.0)
+    a = torch.arange(24, dtype=torch.float32).reshape(3, 2, 4) / 24
+    b = torch.arange(24, dtype=torch.float32).flip(0).reshape(3, 2, 4) / 24
+    np.testing.assert_array_equal(datapath.mixup_blend(a, b, r).numpy(), g["mixup_image"])
