@@ -1,0 +1,127 @@
+/* libkodhip - C ABI of the MI355X-native YOLOv5 training hot path for `kod`
+ * (craston/object_detection_cib).
+ *
+ * The reference has no FFI: its seam is Hydra `_target_` instantiation of Python classes
+ * (kod/configs/nn/networks/yv5.yaml:1, kod/configs/nn/losses/yv5.yaml:4, kod/configs/assigners/yv5.yaml:6)
+ * whose arithmetic is reached through aten / torchvision ops.  Each entry point below replaces the aten
+ * op(s) a reference call site asks for; INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *   - the library never allocates, frees or retains device memory and never synchronises: work is
+ *     enqueued on `stream` (pass torch.cuda.current_stream().cuda_stream);
+ *   - return 0 = OK, <0 = argument error (nothing launched), >0 = hipError_t; kodhip_last_error() gives
+ *     the message (thread local);
+ *   - activations are channels-last bf16 [B][H][W][ld]; a tensor may be a channel slice (ld, coff) of a
+ *     wider concat buffer - that is how torch.cat (csp.py:109, sppf.py:76, yolov5_pafpn.py:186,199)
+ *     disappears; all channel counts / offsets are multiples of 8 (16-byte accesses).
+ */
+#ifndef KODHIP_H
+#define KODHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* kodStream_t;
+
+const char* kodhip_last_error(void);
+int kodhip_version(void);
+int kodhip_device_count(void);
+
+/* ---- layout / packing ------------------------------------------------------------------------- */
+/* Lightning batch_to_device + first conv input: NCHW fp32 image -> [B][H][W][4] bf16 (C<=4, zero pad). */
+int kodhip_nchw_to_nhwc4(const float* x, void* y, int B, int C, int H, int W, kodStream_t stream);
+/* fp32 master weights (state_dict layout [Cout][Cin][KH][KW]) -> bf16 MFMA packs; descs = device array of
+ * int64[13] rows {w_off,f_off,d_off,N,Cin,KH,KW,Kp,Kdp,Ntot,n_off,stem,blk_begin}. */
+int kodhip_pack_weights(const float* master, void* fpack, void* dpack, const void* descs, int nlayers,
+                        long total_blocks, kodStream_t stream);
+int kodhip_pack_desc_bytes(void);
+
+/* ---- convolution (aten::convolution / convolution_backward; call sites kod/nn/layers/csp.py:30-46,
+ *      kod/nn/layers/sppf.py:29-36,61-67, kod/nn/backbones/yolov5.py:44-52,102-110,
+ *      kod/nn/necks/yolov5_pafpn.py:61-73,110-122,152-166) ------------------------------------------ */
+int kodhip_conv_stats_slots(long M, int N);
+int kodhip_conv_fwd_raw(const void* x, const void* w_packed, void* y, float* stats,
+                        int B, int H, int W, int ldx, int xcoff, int Cin,
+                        int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                        int ldy, int ycoff, kodStream_t stream);
+/* three biased 1x1 head convs of one level fused (kod/nn/heads/yolov5.py:12-136), out [B][A][H*W][5+nc] fp32 */
+int kodhip_conv_fwd_head(const void* x, const void* w_packed, const float* bias, float* out,
+                         int B, int H, int W, int ldx, int xcoff, int Cin, int A, int nc, int Kp,
+                         kodStream_t stream);
+int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
+                      int B, int H, int W, int ldx, int xcoff, int Cin,
+                      int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                      int ldy, int ycoff, int accumulate, kodStream_t stream);
+int kodhip_conv_wgrad_splits(long M, int N, int Kp);
+int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* grad,
+                      int B, int H, int W, int ldx, int xcoff, int Cin,
+                      int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                      int ldy, int ycoff, int n_valid, int stem, float scale, kodStream_t stream);
+
+/* ---- BatchNorm2d(eps 1e-3, momentum .03) + SiLU (kod/nn/networks/yolov5.py:24,
+ *      kod/nn/layers/activations.py:7; aten::native_batch_norm(+backward), silu(+backward)) ---------- */
+int kodhip_bn_reduce_partials(const float* partials, double* sums, int C, int T, kodStream_t stream);
+int kodhip_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps,
+                       float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
+                       kodStream_t stream);
+int kodhip_bn_silu_apply(const void* y, const float* scale, const float* shift,
+                         const void* residual, int ldr, int rcoff,
+                         void* out, int ldo, int ocoff, long M, int C, kodStream_t stream);
+int kodhip_bn_bwd_slots(long M, int C);
+int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, float* partials,
+                              long M, int C, kodStream_t stream);
+int kodhip_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const float* gamma,
+                         const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
+                         kodStream_t stream);
+int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, const float* scale,
+                             const float* shift, const float* coef, void* dI, int ldi, int dicoff, int di_accum,
+                             long M, int C, kodStream_t stream);
+
+/* ---- SPPF max-pool, nearest upsample (kod/nn/layers/sppf.py:46-50,73-76,
+ *      kod/nn/necks/yolov5_pafpn.py:144-146,182-184) ------------------------------------------------- */
+int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff, void* idx,
+                        int B, int H, int W, int C, kodStream_t stream);
+int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, void* dx, int ldx, int xcoff,
+                        int B, int H, int W, int C, kodStream_t stream);
+int kodhip_upsample2x_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff,
+                          int B, int H, int W, int C, kodStream_t stream);
+int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx, int xcoff, int accumulate,
+                          int B, int H, int W, int C, kodStream_t stream);
+int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_box, float* db_obj, float* db_cls,
+                         int B, int HW, int A, int nc, int Npad, kodStream_t stream);
+
+/* ---- optimizer (torch.optim.SGD nesterov as grouped by kod/nn/optim/smart.py:36-58) --------------- */
+int kodhip_sgd_nesterov(float* params, const float* grads, float* momentum_buf, const void* group_ids,
+                        long n, const float* hyper /* host, 10 floats */, kodStream_t stream);
+int kodhip_fill_u32(void* p, uint32_t value, long n, kodStream_t stream);
+
+/* ---- target assignment + loss (kod/core/label_assignment/yv5.py:45-319,
+ *      kod/lightning/experiments/yv5_baseline/loss.py:65-248, kod/core/bbox/iou.py:200-246) ---------- */
+typedef struct KodAssignLevel {
+  int* idx; int* label; float* gt; float* anc; int* count;
+  float anchor_w[3], anchor_h[3];
+  int stride;
+} KodAssignLevel;
+int kodhip_assign_targets(const double* boxes, const long* labels, const int* samples, int n, int cap,
+                          int img_w, int img_h, float threshold, const KodAssignLevel* levels /* host[3] */,
+                          kodStream_t stream);
+typedef struct KodLossLevel {
+  const float* logits; float* grad;
+  const int* idx; const int* label; const float* gt; const float* anc; const int* count;
+  int* cellmaps; float* rowgrad; float* tobj;
+  int fh, fw;
+  float balance;
+} KodLossLevel;
+int kodhip_yolo_loss(const KodLossLevel* levels /* host[3] */, int B, int A, int nc, int cap,
+                     float lam_box, float lam_obj, float lam_cls, const float* pos_weight,
+                     const float* upstream, float* partials, int nslots, float* out, int compute_grad,
+                     kodStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KODHIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libkodhip.so (include/kodhip.h).  Fails loudly when the library is missing:
+there is no CPU / PyTorch fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkodhip.so")
+
+vp, i32, i64, f32, f64, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint32
+
+
+class KodAssignLevel(C.Structure):
+    _fields_ = [("idx", vp), ("label", vp), ("gt", vp), ("anc", vp), ("count", vp),
+                ("anchor_w", f32 * 3), ("anchor_h", f32 * 3), ("stride", i32)]
+
+
+class KodLossLevel(C.Structure):
+    _fields_ = [("logits", vp), ("grad", vp), ("idx", vp), ("label", vp), ("gt", vp), ("anc", vp),
+                ("count", vp), ("cellmaps", vp), ("rowgrad", vp), ("tobj", vp),
+                ("fh", i32), ("fw", i32), ("balance", f32)]
+
+
+# name -> (restype, argtypes); mirrors include/kodhip.h one to one (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    "kodhip_last_error": (C.c_char_p, []),
+    "kodhip_version": (i32, []),
+    "kodhip_device_count": (i32, []),
+    "kodhip_nchw_to_nhwc4": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "kodhip_pack_weights": (i32, [vp, vp, vp, vp, i32, i64, vp]),
+    "kodhip_pack_desc_bytes": (i32, []),
+    "kodhip_conv_stats_slots": (i32, [i64, i32]),
+    "kodhip_conv_fwd_raw": (i32, [vp, vp, vp, vp] + [i32] * 16 + [vp]),
+    "kodhip_conv_fwd_head": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp]),
+    "kodhip_conv_dgrad": (i32, [vp, vp, vp] + [i32] * 17 + [vp]),
+    "kodhip_conv_wgrad_splits": (i32, [i64, i32, i32]),
+    "kodhip_conv_wgrad": (i32, [vp, vp, vp, vp] + [i32] * 18 + [f32, vp]),
+    "kodhip_bn_reduce_partials": (i32, [vp, vp, i32, i32, vp]),
+    "kodhip_bn_finalize": (i32, [vp, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
+    "kodhip_bn_silu_apply": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, vp]),
+    "kodhip_bn_bwd_slots": (i32, [i64, i32]),
+    "kodhip_bn_silu_bwd_reduce": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "kodhip_bn_bwd_coeffs": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "kodhip_bn_silu_bwd_apply": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i64, i32, vp]),
+    "kodhip_maxpool5_fwd": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, vp]),
+    "kodhip_maxpool5_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "kodhip_upsample2x_fwd": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "kodhip_upsample2x_bwd": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "kodhip_head_bwd_prep": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "kodhip_sgd_nesterov": (i32, [vp, vp, vp, vp, i64, C.POINTER(f32), vp]),
+    "kodhip_fill_u32": (i32, [vp, u32, i64, vp]),
+    "kodhip_assign_targets": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, C.POINTER(KodAssignLevel), vp]),
+    "kodhip_yolo_loss": (i32, [C.POINTER(KodLossLevel), i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp,
+                               i32, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if libkodhip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m object_detection_cib_amd.build` "
+                "(hipcc, gfx950).  There is no CPU fallback for the HIP hot path.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().kodhip_last_error().decode(errors="replace")
+        raise RuntimeError(f"libkodhip {what} failed (rc={rc}): {msg}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("object_detection_cib_amd: the HIP hot path needs an MI355X (no CPU fallback)")
+    lib()

@@ -1,0 +1,273 @@
+// Train-mode BatchNorm2d(eps=1e-3, momentum=.03) + SiLU around the conv kernels
+// (kod/nn/networks/yolov5.py:24 Yolov5BatchNorm2d, kod/nn/layers/activations.py:7 SiLUInplace; the
+// aten ops native_batch_norm / silu / their backwards and the CSPBlock residual add, csp.py:55-56).
+//
+// All tensors are channels-last bf16; per-channel statistics are fp32/fp64.  HBM-bound elementwise
+// kernels: 16-byte (8-channel) accesses, each thread keeps a fixed channel chunk so the per-channel
+// constants live in registers; reductions are wavefront shuffles -> LDS -> fixed-order partial slabs
+// (deterministic, no float atomics).
+#include "kodhip_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- partial slabs -> fp64 sums
+// in: part[2][C][T] fp32 ; out: sums[2][C] fp64.  One wave per (stat, channel).
+__global__ void bn_reduce_partials_kernel(const float* part, double* sums, int C, int T) {
+  int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (idx >= 2 * C) return;
+  int lane = threadIdx.x & 63;
+  const float* p = part + (size_t)idx * T;
+  double s = 0.0;
+  for (int t = lane; t < T; t += 64) s += (double)p[t];
+  s = wave_sum_d(s);
+  if (lane == 0) sums[idx] = s;
+}
+
+// forward finalize: sums (already all-reduced over ranks when SyncBN) -> affine constants + running stats
+__global__ void bn_finalize_kernel(const double* sums, double count, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps,
+                                   float* scale, float* shift, float* mean_out, float* rstd_out, int C,
+                                   int update_running) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float g = gamma[c], b = beta[c];
+  float sc = g * rstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  if (update_running) {
+    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// ---------------------------------------------------------------- forward apply
+// out[m][ocoff + c] = silu(y[m][c]*scale[c] + shift[c]) (+ res[m][rcoff + c])
+__global__ void bn_silu_apply_kernel(const bf16_t* y, const float* scale, const float* shift,
+                                     const bf16_t* res, int ldr, int rcoff,
+                                     bf16_t* out, int ldo, int ocoff, long M, int C, int rows_per_block_iter) {
+  const int CC = C >> 3;
+  const int cc = threadIdx.x % CC;
+  const int rl = threadIdx.x / CC;
+  if (rl >= rows_per_block_iter) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; }
+  for (long m = (long)blockIdx.x * rows_per_block_iter + rl; m < M; m += (long)gridDim.x * rows_per_block_iter) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+    bf16x8 o;
+    if (res) {
+      bf16x8 r = *reinterpret_cast<const bf16x8*>(res + m * ldr + rcoff + cc * 8);
+#pragma unroll
+      // the reference adds in fp32 on the fp32 activation; here the activation is rounded to bf16 first
+      // only when it is materialised, so add before the single rounding.
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(silu_f((float)v[e] * sc[e] + sh[e]) + (float)r[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)silu_f((float)v[e] * sc[e] + sh[e]);
+    }
+    *reinterpret_cast<bf16x8*>(out + m * ldo + ocoff + cc * 8) = o;
+  }
+}
+
+// ---------------------------------------------------------------- backward reduce
+// dz = dA * silu'(z), z = y*scale + shift ; xhat = (y - mean)*rstd
+// part[0][c][blk] = sum dz ; part[1][c][blk] = sum dz*xhat
+__global__ void bn_silu_bwd_reduce_kernel(const bf16_t* dA, int lda, int dacoff, const bf16_t* y,
+                                          const float* scale, const float* shift, const float* mean,
+                                          const float* rstd, float* part, long M, int C, int rpb) {
+  extern __shared__ float sm[];   // [rpb][CC][16]
+  const int CC = C >> 3;
+  const int cc = threadIdx.x % CC;
+  const int rl = threadIdx.x / CC;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+  if (rl < rpb) {
+    float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; mu[e] = mean[cc * 8 + e]; rs[e] = rstd[cc * 8 + e];
+    }
+    for (long m = (long)blockIdx.x * rpb + rl; m < M; m += (long)gridDim.x * rpb) {
+      bf16x8 g = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float yv = (float)v[e];
+        float z = yv * sc[e] + sh[e];
+        float sg = sigmoid_f(z);
+        float dz = (float)g[e] * sg * (1.f + z * (1.f - sg));
+        s0[e] += dz;
+        s1[e] += dz * (yv - mu[e]) * rs[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sm[(rl * CC + cc) * 16 + e] = s0[e];
+      sm[(rl * CC + cc) * 16 + 8 + e] = s1[e];
+    }
+  }
+  __syncthreads();
+  // fixed-order reduction over the row lanes
+  for (int i = threadIdx.x; i < CC * 16; i += blockDim.x) {
+    int c8 = i >> 4, e = i & 15;
+    float s = 0.f;
+    for (int r = 0; r < rpb; ++r) s += sm[(r * CC + c8) * 16 + e];
+    int st = e >> 3, ch = c8 * 8 + (e & 7);
+    part[((size_t)st * C + ch) * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// grads from the LOCAL sums; coefficients from the (all-reduced) sums:
+//   dY = k1*dz + k2*y + k3,  k1 = g*rstd, k2 = -g*rstd^2*S1/n, k3 = -g*rstd*S0/n + g*rstd^2*mean*S1/n
+__global__ void bn_bwd_coeffs_kernel(const double* sums_local, const double* sums_global, double count,
+                                     const float* gamma, const float* mean, const float* rstd,
+                                     float* dgamma, float* dbeta, float* coef, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)sums_local[c];
+  dgamma[c] = (float)sums_local[C + c];
+  double g = gamma[c], rs = rstd[c], mu = mean[c];
+  double S0 = sums_global[c] / count, S1 = sums_global[C + c] / count;
+  coef[c] = (float)(g * rs);
+  coef[C + c] = (float)(-g * rs * rs * S1);
+  coef[2 * C + c] = (float)(-g * rs * S0 + g * rs * rs * mu * S1);
+}
+
+// dY (bf16, written in place over y) ; optional identity gradient: dI[m][c] (+)= dA[m][c]
+__global__ void bn_silu_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, bf16_t* y,
+                                         const float* scale, const float* shift, const float* coef,
+                                         bf16_t* dI, int ldi, int dicoff, int di_accum,
+                                         long M, int C, int rpb) {
+  const int CC = C >> 3;
+  const int cc = threadIdx.x % CC;
+  const int rl = threadIdx.x / CC;
+  if (rl >= rpb) return;
+  float sc[8], sh[8], k1[8], k2[8], k3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int c = cc * 8 + e;
+    sc[e] = scale[c]; sh[e] = shift[c]; k1[e] = coef[c]; k2[e] = coef[C + c]; k3[e] = coef[2 * C + c];
+  }
+  for (long m = (long)blockIdx.x * rpb + rl; m < M; m += (long)gridDim.x * rpb) {
+    bf16x8 g = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float yv = (float)v[e];
+      float z = yv * sc[e] + sh[e];
+      float sg = sigmoid_f(z);
+      float dz = (float)g[e] * sg * (1.f + z * (1.f - sg));
+      o[e] = (bf16_t)(k1[e] * dz + k2[e] * yv + k3[e]);
+    }
+    *reinterpret_cast<bf16x8*>(y + m * C + cc * 8) = o;
+    if (dI) {
+      bf16_t* d = dI + m * ldi + dicoff + cc * 8;
+      if (di_accum) {
+        bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (bf16_t)((float)g[e] + (float)old[e]);
+      }
+      *reinterpret_cast<bf16x8*>(d) = g;
+    }
+  }
+}
+
+struct Geo { int threads, rpb, grid; };
+Geo geo(long M, int C, int max_blocks) {
+  int CC = C / 8;
+  int rpb = 256 / CC;
+  if (rpb < 1) rpb = 1;
+  Geo g;
+  g.rpb = rpb;
+  g.threads = ((rpb * CC + 63) / 64) * 64;
+  long blocks = (M + rpb - 1) / rpb;
+  g.grid = (int)(blocks < max_blocks ? blocks : max_blocks);
+  if (g.grid < 1) g.grid = 1;
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kodhip_bn_reduce_partials(const float* partials, double* sums, int C, int T, hipStream_t stream) {
+  KOD_CHECK_ARG(partials && sums && C > 0 && T > 0, "bn_reduce_partials: bad args");
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, stream, partials, sums, C, T);
+  KOD_LAUNCH_CHECK("bn_reduce_partials");
+  return KOD_OK;
+}
+
+int kodhip_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps,
+                       float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
+                       hipStream_t stream) {
+  KOD_CHECK_ARG(sums && gamma && beta && scale && shift && mean && rstd && C > 0 && count > 0, "bn_finalize: bad args");
+  KOD_CHECK_ARG(!update_running || (running_mean && running_var), "bn_finalize: running stats missing");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, sums, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, scale, shift, mean, rstd, C, update_running);
+  KOD_LAUNCH_CHECK("bn_finalize");
+  return KOD_OK;
+}
+
+int kodhip_bn_silu_apply(const void* y, const float* scale, const float* shift,
+                         const void* residual, int ldr, int rcoff,
+                         void* out, int ldo, int ocoff, long M, int C, hipStream_t stream) {
+  KOD_CHECK_ARG(y && scale && shift && out && M > 0, "bn_silu_apply: bad args");
+  KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldo % 8 == 0 && ocoff % 8 == 0 && ocoff + C <= ldo, "bn_silu_apply: bad channel geometry");
+  KOD_CHECK_ARG(!residual || (ldr % 8 == 0 && rcoff % 8 == 0 && rcoff + C <= ldr), "bn_silu_apply: bad residual slice");
+  Geo g = geo(M, C, 4096);
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, scale, shift,
+                     (const bf16_t*)residual, ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb);
+  KOD_LAUNCH_CHECK("bn_silu_apply");
+  return KOD_OK;
+}
+
+int kodhip_bn_bwd_slots(long M, int C) { return geo(M, C, 1024).grid; }
+
+int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, float* partials,
+                              long M, int C, hipStream_t stream) {
+  KOD_CHECK_ARG(dA && y && scale && shift && mean && rstd && partials && M > 0, "bn_silu_bwd_reduce: bad args");
+  KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda, "bn_silu_bwd_reduce: bad geometry");
+  Geo g = geo(M, C, 1024);
+  size_t shm = (size_t)g.rpb * (C / 8) * 16 * sizeof(float);
+  hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(g.grid), dim3(g.threads), shm, stream, (const bf16_t*)dA, lda,
+                     dacoff, (const bf16_t*)y, scale, shift, mean, rstd, partials, M, C, g.rpb);
+  KOD_LAUNCH_CHECK("bn_silu_bwd_reduce");
+  return KOD_OK;
+}
+
+int kodhip_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const float* gamma,
+                         const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
+                         hipStream_t stream) {
+  KOD_CHECK_ARG(sums_local && sums_global && gamma && mean && rstd && dgamma && dbeta && coef && C > 0 && count > 0,
+                "bn_bwd_coeffs: bad args");
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, sums_local, sums_global, count,
+                     gamma, mean, rstd, dgamma, dbeta, coef, C);
+  KOD_LAUNCH_CHECK("bn_bwd_coeffs");
+  return KOD_OK;
+}
+
+int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, const float* scale,
+                             const float* shift, const float* coef, void* dI, int ldi, int dicoff, int di_accum,
+                             long M, int C, hipStream_t stream) {
+  KOD_CHECK_ARG(dA && y_inout && scale && shift && coef && M > 0, "bn_silu_bwd_apply: bad args");
+  KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda, "bn_silu_bwd_apply: bad geometry");
+  KOD_CHECK_ARG(!dI || (ldi % 8 == 0 && dicoff % 8 == 0 && dicoff + C <= ldi), "bn_silu_bwd_apply: bad identity slice");
+  Geo g = geo(M, C, 4096);
+  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)dA, lda, dacoff,
+                     (bf16_t*)y_inout, scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb);
+  KOD_LAUNCH_CHECK("bn_silu_bwd_apply");
+  return KOD_OK;
+}
+
+}  // extern "C"

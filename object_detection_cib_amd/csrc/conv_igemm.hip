@@ -1,0 +1,401 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4): bf16 MFMA 32x32x16, fp32 accumulate.
+//
+// One kernel serves
+//   * forward conv  (kod.nn conv+BN+SiLU units: torchvision Conv2dNormActivation as used at
+//     kod/nn/layers/csp.py:30-46,81-89, kod/nn/backbones/yolov5.py:44-52,102-110, ...)  -> mode RAW:
+//     bf16 pre-BN output + per-channel sum / sum-of-squares partials for train-mode BatchNorm
+//   * the three biased 1x1 head convs per level (kod/nn/heads/yolov5.py:12-136) fused into one GEMM
+//     -> mode HEAD: fp32 output scattered into [B, A, h, w, 5+nc]
+//   * data gradient (aten::convolution_backward dX) as a gather-form transposed conv -> mode PLAIN
+//
+// Data layout: activations channels-last [B, H, W, ld] bf16 (a tensor may be a channel slice of a
+// wider concat buffer: ld / channel offset), weights pre-packed [N][Kp] with k = (kh, kw, ci),
+// k-contiguous, so both MFMA operands are 16-byte k-runs.
+//
+// Tiling: block = 256 threads (4 waves), tile 128(M pixels) x BN(out channels) x 32(K); operands are
+// staged global -> registers -> LDS (double buffered, 80-byte padded rows => conflict-free
+// ds_read_b128); the MFMA is issued "transposed" (A operand = weights, B operand = pixels) so each lane
+// ends up with 4 consecutive output channels per accumulator quad and the epilogue can stage the tile
+// through LDS with ds_write_b64 and leave the chip as full 16-byte channel-contiguous stores.
+// Blocks are persistent over M tiles (fixed N tile) so BatchNorm partial statistics are reduced in
+// registers and written once per block; block ids are laid out so the N tiles that share an M tile
+// land on the same XCD (same L2).
+#include "kodhip_common.h"
+
+namespace {
+
+enum { MODE_RAW = 0, MODE_PLAIN = 1, MODE_HEAD = 2 };
+
+struct ConvArgs {
+  const bf16_t* x;
+  const bf16_t* w;
+  bf16_t* y;
+  float* stats;
+  const float* bias;
+  float* head_out;
+  int B, Hs, Ws, ldx, xcoff, Cin;
+  int Ho, Wo, M;
+  int N, K, Kp;
+  int KH, KW;
+  int mul_h, mul_w, add_h, add_w, tap_sign, sh_shift, sw_shift;
+  int ldy, ycoff, accumulate;
+  int head_A, head_P, head_nc;
+  uint32_t magic_cin, magic_kw;
+  int tiles_m, tiles_n, groups_m;
+};
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDS_ROW = BK + 8;   // bf16 elements per staged row (80 bytes)
+
+template <int BN, int WAVES_M, int WAVES_N, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int WM = BM / WAVES_M;          // pixels per wave
+  constexpr int WN = BN / WAVES_N;          // channels per wave
+  constexpr int TM = WM / 32;
+  constexpr int TN = WN / 32;
+  constexpr int B_CHUNKS = BN * 4;          // 16-byte chunks in the weight tile
+  constexpr int B_PER_THREAD = (B_CHUNKS + 255) / 256;
+  constexpr int STAGE_ELEMS = (BM + BN) * LDS_ROW;
+  constexpr int CS_ROW = BN + 8;            // epilogue staging row (bf16)
+  constexpr int LDS_ELEMS = (2 * STAGE_ELEMS > BM * CS_ROW) ? 2 * STAGE_ELEMS : BM * CS_ROW;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[LDS_ELEMS];
+  __shared__ float sred[4 * BN * 2];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+
+  // XCD-aware block -> (m group, n tile): blocks b and b+8 share an XCD.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int j = bid >> 3;
+  const int nt = j % a.tiles_n;
+  const int gm = (j / a.tiles_n) * 8 + xcd;
+  if (gm >= a.groups_m) return;
+  const int n0 = nt * BN;
+
+  // staging assignment
+  const int a_chunk = tid & 3;              // which 8-element k chunk of the 32-wide K tile
+  const int a_row = tid >> 2;               // rows a_row and a_row + 64
+  const int HWs = a.Hs * a.Ws;
+  const int HWo = a.Ho * a.Wo;
+
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
+
+  const int nk = a.Kp / BK;
+
+  for (int mt = gm; mt < a.tiles_m; mt += a.groups_m) {
+    const int m0 = mt * BM;
+    // ---- per-thread gather rows
+    int rbase[2], rby[2], rbx[2];
+    bool rvalid[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int m = m0 + a_row + r * 64;
+      rvalid[r] = m < a.M;
+      int mm = rvalid[r] ? m : 0;
+      int b = mm / HWo;
+      int rem = mm - b * HWo;
+      int oy = rem / a.Wo;
+      int ox = rem - oy * a.Wo;
+      rbase[r] = b * HWs;
+      rby[r] = oy * a.mul_h + a.add_h;
+      rbx[r] = ox * a.mul_w + a.add_w;
+    }
+
+    u32x4 areg[2];
+    u32x4 breg[B_PER_THREAD];
+
+    auto load_tile = [&](int kt) {
+      const int k = kt * BK + a_chunk * 8;
+      const uint32_t tap = __umulhi((uint32_t)k, a.magic_cin);
+      const int ci = k - (int)tap * a.Cin;
+      const uint32_t kh = (a.KW == 1) ? tap : __umulhi(tap, a.magic_kw);
+      const int kw = (int)tap - (int)kh * a.KW;
+      const bool kvalid = k < a.K;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        int ty = rby[r] + a.tap_sign * (int)kh;
+        int tx = rbx[r] + a.tap_sign * kw;
+        bool ok = rvalid[r] && kvalid && ty >= 0 && tx >= 0 &&
+                  ((ty & ((1 << a.sh_shift) - 1)) == 0) && ((tx & ((1 << a.sw_shift) - 1)) == 0);
+        int iy = ty >> a.sh_shift;
+        int ix = tx >> a.sw_shift;
+        ok = ok && iy < a.Hs && ix < a.Ws;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) {
+          size_t off = (size_t)(rbase[r] + iy * a.Ws + ix) * a.ldx + a.xcoff + ci;
+          v = *reinterpret_cast<const u32x4*>(a.x + off);
+        }
+        areg[r] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < B_PER_THREAD; ++q) {
+        int c = tid + q * 256;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (c < B_CHUNKS) {
+          int n = n0 + (c >> 2);
+          if (n < a.N) v = *reinterpret_cast<const u32x4*>(a.w + (size_t)n * a.Kp + kt * BK + (c & 3) * 8);
+        }
+        breg[q] = v;
+      }
+    };
+    auto store_tile = [&](int buf) {
+      bf16_t* As = lds + buf * STAGE_ELEMS;
+      bf16_t* Bs = As + BM * LDS_ROW;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        *reinterpret_cast<u32x4*>(As + (a_row + r * 64) * LDS_ROW + a_chunk * 8) = areg[r];
+#pragma unroll
+      for (int q = 0; q < B_PER_THREAD; ++q) {
+        int c = tid + q * 256;
+        if (c < B_CHUNKS) *reinterpret_cast<u32x4*>(Bs + (c >> 2) * LDS_ROW + (c & 3) * 8) = breg[q];
+      }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int jj = 0; jj < TM; ++jj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 31;
+    const int fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load_tile(kt + 1);
+      const bf16_t* As = lds + buf * STAGE_ELEMS;
+      const bf16_t* Bs = As + BM * LDS_ROW;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 wf[TN], xf[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          wf[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WN + i * 32 + fr) * LDS_ROW + ks * 16 + fh * 8);
+#pragma unroll
+        for (int jj = 0; jj < TM; ++jj)
+          xf[jj] = *reinterpret_cast<const bf16x8*>(As + (wm * WM + jj * 32 + fr) * LDS_ROW + ks * 16 + fh * 8);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int jj = 0; jj < TM; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[jj], acc[i][jj], 0, 0, 0);
+      }
+      if (kt + 1 < nk) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+
+    // ---- epilogue.  acc[i][jj][e]: pixel = wm*WM + jj*32 + (lane&31),
+    //      channel = wn*WN + i*32 + 8*(e>>2) + 4*(lane>>5) + (e&3)
+    if constexpr (MODE == MODE_HEAD) {
+#pragma unroll
+      for (int jj = 0; jj < TM; ++jj) {
+        int m = m0 + wm * WM + jj * 32 + fr;
+        if (m < a.M) {
+          int b = m / HWo;
+          int pix = m - b * HWo;
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              int n = n0 + wn * WN + i * 32 + 8 * (e >> 2) + 4 * fh + (e & 3);
+              if (n < a.N) {
+                int an, slot;
+                if (n < 4 * a.head_A) { an = n >> 2; slot = n & 3; }
+                else if (n < 5 * a.head_A) { an = n - 4 * a.head_A; slot = 4; }
+                else { int q = n - 5 * a.head_A; an = q / a.head_nc; slot = 5 + q - an * a.head_nc; }
+                a.head_out[((size_t)(b * a.head_A + an) * HWo + pix) * a.head_P + slot] = acc[i][jj][e] + a.bias[n];
+              }
+            }
+        }
+      }
+    } else {
+      bf16_t* Cs = lds;
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TM; ++jj)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (bf16_t)acc[i][jj][g * 4 + e];
+            *reinterpret_cast<bf16x4*>(Cs + (wm * WM + jj * 32 + fr) * CS_ROW + wn * WN + i * 32 + 8 * g + 4 * fh) = v;
+          }
+      __syncthreads();
+      constexpr int CPR = BN / 8;            // 16-byte chunks per row
+      constexpr int RPP = 256 / CPR;         // rows per pass
+      const int c = tid % CPR;
+      const int r0 = tid / CPR;
+      const int n = n0 + c * 8;
+#pragma unroll
+      for (int p = 0; p < BM / RPP; ++p) {
+        int row = r0 + p * RPP;
+        int m = m0 + row;
+        if (m < a.M && n < a.N) {
+          bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS_ROW + c * 8);
+          bf16_t* dst = a.y + (size_t)m * a.ldy + a.ycoff + n;
+          if constexpr (MODE == MODE_PLAIN) {
+            if (a.accumulate) {
+              bf16x8 o = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)o[e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float f = (float)v[e];
+              ssum[e] += f;
+              ssq[e] += f * f;
+            }
+          }
+          *reinterpret_cast<bf16x8*>(dst) = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  if constexpr (MODE == MODE_RAW) {
+    constexpr int CPR = BN / 8;
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ssum[e] += __shfl_xor(ssum[e], o, 64);
+        ssq[e] += __shfl_xor(ssq[e], o, 64);
+      }
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sred[(wave * BN + lane * 8 + e) * 2 + 0] = ssum[e];
+        sred[(wave * BN + lane * 8 + e) * 2 + 1] = ssq[e];
+      }
+    }
+    __syncthreads();
+    if (tid < BN * 2) {
+      int ch = tid >> 1, st = tid & 1;
+      // lanes of different waves cover the same chunk set only when CPR divides the wave evenly:
+      // thread t handles chunk t % CPR, so every wave holds every chunk (CPR <= 64).
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += sred[(w * BN + ch) * 2 + st];
+      int nn = n0 + ch;
+      if (nn < a.N) a.stats[((size_t)st * a.N + nn) * a.groups_m + gm] = s;
+    }
+  }
+}
+
+template <int MODE>
+int launch(const ConvArgs& a, hipStream_t stream) {
+  ConvArgs args = a;
+  int bn = (a.N >= 128) ? 128 : (a.N > 32 ? 64 : 32);
+  args.tiles_n = cdiv(a.N, bn);
+  args.tiles_m = cdiv(a.M, BM);
+  int target = 768 / args.tiles_n;
+  if (target < 8) target = 8;
+  int gm = args.tiles_m < target ? args.tiles_m : target;
+  args.groups_m = gm;
+  int grid = cdiv(gm, 8) * 8 * args.tiles_n;
+  if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 2, MODE>), dim3(grid), dim3(256), 0, stream, args);
+  else if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, 2, 2, MODE>), dim3(grid), dim3(256), 0, stream, args);
+  else hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1, MODE>), dim3(grid), dim3(256), 0, stream, args);
+  KOD_LAUNCH_CHECK("conv_igemm");
+  return KOD_OK;
+}
+
+int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
+
+}  // namespace
+
+extern "C" {
+
+// Number of per-channel partial slots the forward kernel writes: stats buffer must hold
+// 2 * N * kodhip_conv_stats_slots(M, N) floats.
+int kodhip_conv_stats_slots(long M, int N) {
+  int bn = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
+  int tiles_n = cdiv(N, bn);
+  int tiles_m = cdiv(M, BM);
+  int target = 768 / tiles_n;
+  if (target < 8) target = 8;
+  return tiles_m < target ? tiles_m : target;
+}
+
+static int fill_common(ConvArgs& a, const void* x, const void* w, int B, int Hs, int Ws, int ldx, int xcoff,
+                       int Cin, int Ho, int Wo, int N, int KH, int KW, int Kp) {
+  KOD_CHECK_ARG(x && w, "conv: null pointer");
+  KOD_CHECK_ARG(B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0 && N > 0, "conv: bad dims");
+  KOD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0, "conv: channels must be multiples of 8 (Cin=%d ldx=%d off=%d)", Cin, ldx, xcoff);
+  KOD_CHECK_ARG(xcoff + Cin <= ldx, "conv: channel slice out of range");
+  KOD_CHECK_ARG(Kp % 32 == 0 && Kp >= KH * KW * Cin, "conv: Kp=%d must be a multiple of 32 covering K=%d", Kp, KH * KW * Cin);
+  KOD_CHECK_ARG((long)B * Hs * Ws < (1l << 31) / 1 && (long)B * Ho * Wo < (1l << 31), "conv: pixel count overflows int32");
+  a.x = (const bf16_t*)x; a.w = (const bf16_t*)w;
+  a.B = B; a.Hs = Hs; a.Ws = Ws; a.ldx = ldx; a.xcoff = xcoff; a.Cin = Cin;
+  a.Ho = Ho; a.Wo = Wo; a.M = B * Ho * Wo; a.N = N; a.K = KH * KW * Cin; a.Kp = Kp; a.KH = KH; a.KW = KW;
+  a.magic_cin = magic_u32((uint32_t)Cin); a.magic_kw = magic_u32((uint32_t)KW);
+  return KOD_OK;
+}
+
+// Forward conv of a conv+BN+SiLU unit: y_raw[M][ldy] (bf16) + BatchNorm partials stats[2][N][slots].
+int kodhip_conv_fwd_raw(const void* x, const void* w_packed, void* y, float* stats,
+                        int B, int H, int W, int ldx, int xcoff, int Cin,
+                        int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                        int ldy, int ycoff, hipStream_t stream) {
+  ConvArgs a = {};
+  int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
+  int rc = fill_common(a, x, w_packed, B, H, W, ldx, xcoff, Cin, Ho, Wo, N, KH, KW, Kp);
+  if (rc) return rc;
+  KOD_CHECK_ARG(y && stats, "conv_fwd_raw: null output");
+  KOD_CHECK_ARG(N % 8 == 0 && ldy % 8 == 0 && ycoff % 8 == 0 && ycoff + N <= ldy, "conv_fwd_raw: bad output slice");
+  a.y = (bf16_t*)y; a.stats = stats; a.ldy = ldy; a.ycoff = ycoff;
+  a.mul_h = SH; a.mul_w = SW; a.add_h = -PH; a.add_w = -PW; a.tap_sign = 1; a.sh_shift = 0; a.sw_shift = 0;
+  return launch<MODE_RAW>(a, stream);
+}
+
+// Fused detection head of one level: out[B][A][Ho*Wo][P] fp32 = 1x1 conv (N = A*(5+nc) packed as
+// box(4A) | obj(A) | cls(nc*A)) + bias.
+int kodhip_conv_fwd_head(const void* x, const void* w_packed, const float* bias, float* out,
+                         int B, int H, int W, int ldx, int xcoff, int Cin, int A, int nc, int Kp,
+                         hipStream_t stream) {
+  ConvArgs a = {};
+  int N = A * (5 + nc);
+  int rc = fill_common(a, x, w_packed, B, H, W, ldx, xcoff, Cin, H, W, N, 1, 1, Kp);
+  if (rc) return rc;
+  KOD_CHECK_ARG(bias && out && A > 0 && nc > 0, "conv_fwd_head: bad args");
+  a.bias = bias; a.head_out = out; a.head_A = A; a.head_P = 5 + nc; a.head_nc = nc;
+  a.mul_h = 1; a.mul_w = 1; a.add_h = 0; a.add_w = 0; a.tap_sign = 1;
+  return launch<MODE_HEAD>(a, stream);
+}
+
+// Data gradient: dx[B][H][W][ldx](+xcoff, Cin channels) (+)= conv_transpose(dy[B][Ho][Wo][ldy](+ycoff, N), w).
+// w_dgrad is packed [Cin][Kp] with k = (kh, kw, n).
+int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
+                      int B, int H, int W, int ldx, int xcoff, int Cin,
+                      int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                      int ldy, int ycoff, int accumulate, hipStream_t stream) {
+  ConvArgs a = {};
+  int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
+  // gather source is dy (channels N per tap), output pixels are the input pixels of the forward conv
+  int rc = fill_common(a, dy, w_dgrad, B, Ho, Wo, ldy, ycoff, N, H, W, Cin, KH, KW, Kp);
+  if (rc) return rc;
+  KOD_CHECK_ARG(dx, "conv_dgrad: null output");
+  KOD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0 && xcoff + Cin <= ldx, "conv_dgrad: bad output slice");
+  int ssh = ilog2_exact(SH), ssw = ilog2_exact(SW);
+  KOD_CHECK_ARG(ssh >= 0 && ssw >= 0, "conv_dgrad: stride must be a power of two");
+  a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff; a.accumulate = accumulate;
+  a.mul_h = 1; a.mul_w = 1; a.add_h = PH; a.add_w = PW; a.tap_sign = -1; a.sh_shift = ssh; a.sw_shift = ssw;
+  return launch<MODE_PLAIN>(a, stream);
+}
+
+}  // extern "C"

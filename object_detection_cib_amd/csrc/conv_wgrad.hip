@@ -1,0 +1,289 @@
+// Weight gradient of a convolution (aten::convolution_backward dW) for gfx950.
+//
+//   dW[n][k] = sum_m dY[m][n] * im2col(X)[m][k],  m = (b, oy, ox), k = (kh, kw, ci)
+//
+// Both MFMA operands are indexed [reduction m][n or k] in memory (channels-last), i.e. the reduction
+// index is the slow one, so the fragments are read from LDS with gfx950's transposing
+// ds_read_b64_tr_b16 (row stride = 64 or 192 mod 256 bytes => conflict-free).  The huge reduction
+// (m up to 6.5M rows) is split across blocks; each split writes an fp32 partial slab, and a second
+// kernel sums the slabs in a fixed order (deterministic, no float atomics) while un-permuting k back
+// to torch's [Cout][Cin][KH][KW] fp32 layout.
+#include "kodhip_common.h"
+
+namespace {
+
+struct WgradArgs {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* part;
+  int B, Hs, Ws, ldx, xcoff, Cin;
+  int Ho, Wo, M;
+  int N, K, Kp;
+  int KH, KW, SH, SW, PH, PW;
+  int ldy, ycoff;
+  int m_per_split, splits;
+  int tiles_n, tiles_k;
+  uint32_t magic_cin, magic_kw;
+};
+
+__host__ __device__ constexpr int row_bytes(int T) { return (T * 2) % 128 == 0 ? T * 2 + 64 : T * 2; }
+
+// Block tile = (WN*RN*32) channels x (WK*RK*32) k, 64*WN*WK threads, 32 reduction rows per step.
+template <int WN, int WK, int RN, int RK>
+__global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int NT = 64 * WN * WK;
+  constexpr int TNB = WN * RN * 32;
+  constexpr int TKB = WK * RK * 32;
+  constexpr int SY = row_bytes(TNB);
+  constexpr int SX = row_bytes(TKB);
+  constexpr int YC = TNB / 8, XC = TKB / 8;
+  constexpr int YL = (32 * YC + NT - 1) / NT;    // chunks per thread
+  constexpr int XL = (32 * XC + NT - 1) / NT;
+  constexpr int STAGE = 32 * SY + 32 * SX;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave / WK, wk = wave % WK;
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int j = bid >> 3;
+  const int tiles = a.tiles_n * a.tiles_k;
+  const int tile = j % tiles;
+  const int split = (j / tiles) * 8 + xcd;
+  if (split >= a.splits) return;
+  const int n0 = (tile % a.tiles_n) * TNB;
+  const int k0 = (tile / a.tiles_n) * TKB;
+  const int m_begin = split * a.m_per_split;
+  int m_end = m_begin + a.m_per_split;
+  if (m_end > a.M) m_end = a.M;
+
+  // fixed per-thread k-chunk decomposition for the X gather
+  const int xkc = tid % XC;                 // NT % XC == 0 for all instantiations
+  const int xrow0 = tid / XC;
+  constexpr int XRS = NT / XC;              // row step between a thread's chunks
+  const int xk = k0 + xkc * 8;
+  const uint32_t tap = __umulhi((uint32_t)xk, a.magic_cin);
+  const int xci = xk - (int)tap * a.Cin;
+  const int xkh = (a.KW == 1) ? (int)tap : (int)__umulhi(tap, a.magic_kw);
+  const int xkw = (int)tap - xkh * a.KW;
+  const bool xkvalid = xk < a.K;
+
+  const int ykc = tid % YC;
+  const int yrow0 = tid / YC;
+  constexpr int YRS = NT / YC;
+  const bool ynvalid = (n0 + ykc * 8) < a.N;
+
+  const int HWo = a.Ho * a.Wo;
+
+  u32x4 xreg[XL], yreg[YL];
+  auto load_tile = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      int row = xrow0 + i * XRS;
+      int m = mb + row;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < 32 && m < m_end && xkvalid) {
+        int b = m / HWo;
+        int rem = m - b * HWo;
+        int oy = rem / a.Wo;
+        int ox = rem - oy * a.Wo;
+        int iy = oy * a.SH - a.PH + xkh;
+        int ix = ox * a.SW - a.PW + xkw;
+        if (iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws)
+          v = *reinterpret_cast<const u32x4*>(a.x + (size_t)((b * a.Hs + iy) * a.Ws + ix) * a.ldx + a.xcoff + xci);
+      }
+      xreg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < YL; ++i) {
+      int row = yrow0 + i * YRS;
+      int m = mb + row;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < 32 && m < m_end && ynvalid)
+        v = *reinterpret_cast<const u32x4*>(a.dy + (size_t)m * a.ldy + a.ycoff + n0 + ykc * 8);
+      yreg[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* Ys = lds + buf * STAGE;
+    unsigned char* Xs = Ys + 32 * SY;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      int row = xrow0 + i * XRS;
+      if (row < 32) *reinterpret_cast<u32x4*>(Xs + row * SX + xkc * 16) = xreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < YL; ++i) {
+      int row = yrow0 + i * YRS;
+      if (row < 32) *reinterpret_cast<u32x4*>(Ys + row * SY + ykc * 16) = yreg[i];
+    }
+  };
+
+  f32x16 acc[RN][RK];
+#pragma unroll
+  for (int i = 0; i < RN; ++i)
+#pragma unroll
+    for (int jj = 0; jj < RK; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+  // transposed-read lane geometry (see file header): rows = reduction index, columns = n or k
+  const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  const int nsteps = (m_end - m_begin + 31) / 32;
+  if (nsteps > 0) {
+    load_tile(m_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) load_tile(m_begin + (st + 1) * 32);
+    const unsigned char* Ys = lds + buf * STAGE;
+    const unsigned char* Xs = Ys + 32 * SY;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 yf[RN], xf[RK];
+#pragma unroll
+      for (int i = 0; i < RN; ++i) {
+        const unsigned char* p = Ys + (ks * 16 + tr_row) * SY + ((wn * RN + i) * 32 + tr_col) * 2;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * SY));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        yf[i] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int jj = 0; jj < RK; ++jj) {
+        const unsigned char* p = Xs + (ks * 16 + tr_row) * SX + ((wk * RK + jj) * 32 + tr_col) * 2;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * SX));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        xf[jj] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int i = 0; i < RN; ++i)
+#pragma unroll
+        for (int jj = 0; jj < RK; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i], xf[jj], acc[i][jj], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // D[n][k]: k = lane & 31, n = 8*(e>>2) + 4*(lane>>5) + (e&3)
+  float* slab = a.part + (size_t)split * a.N * a.Kp;
+#pragma unroll
+  for (int i = 0; i < RN; ++i)
+#pragma unroll
+    for (int jj = 0; jj < RK; ++jj) {
+      int k = k0 + (wk * RK + jj) * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int n = n0 + (wn * RN + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        if (n < a.N && k < a.Kp) slab[(size_t)n * a.Kp + k] = acc[i][jj][e];
+      }
+    }
+}
+
+// grad[n][ci][kh][kw] = scale * sum_s part[s][n][k(kh,kw,ci)]   (stem: k = (kh, kw', dx, c4), see pack)
+__global__ void wgrad_reduce_kernel(const float* part, float* grad, int splits, int Nfull, int N, int K, int Kp,
+                                    int Cin, int KK, int stem, float scale) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * K) return;
+  int n = idx / K;
+  int k = idx - n * K;
+  float s = 0.f;
+  const float* p = part + (size_t)n * Kp + k;
+  for (int i = 0; i < splits; ++i) s += p[(size_t)i * Nfull * Kp];
+  if (stem) {
+    // k = (kh*3 + kwp)*8 + dx*4 + c, real weight [n][c(3)][kh(6)][kw = 2*kwp+dx (6)]
+    int c = k & 3, dx = (k >> 2) & 1, t = k >> 3;
+    int kh = t / 3, kwp = t - kh * 3;
+    if (c < 3) grad[(size_t)n * 108 + c * 36 + kh * 6 + 2 * kwp + dx] = s * scale;
+  } else {
+    int tap = k / Cin;
+    int ci = k - tap * Cin;
+    grad[(size_t)n * Cin * KK + ci * KK + tap] = s * scale;
+  }
+}
+
+template <int WN, int WK, int RN, int RK>
+int launch_cfg(WgradArgs a, hipStream_t stream) {
+  constexpr int TNB = WN * RN * 32, TKB = WK * RK * 32;
+  a.tiles_n = cdiv(a.N, TNB);
+  a.tiles_k = cdiv(a.Kp, TKB);
+  int grid = cdiv(a.splits, 8) * 8 * a.tiles_n * a.tiles_k;
+  hipLaunchKernelGGL((conv_wgrad_kernel<WN, WK, RN, RK>), dim3(grid), dim3(64 * WN * WK), 0, stream, a);
+  KOD_LAUNCH_CHECK("conv_wgrad");
+  return KOD_OK;
+}
+
+void tile_shape(int N, int Kp, int* tn, int* tk) {
+  *tn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  *tk = Kp > 64 ? 128 : (Kp > 32 ? 64 : 32);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Number of reduction splits the launcher will use (partials buffer must hold splits*N*Kp floats).
+int kodhip_conv_wgrad_splits(long M, int N, int Kp) {
+  int tn, tk;
+  tile_shape(N, Kp, &tn, &tk);
+  int tiles = cdiv(N, tn) * cdiv(Kp, tk);
+  int s = 1024 / tiles;
+  if (s < 1) s = 1;
+  long maxs = (M + 255) / 256;
+  if (s > maxs) s = (int)maxs;
+  if (s < 1) s = 1;
+  return s;
+}
+
+int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* grad,
+                      int B, int H, int W, int ldx, int xcoff, int Cin,
+                      int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                      int ldy, int ycoff, int n_valid, int stem, float scale, hipStream_t stream) {
+  KOD_CHECK_ARG(x && dy && partials && grad, "conv_wgrad: null pointer");
+  KOD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0 && xcoff + Cin <= ldx, "conv_wgrad: bad input slice");
+  KOD_CHECK_ARG(N % 8 == 0 && ldy % 8 == 0 && ycoff % 8 == 0 && ycoff + N <= ldy, "conv_wgrad: bad dy slice (N=%d ldy=%d)", N, ldy);
+  KOD_CHECK_ARG(Kp % 32 == 0 && Kp >= KH * KW * Cin, "conv_wgrad: bad Kp");
+  KOD_CHECK_ARG(n_valid > 0 && n_valid <= N, "conv_wgrad: bad n_valid");
+  WgradArgs a = {};
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.part = partials;
+  a.B = B; a.Hs = H; a.Ws = W; a.ldx = ldx; a.xcoff = xcoff; a.Cin = Cin;
+  a.Ho = (H + 2 * PH - KH) / SH + 1; a.Wo = (W + 2 * PW - KW) / SW + 1;
+  long M = (long)B * a.Ho * a.Wo;
+  KOD_CHECK_ARG(M < (1l << 31) && (long)B * H * W < (1l << 31), "conv_wgrad: pixel count overflows int32");
+  a.M = (int)M; a.N = N; a.K = KH * KW * Cin; a.Kp = Kp;
+  a.KH = KH; a.KW = KW; a.SH = SH; a.SW = SW; a.PH = PH; a.PW = PW; a.ldy = ldy; a.ycoff = ycoff;
+  a.magic_cin = magic_u32((uint32_t)Cin); a.magic_kw = magic_u32((uint32_t)KW);
+  a.splits = kodhip_conv_wgrad_splits(M, N, Kp);
+  a.m_per_split = cdiv(cdiv(M, a.splits), 32) * 32;
+  a.splits = cdiv(M, a.m_per_split);
+  int tn, tk, rc;
+  tile_shape(N, Kp, &tn, &tk);
+  if (tn == 128 && tk == 128) rc = launch_cfg<2, 2, 2, 2>(a, stream);
+  else if (tn == 64 && tk == 128) rc = launch_cfg<2, 2, 1, 2>(a, stream);
+  else if (tn == 32 && tk == 128) rc = launch_cfg<1, 4, 1, 1>(a, stream);
+  else if (tn == 128 && tk == 64) rc = launch_cfg<2, 2, 2, 1>(a, stream);
+  else if (tn == 64 && tk == 64) rc = launch_cfg<2, 2, 1, 1>(a, stream);
+  else if (tn == 32 && tk == 64) rc = launch_cfg<1, 2, 1, 1>(a, stream);
+  else if (tn == 128 && tk == 32) rc = launch_cfg<4, 1, 1, 1>(a, stream);
+  else if (tn == 64 && tk == 32) rc = launch_cfg<2, 1, 1, 1>(a, stream);
+  else rc = launch_cfg<1, 1, 1, 1>(a, stream);
+  if (rc) return rc;
+  int total = n_valid * a.K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+                     (const float*)partials, grad, a.splits, N, n_valid, a.K, Kp, stem ? 8 : Cin, KH * KW, stem, scale);
+  KOD_LAUNCH_CHECK("wgrad_reduce");
+  return KOD_OK;
+}
+
+}  // extern "C"

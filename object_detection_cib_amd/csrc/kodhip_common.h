@@ -1,0 +1,55 @@
+// Shared device/host helpers for libkodhip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define KOD_OK 0
+#define KOD_EARG (-1)
+
+extern "C" void kodhip_set_error(const char* fmt, ...);
+
+#define KOD_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      kodhip_set_error(__VA_ARGS__);             \
+      return KOD_EARG;                           \
+    }                                            \
+  } while (0)
+
+#define KOD_LAUNCH_CHECK(name)                                             \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      kodhip_set_error("%s: %s", name, hipGetErrorString(e__));            \
+      return (int)e__;                                                     \
+    }                                                                      \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+__device__ __forceinline__ float sigmoid_f(float z) { return 1.0f / (1.0f + __expf(-z)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline uint32_t magic_u32(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }

@@ -1,0 +1,386 @@
+// Small HBM-bound helpers of the YOLOv5 train step (gfx950):
+//   * NCHW fp32 image -> channels-last bf16 (C padded to 4, so the 6x6/s2 stem becomes a 6x3 conv over
+//     8-channel pixel pairs with 16-byte k-runs)
+//   * fp32 master weights [Cout][Cin][KH][KW] -> bf16 MFMA packs (forward / wgrad order and dgrad order)
+//   * SPPF 5x5/s1/p2 max-pool forward (+argmax) and backward (kod/nn/layers/sppf.py:46-50,73-76)
+//   * nearest x2 upsample forward / backward (kod/nn/necks/yolov5_pafpn.py:144-146,182-184)
+//   * detection-head gradient re-layout [B,A,h,w,5+nc] fp32 -> [M][Npad] bf16 + bias gradient
+//   * fused multi-tensor Nesterov SGD (torch.optim.SGD as configured by kod/nn/optim/smart.py:36-58)
+#include "kodhip_common.h"
+
+namespace {
+
+__global__ void nchw_to_nhwc4_kernel(const float* x, bf16_t* y, int B, int C, long HW) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * HW) return;
+  long b = i / HW, p = i - b * HW;
+  bf16x4 v;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = (bf16_t)(c < C ? x[(b * C + c) * HW + p] : 0.f);
+  *reinterpret_cast<bf16x4*>(y + i * 4) = v;
+}
+
+struct PackDesc {          // all int64 so the host can fill it as a plain int64[13] row
+  long w_off;              // offset (elements) of this weight in the fp32 master arena
+  long f_off;              // offset of its first row in the bf16 forward pack arena ([N][Kp] rows)
+  long d_off;              // offset of the layer's dgrad pack ([Cin][Kdp]), -1: none
+  long N, Cin, KH, KW;     // true weight dims [N][Cin][KH][KW]
+  long Kp, Kdp;            // padded row lengths of the two packs
+  long Ntot, n_off;        // dgrad pack: channels per tap (padded total) and this weight's first channel
+  long stem;               // 1: 6x6/s2 stem in pixel-pair form, k = (kh, kw', dx, c4)
+  long blk_begin;          // first block of this descriptor in the grid
+};
+
+// One launch packs every layer: block -> descriptor by binary search on blk_begin.  Only valid entries
+// are written; padding stays zero from the one-time arena memset.
+__global__ void pack_weights_kernel(const float* master, bf16_t* fpack, bf16_t* dpack, const PackDesc* descs,
+                                    int nlayers) {
+  int lo = 0, hi = nlayers - 1;
+  long blk = blockIdx.x;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk_begin <= blk) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  long local = (blk - d.blk_begin) * blockDim.x + threadIdx.x;
+  const long KK = d.KH * d.KW;
+  const long count = d.N * d.Cin * KK;          // true element count
+  if (local >= count) return;
+  // local enumerates the master layout [n][ci][tap] so reads are coalesced
+  long n = local / (d.Cin * KK);
+  long rem = local - n * d.Cin * KK;
+  long ci = rem / KK;
+  long tap = rem - ci * KK;
+  bf16_t v = (bf16_t)master[d.w_off + local];
+  if (d.stem) {
+    long kh = tap / 6, kw = tap - kh * 6;
+    long k = (kh * 3 + (kw >> 1)) * 8 + (kw & 1) * 4 + ci;
+    fpack[d.f_off + n * d.Kp + k] = v;
+  } else {
+    fpack[d.f_off + n * d.Kp + tap * d.Cin + ci] = v;
+    if (d.d_off >= 0) dpack[d.d_off + ci * d.Kdp + tap * d.Ntot + d.n_off + n] = v;
+  }
+}
+
+// ------------------------------------------------------------------ SPPF max pool 5x5 s1 p2
+__global__ void maxpool5_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_t* y, int ldy, int ycoff,
+                                    unsigned char* idx, int B, int H, int W, int C) {
+  const int CC = C >> 3;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * H * W * CC;
+  if (i >= total) return;
+  int cc = (int)(i % CC);
+  long p = i / CC;
+  int ox = (int)(p % W);
+  long q = p / W;
+  int oy = (int)(q % H);
+  int b = (int)(q / H);
+  float best[8];
+  unsigned char bi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+  for (int dy = 0; dy < 5; ++dy) {
+    int iy = oy + dy - 2;
+    if (iy < 0 || iy >= H) continue;
+    for (int dx = 0; dx < 5; ++dx) {
+      int ix = ox + dx - 2;
+      if (ix < 0 || ix >= W) continue;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)(b * H + iy) * W + ix) * ldx + xcoff + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v[e];
+        if (f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(dy * 5 + dx); }
+      }
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)best[e];
+  *reinterpret_cast<bf16x8*>(y + p * ldy + ycoff + cc * 8) = o;
+  unsigned char* ip = idx + p * C + cc * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ip[e] = bi[e];
+}
+
+// dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic)
+__global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const unsigned char* idx,
+                                    bf16_t* dx, int ldx, int xcoff, int B, int H, int W, int C) {
+  const int CC = C >> 3;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * H * W * CC;
+  if (i >= total) return;
+  int cc = (int)(i % CC);
+  long p = i / CC;
+  int ix = (int)(p % W);
+  long q = p / W;
+  int iy = (int)(q % H);
+  int b = (int)(q / H);
+  float acc[8];
+  bf16_t* d = dx + p * ldx + xcoff + cc * 8;
+  bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = (float)old[e];
+  for (int dyy = 0; dyy < 5; ++dyy) {
+    int oy = iy - dyy + 2;                 // output row whose window tap dyy hits iy
+    if (oy < 0 || oy >= H) continue;
+    for (int dxx = 0; dxx < 5; ++dxx) {
+      int ox = ix - dxx + 2;
+      if (ox < 0 || ox >= W) continue;
+      long op = (long)(b * H + oy) * W + ox;
+      const unsigned char* ip = idx + op * C + cc * 8;
+      bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + op * ldy + ycoff + cc * 8);
+      unsigned char want = (unsigned char)(dyy * 5 + dxx);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (ip[e] == want) acc[e] += (float)g[e];
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
+  *reinterpret_cast<bf16x8*>(d) = o;
+}
+
+// ------------------------------------------------------------------ nearest x2 upsample
+__global__ void upsample2x_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_t* y, int ldy, int ycoff,
+                                      int B, int H, int W, int C) {   // H,W = input dims
+  const int CC = C >> 3;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * 4 * H * W * CC;
+  if (i >= total) return;
+  int cc = (int)(i % CC);
+  long p = i / CC;
+  int ox = (int)(p % (2 * W));
+  long q = p / (2 * W);
+  int oy = (int)(q % (2 * H));
+  int b = (int)(q / (2 * H));
+  bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)(b * H + (oy >> 1)) * W + (ox >> 1)) * ldx + xcoff + cc * 8);
+  *reinterpret_cast<bf16x8*>(y + p * ldy + ycoff + cc * 8) = v;
+}
+
+__global__ void upsample2x_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, bf16_t* dx, int ldx, int xcoff,
+                                      int accumulate, int B, int H, int W, int C) {  // H,W = input dims
+  const int CC = C >> 3;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * H * W * CC;
+  if (i >= total) return;
+  int cc = (int)(i % CC);
+  long p = i / CC;
+  int ix = (int)(p % W);
+  long q = p / W;
+  int iy = (int)(q % H);
+  int b = (int)(q / H);
+  float acc[8];
+  bf16_t* d = dx + p * ldx + xcoff + cc * 8;
+  if (accumulate) {
+    bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (float)old[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    long op = (long)(b * 2 * H + 2 * iy + (s >> 1)) * (2 * W) + 2 * ix + (s & 1);
+    bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + op * ldy + ycoff + cc * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += (float)g[e];
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
+  *reinterpret_cast<bf16x8*>(d) = o;
+}
+
+// ------------------------------------------------------------------ head gradient re-layout
+// g[B][A][HW][P] fp32 -> dy[M = B*HW][Npad] bf16 with n = box(4A) | obj(A) | cls(nc*A); bias partials
+// bpart[blk][Npad] (summed by bias_reduce).
+__global__ void head_bwd_prep_kernel(const float* g, bf16_t* dy, float* bpart, int B, int HW, int A, int nc,
+                                     int Npad) {
+  extern __shared__ float sm[];            // [blockDim.x / Npad][Npad]
+  const int P = 5 + nc;
+  const int N = A * P;
+  const int n = threadIdx.x % Npad;
+  const int rl = threadIdx.x / Npad;
+  const int rpb = blockDim.x / Npad;
+  long M = (long)B * HW;
+  float s = 0.f;
+  int an = 0, slot = 0;
+  if (n < N) {
+    if (n < 4 * A) { an = n >> 2; slot = n & 3; }
+    else if (n < 5 * A) { an = n - 4 * A; slot = 4; }
+    else { int q = n - 5 * A; an = q / nc; slot = 5 + q - an * nc; }
+  }
+  if (rl < rpb) {
+    for (long m = (long)blockIdx.x * rpb + rl; m < M; m += (long)gridDim.x * rpb) {
+      float v = 0.f;
+      if (n < N) {
+        long b = m / HW, pix = m - b * HW;
+        v = g[((b * A + an) * HW + pix) * P + slot];
+      }
+      dy[m * Npad + n] = (bf16_t)v;
+      s += v;
+    }
+    sm[rl * Npad + n] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < Npad) {
+    float t = 0.f;
+    for (int r = 0; r < rpb; ++r) t += sm[r * Npad + threadIdx.x];
+    bpart[(size_t)blockIdx.x * Npad + threadIdx.x] = t;
+  }
+}
+
+// bias grads of the three heads: db_box[4A], db_obj[A], db_cls[nc*A] are consecutive in n order.
+__global__ void head_bias_reduce_kernel(const float* bpart, int nblk, int Npad, float* db_box, float* db_obj,
+                                        float* db_cls, int A, int nc) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  int N = A * (5 + nc);
+  if (n >= N) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)bpart[(size_t)b * Npad + n];
+  if (n < 4 * A) db_box[n] = (float)s;
+  else if (n < 5 * A) db_obj[n - 4 * A] = (float)s;
+  else db_cls[n - 5 * A] = (float)s;
+}
+
+// ------------------------------------------------------------------ SGD
+// group id per 64-element granule: 0 bias, 1 decay, 2 norm, 255 padding
+struct SgdHyper { float lr[3], momentum[3], wd[3]; float grad_scale; };
+
+__global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, const unsigned char* gid, long n,
+                                    SgdHyper h) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  unsigned char grp = gid[i >> 6];
+  if (grp > 2) return;
+  float lr = h.lr[grp], mu = h.momentum[grp], wd = h.wd[grp];
+  f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+  f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+  f32x4 bv = *reinterpret_cast<const f32x4*>(buf + i);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float gg = gv[e] * h.grad_scale;
+    if (wd != 0.f) gg = gg + wd * pv[e];
+    float b = mu * bv[e] + gg;
+    bv[e] = b;
+    pv[e] = pv[e] - lr * (gg + mu * b);
+  }
+  *reinterpret_cast<f32x4*>(p + i) = pv;
+  *reinterpret_cast<f32x4*>(buf + i) = bv;
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kodhip_nchw_to_nhwc4(const float* x, void* y, int B, int C, int H, int W, hipStream_t stream) {
+  KOD_CHECK_ARG(x && y && B > 0 && C > 0 && C <= 4 && H > 0 && W > 0, "nchw_to_nhwc4: bad args");
+  long n = (long)B * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, (bf16_t*)y, B, C, (long)H * W);
+  KOD_LAUNCH_CHECK("nchw_to_nhwc4");
+  return KOD_OK;
+}
+
+// descs: device array of nlayers PackDesc (13 x int64 each); total_blocks = sum over descriptors of
+// ceil(N*Cin*KH*KW / 256).
+int kodhip_pack_weights(const float* master, void* fpack, void* dpack, const void* descs, int nlayers,
+                        long total_blocks, hipStream_t stream) {
+  KOD_CHECK_ARG(master && fpack && descs && nlayers > 0 && total_blocks > 0, "pack_weights: bad args");
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)total_blocks), dim3(256), 0, stream, master, (bf16_t*)fpack,
+                     (bf16_t*)dpack, (const PackDesc*)descs, nlayers);
+  KOD_LAUNCH_CHECK("pack_weights");
+  return KOD_OK;
+}
+int kodhip_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
+
+int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff, void* idx,
+                        int B, int H, int W, int C, hipStream_t stream) {
+  KOD_CHECK_ARG(x && y && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
+                "maxpool5_fwd: bad args");
+  long n = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool5_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, xcoff,
+                     (bf16_t*)y, ldy, ycoff, (unsigned char*)idx, B, H, W, C);
+  KOD_LAUNCH_CHECK("maxpool5_fwd");
+  return KOD_OK;
+}
+
+int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, void* dx, int ldx, int xcoff,
+                        int B, int H, int W, int C, hipStream_t stream) {
+  KOD_CHECK_ARG(dy && dx && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
+                "maxpool5_bwd: bad args");
+  long n = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)dy, ldy, ycoff,
+                     (const unsigned char*)idx, (bf16_t*)dx, ldx, xcoff, B, H, W, C);
+  KOD_LAUNCH_CHECK("maxpool5_bwd");
+  return KOD_OK;
+}
+
+int kodhip_upsample2x_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff,
+                          int B, int H, int W, int C, hipStream_t stream) {
+  KOD_CHECK_ARG(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
+                "upsample2x_fwd: bad args");
+  long n = (long)B * 4 * H * W * (C / 8);
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, xcoff,
+                     (bf16_t*)y, ldy, ycoff, B, H, W, C);
+  KOD_LAUNCH_CHECK("upsample2x_fwd");
+  return KOD_OK;
+}
+
+int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx, int xcoff, int accumulate,
+                          int B, int H, int W, int C, hipStream_t stream) {
+  KOD_CHECK_ARG(dy && dx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
+                "upsample2x_bwd: bad args");
+  long n = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)dy, ldy, ycoff,
+                     (bf16_t*)dx, ldx, xcoff, accumulate, B, H, W, C);
+  KOD_LAUNCH_CHECK("upsample2x_bwd");
+  return KOD_OK;
+}
+
+// workspace: bias partials, 512 * Npad floats
+int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_box, float* db_obj, float* db_cls,
+                         int B, int HW, int A, int nc, int Npad, hipStream_t stream) {
+  KOD_CHECK_ARG(g && dy && workspace && db_box && db_obj && db_cls, "head_bwd_prep: null pointer");
+  KOD_CHECK_ARG(Npad % 8 == 0 && Npad >= A * (5 + nc) && Npad <= 256, "head_bwd_prep: bad Npad");
+  int rpb = 256 / Npad;
+  int threads = rpb * Npad;
+  long M = (long)B * HW;
+  int grid = (int)((M + rpb - 1) / rpb);
+  if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(head_bwd_prep_kernel, dim3(grid), dim3(threads), rpb * Npad * sizeof(float), stream, g,
+                     (bf16_t*)dy, workspace, B, HW, A, nc, Npad);
+  KOD_LAUNCH_CHECK("head_bwd_prep");
+  hipLaunchKernelGGL(head_bias_reduce_kernel, dim3(cdiv(A * (5 + nc), 64)), dim3(64), 0, stream,
+                     (const float*)workspace, grid, Npad, db_box, db_obj, db_cls, A, nc);
+  KOD_LAUNCH_CHECK("head_bias_reduce");
+  return KOD_OK;
+}
+
+// hyper: 10 floats = lr[3], momentum[3], weight_decay[3], grad_scale  (groups: bias, decay, norm)
+int kodhip_sgd_nesterov(float* params, const float* grads, float* momentum_buf, const void* group_ids,
+                        long n, const float* hyper, hipStream_t stream) {
+  KOD_CHECK_ARG(params && grads && momentum_buf && group_ids && hyper && n > 0 && n % 64 == 0, "sgd_nesterov: bad args");
+  SgdHyper h;
+  for (int i = 0; i < 3; ++i) { h.lr[i] = hyper[i]; h.momentum[i] = hyper[3 + i]; h.wd[i] = hyper[6 + i]; }
+  h.grad_scale = hyper[9];
+  hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, params, grads, momentum_buf,
+                     (const unsigned char*)group_ids, n, h);
+  KOD_LAUNCH_CHECK("sgd_nesterov");
+  return KOD_OK;
+}
+
+int kodhip_fill_u32(void* p, uint32_t value, long n, hipStream_t stream) {
+  KOD_CHECK_ARG(p && n > 0, "fill_u32: bad args");
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (uint32_t*)p, value, n);
+  KOD_LAUNCH_CHECK("fill_u32");
+  return KOD_OK;
+}
+
+}  // extern "C"

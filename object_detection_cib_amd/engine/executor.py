@@ -1,0 +1,477 @@
+"""Executes the static YOLOv5 program (engine/graph.py) with libkodhip kernels.
+
+Replaces what autograd + aten do for the reference's training step
+(kod/lightning/experiments/yv5_baseline/exp.py:104-138 -> net forward, loss.backward): forward and
+backward are explicit op lists over pre-allocated channels-last bf16 buffers; parameters, gradients and
+momentum live in flat fp32 arenas (one fused SGD launch, contiguous all-reduce buckets); weights are
+re-packed to bf16 MFMA layouts once per step.
+
+PyTorch is used for device memory, streams and torch.distributed only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .graph import Graph, ConvUnit, HeadUnit, View, Buf
+
+BN_EPS, BN_MOMENTUM = 1e-3, 0.03        # kod/nn/networks/yolov5.py:24
+
+
+def _pad(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class _UnitState:
+    __slots__ = ("u", "w_off", "g_off", "b_off", "f_off", "d_off", "Kp", "Kdp", "rs_off", "stats", "T",
+                 "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho", "Wo")
+
+
+class Engine:
+    """Owns arenas + buffers for one network instance (one process, one GPU)."""
+
+    def __init__(self, graph: Graph, params: Dict[str, torch.nn.Parameter], buffers: Dict[str, torch.Tensor]):
+        _lib.require_gpu()
+        self.lib = _lib.lib()
+        self.g = graph
+        self.params = params          # full state_dict-style names -> Parameter (shared with the nn.Module)
+        self.buffers = buffers        # running_mean / running_var / num_batches_tracked
+        self.device = None
+        self.shape = None             # (B, H, W) of the current allocation
+        self.training_ready = False
+        self.sync_bn = False
+        self.process_group = None
+        self.world_size = 1
+        self.bucket_bytes = 8 << 20
+        self._pending = []
+        self._packed_version = -1
+        self.param_version = 0
+
+    # ------------------------------------------------------------------ arenas
+    def _build_arenas(self, device):
+        g = self.g
+        order = []                    # (param name, group) in forward execution order, packed sets
+        self.ustate: Dict[str, _UnitState] = {}
+        off = 0
+        layout = {}                   # name -> (offset, numel)
+        gid = []
+
+        def place(names, group):
+            nonlocal off
+            start = off
+            for n in names:
+                p = self.params[n]
+                layout[n] = (off, p.numel())
+                off += p.numel()
+            end = _pad(off)
+            gid.extend([group] * ((end - start) // 64))
+            off = end
+
+        exec_units = [op.unit for op in g.ops if op.kind == "conv"]
+        for u in exec_units:
+            place([u.name + ".0.weight"], 1)
+            place([u.name + ".1.weight"], 2)
+            place([u.name + ".1.bias"], 0)
+        for h in g.heads:
+            place([f"{h.name}.{k}_head.conv.weight" for k in ("box", "obj", "cls")], 1)
+            place([f"{h.name}.{k}_head.conv.bias" for k in ("box", "obj", "cls")], 0)
+        self.n_arena = off
+        self.layout = layout
+        self.p_arena = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g_arena = [torch.zeros(off, dtype=torch.float32, device=device) for _ in range(2)]
+        self.g_cur = 0
+        self.m_arena = torch.zeros(off, dtype=torch.float32, device=device)
+        self.gid = torch.tensor(gid, dtype=torch.uint8, device=device)
+        with torch.no_grad():
+            for n, (o, k) in layout.items():
+                p = self.params[n]
+                self.p_arena[o:o + k].copy_(p.detach().reshape(-1).to(device))
+                p.data = self.p_arena[o:o + k].view(p.shape)
+                p.grad = None
+        # BN running statistics arena
+        roff = 0
+        self.rs_layout = {}
+        for u in exec_units:
+            self.rs_layout[u.name] = roff
+            roff += _pad(u.cout, 16)
+        self.rm_arena = torch.zeros(roff, dtype=torch.float32, device=device)
+        self.rv_arena = torch.ones(roff, dtype=torch.float32, device=device)
+        self.nbt_arena = torch.zeros(len(exec_units), dtype=torch.int64, device=device)
+        with torch.no_grad():
+            for i, u in enumerate(exec_units):
+                o = self.rs_layout[u.name]
+                for key, arena in (("running_mean", self.rm_arena), ("running_var", self.rv_arena)):
+                    b = self.buffers[f"{u.name}.1.{key}"]
+                    arena[o:o + u.cout].copy_(b.to(device))
+                    b.data = arena[o:o + u.cout]
+                b = self.buffers[f"{u.name}.1.num_batches_tracked"]
+                self.nbt_arena[i] = b.to(device)
+                b.data = self.nbt_arena[i]
+        # weight packs
+        descs = []
+        foff = doff = 0
+        blk = 0
+        A, nc = g.num_anchors, g.num_classes
+
+        def add_desc(w_name, f_off, d_off, N, Cin, KH, KW, Kp, Kdp, Ntot, n_off, stem):
+            nonlocal blk
+            descs.append([layout[w_name][0], f_off, d_off, N, Cin, KH, KW, Kp, Kdp, Ntot, n_off, stem, blk])
+            blk += (N * Cin * KH * KW + 255) // 256
+
+        for u in exec_units:
+            st = _UnitState()
+            st.u = u
+            K = u.k * u.k * u.cin if not u.stem else 144
+            st.Kp = _pad(K, 32)
+            st.Kdp = _pad(u.k * u.k * u.cout, 32)
+            st.f_off, st.d_off = foff, (-1 if u.stem else doff)
+            foff += u.cout * st.Kp
+            if not u.stem:
+                doff += u.cin * st.Kdp
+            st.w_off = layout[u.name + ".0.weight"][0]
+            st.g_off = layout[u.name + ".1.weight"][0]
+            st.b_off = layout[u.name + ".1.bias"][0]
+            st.rs_off = self.rs_layout[u.name]
+            if u.stem:
+                add_desc(u.name + ".0.weight", st.f_off, -1, u.cout, 3, 6, 6, st.Kp, 0, 0, 0, 1)
+            else:
+                add_desc(u.name + ".0.weight", st.f_off, st.d_off, u.cout, u.cin, u.k, u.k, st.Kp, st.Kdp,
+                         u.cout, 0, 0)
+            self.ustate[u.name] = st
+        self.hstate = {}
+        self.head_npad = _pad(A * (5 + nc), 8)
+        for h in g.heads:
+            Kp = _pad(h.cin, 32)
+            Kdp = _pad(self.head_npad, 32)
+            hs = dict(f_off=foff, d_off=doff, Kp=Kp, Kdp=Kdp,
+                      w_off=layout[f"{h.name}.box_head.conv.weight"][0],
+                      b_off=layout[f"{h.name}.box_head.conv.bias"][0])
+            n_off = 0
+            for k, n in (("box", 4 * A), ("obj", A), ("cls", nc * A)):
+                add_desc(f"{h.name}.{k}_head.conv.weight", foff + n_off * Kp, doff, n, h.cin, 1, 1, Kp, Kdp,
+                         self.head_npad, n_off, 0)
+                n_off += n
+            foff += self.head_npad * Kp
+            doff += h.cin * Kdp
+            self.hstate[h.name] = hs
+        self.fpack = torch.zeros(foff, dtype=torch.bfloat16, device=device)
+        self.dpack = torch.zeros(max(doff, 8), dtype=torch.bfloat16, device=device)
+        self.pack_descs = torch.tensor(descs, dtype=torch.int64, device=device)
+        assert self.lib.kodhip_pack_desc_bytes() == 13 * 8
+        self.pack_blocks = blk
+        self.exec_units = exec_units
+        self.device = device
+
+    def _grad_view(self, name, arena=None):
+        o, k = self.layout[name]
+        a = self.g_arena[self.g_cur] if arena is None else arena
+        return a[o:o + k].view(self.params[name].shape)
+
+    # ------------------------------------------------------------------ activations
+    def allocate(self, B: int, H: int, W: int):
+        if self.shape == (B, H, W):
+            return
+        assert H % 32 == 0 and W % 32 == 0, "image size must be a multiple of 32"
+        dev = self.device
+        lib = self.lib
+        self.shape = (B, H, W)
+        self.act: Dict[str, torch.Tensor] = {}
+        self.gact: Dict[str, torch.Tensor] = {}
+        for b in self.g.bufs:
+            h, w = H // b.stride, W // b.stride
+            if b.name == "image":
+                shp = (B, H, W // 2, 8)
+            else:
+                shp = (B, h, w, b.C)
+            self.act[b.name] = torch.empty(shp, dtype=torch.bfloat16, device=dev)
+            if b.name != "image":
+                self.gact[b.name] = torch.empty(shp, dtype=torch.bfloat16, device=dev)
+        max_part = 0
+        for u in self.exec_units:
+            st = self.ustate[u.name]
+            if u.stem:
+                st.H, st.W = H, W // 2
+                st.Ho, st.Wo = H // 2, W // 2
+            else:
+                st.H, st.W = H // u.src.stride, W // u.src.stride
+                st.Ho, st.Wo = st.H // u.s, st.W // u.s
+            st.M = B * st.Ho * st.Wo
+            st.raw = torch.empty((B, st.Ho, st.Wo, u.cout), dtype=torch.bfloat16, device=dev)
+            st.T = lib.kodhip_conv_stats_slots(st.M, u.cout)
+            st.stats = torch.empty(2 * u.cout * st.T, dtype=torch.float32, device=dev)
+            st.sums = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
+            st.aff = torch.empty(4 * u.cout, dtype=torch.float32, device=dev)        # scale|shift|mean|rstd
+            st.T2 = lib.kodhip_bn_bwd_slots(st.M, u.cout)
+            st.bpart = torch.empty(2 * u.cout * st.T2, dtype=torch.float32, device=dev)
+            st.bsums = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
+            st.bsums_g = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
+            st.coef = torch.empty(3 * u.cout, dtype=torch.float32, device=dev)
+            splits = lib.kodhip_conv_wgrad_splits(st.M, u.cout, st.Kp)
+            max_part = max(max_part, splits * u.cout * st.Kp)
+        for h in self.g.heads:
+            hs = self.hstate[h.name]
+            hh, ww = H // h.stride, W // h.stride
+            hs.update(H=hh, W=ww, M=B * hh * ww)
+            hs["dy"] = torch.empty((B * hh * ww, self.head_npad), dtype=torch.bfloat16, device=dev)
+            hs["ws"] = torch.empty(512 * self.head_npad, dtype=torch.float32, device=dev)
+            splits = lib.kodhip_conv_wgrad_splits(hs["M"], self.head_npad, hs["Kp"])
+            max_part = max(max_part, splits * self.head_npad * hs["Kp"])
+        self.wg_part = torch.empty(max_part, dtype=torch.float32, device=dev)
+        # SPPF argmax indices
+        self.pool_idx = []
+        for op in self.g.ops:
+            if op.kind == "pool":
+                h, w = H // op.src.stride, W // op.src.stride
+                self.pool_idx.append(torch.empty((B, h, w, op.src.C), dtype=torch.uint8, device=dev))
+
+    # ------------------------------------------------------------------ helpers
+    def _ptr(self, v: View, grad=False):
+        t = (self.gact if grad else self.act)[v.buf.name]
+        return t.data_ptr()
+
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def pack_weights(self):
+        _lib.check(self.lib.kodhip_pack_weights(self.p_arena.data_ptr(), self.fpack.data_ptr(),
+                                                self.dpack.data_ptr(), self.pack_descs.data_ptr(),
+                                                self.pack_descs.shape[0], self.pack_blocks, self._stream()),
+                   "pack_weights")
+        self._packed_version = self.param_version
+
+    def _allreduce(self, t):
+        if self.world_size > 1:
+            torch.distributed.all_reduce(t, group=self.process_group)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, training: bool = True):
+        """x: [B,3,H,W] fp32 NCHW on this device.  Returns 3 tensors [B,A,h,w,5+nc] fp32 (ll, ml, hl)."""
+        lib, chk = self.lib, _lib.check
+        B, Cimg, H, W = x.shape
+        assert Cimg == 3 and x.dtype == torch.float32 and x.is_contiguous() and x.device == self.device
+        self.allocate(B, H, W)
+        s = self._stream()
+        if self._packed_version != self.param_version:
+            self.pack_weights()
+        chk(lib.kodhip_nchw_to_nhwc4(x.data_ptr(), self.act["image"].data_ptr(), B, 3, H, W, s), "nchw_to_nhwc4")
+        A, nc = self.g.num_anchors, self.g.num_classes
+        outs = []
+        pool_i = 0
+        fp, pa = self.fpack.data_ptr(), self.p_arena.data_ptr()
+        for op in self.g.ops:
+            if op.kind == "conv":
+                u: ConvUnit = op.unit
+                st = self.ustate[u.name]
+                C_ = u.cout
+                if u.stem:
+                    geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1, st.Kp)
+                else:
+                    geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p, st.Kp)
+                chk(lib.kodhip_conv_fwd_raw(self._ptr(u.src), fp + 2 * st.f_off, st.raw.data_ptr(),
+                                            st.stats.data_ptr(), *geo, C_, 0, s), u.name)
+                aff = st.aff.data_ptr()
+                if training:
+                    chk(lib.kodhip_bn_reduce_partials(st.stats.data_ptr(), st.sums.data_ptr(), C_, st.T, s), u.name)
+                    count = float(st.M)
+                    if self.sync_bn and self.world_size > 1:
+                        self._allreduce(st.sums)
+                        count *= self.world_size
+                    chk(lib.kodhip_bn_finalize(st.sums.data_ptr(), count, pa + 4 * st.g_off, pa + 4 * st.b_off,
+                                               self.rm_arena.data_ptr() + 4 * st.rs_off,
+                                               self.rv_arena.data_ptr() + 4 * st.rs_off, BN_MOMENTUM, BN_EPS,
+                                               aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
+                else:
+                    self._eval_affine(st)
+                res = u.residual
+                chk(lib.kodhip_bn_silu_apply(st.raw.data_ptr(), aff, aff + 4 * C_,
+                                             self._ptr(res) if res else None, res.buf.C if res else 0,
+                                             res.coff if res else 0,
+                                             self._ptr(u.dst), u.dst.buf.C, u.dst.coff, st.M, C_, s), u.name)
+            elif op.kind == "pool":
+                h, w = H // op.src.stride, W // op.src.stride
+                chk(lib.kodhip_maxpool5_fwd(self._ptr(op.src), op.src.buf.C, op.src.coff, self._ptr(op.dst),
+                                            op.dst.buf.C, op.dst.coff, self.pool_idx[pool_i].data_ptr(),
+                                            B, h, w, op.src.C, s), "maxpool")
+                pool_i += 1
+            elif op.kind == "up":
+                h, w = H // op.src.stride, W // op.src.stride
+                chk(lib.kodhip_upsample2x_fwd(self._ptr(op.src), op.src.buf.C, op.src.coff, self._ptr(op.dst),
+                                              op.dst.buf.C, op.dst.coff, B, h, w, op.src.C, s), "upsample")
+            else:
+                hu: HeadUnit = op.unit
+                hs = self.hstate[hu.name]
+                out = torch.empty((B, A, hs["H"], hs["W"], 5 + nc), dtype=torch.float32, device=self.device)
+                chk(lib.kodhip_conv_fwd_head(self._ptr(hu.src), fp + 2 * hs["f_off"], pa + 4 * hs["b_off"],
+                                             out.data_ptr(), B, hs["H"], hs["W"], hu.src.buf.C, hu.src.coff,
+                                             hu.cin, A, nc, hs["Kp"], s), hu.name)
+                outs.append(out)
+        if training:
+            self.nbt_arena += 1
+            self.training_ready = True
+        return outs
+
+    def _eval_affine(self, st):
+        """Eval-mode BN constants from running statistics (torch ops on tiny per-layer vectors)."""
+        C_ = st.u.cout
+        g = self.p_arena[st.g_off:st.g_off + C_]
+        b = self.p_arena[st.b_off:st.b_off + C_]
+        rm = self.rm_arena[st.rs_off:st.rs_off + C_]
+        rv = self.rv_arena[st.rs_off:st.rs_off + C_]
+        sc = g * torch.rsqrt(rv + BN_EPS)
+        st.aff[:C_] = sc
+        st.aff[C_:2 * C_] = b - rm * sc
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, head_grads: List[torch.Tensor]):
+        """head_grads: d loss / d (ll, ml, hl) head tensors.  Fills the gradient arena; returns nothing."""
+        assert self.training_ready, "backward() needs a preceding training forward()"
+        self.training_ready = False
+        lib, chk = self.lib, _lib.check
+        B, H, W = self.shape
+        s = self._stream()
+        A, nc = self.g.num_anchors, self.g.num_classes
+        ga = self.g_arena[self.g_cur]
+        gp = ga.data_ptr()
+        fp, dp = self.fpack.data_ptr(), self.dpack.data_ptr()
+        pa = self.p_arena.data_ptr()
+        wgp = self.wg_part.data_ptr()
+        touched = set()            # grad buffers already holding a (partial) sum
+
+        def acc_flag(v: View) -> int:
+            """0 = first writer (overwrite), 1 = accumulate; zero-fills on a partial first touch."""
+            name = v.buf.name
+            if name in touched:
+                return 1
+            touched.add(name)
+            if v.C != v.buf.C:
+                self.gact[name].zero_()
+                return 1
+            return 0
+
+        self._pending = []
+        bucket_hi = self.n_arena
+        pool_i = len(self.pool_idx)
+        head_i = len(self.g.heads)
+        for op in reversed(self.g.ops):
+            if op.kind == "head":
+                head_i -= 1
+                hu: HeadUnit = op.unit
+                hs = self.hstate[hu.name]
+                gten = head_grads[head_i].contiguous()
+                assert gten.shape == (B, A, hs["H"], hs["W"], 5 + nc) and gten.dtype == torch.float32
+                names = [f"{hu.name}.{k}_head.conv.bias" for k in ("box", "obj", "cls")]
+                offs = [self.layout[n][0] for n in names]
+                chk(lib.kodhip_head_bwd_prep(gten.data_ptr(), hs["dy"].data_ptr(), hs["ws"].data_ptr(),
+                                             gp + 4 * offs[0], gp + 4 * offs[1], gp + 4 * offs[2],
+                                             B, hs["H"] * hs["W"], A, nc, self.head_npad, s), hu.name)
+                src = hu.src
+                chk(lib.kodhip_conv_dgrad(hs["dy"].data_ptr(), dp + 2 * hs["d_off"], self._ptr(src, True),
+                                          B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
+                                          self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kdp"], self.head_npad, 0,
+                                          acc_flag(src), s), hu.name + ".dgrad")
+                chk(lib.kodhip_conv_wgrad(self._ptr(src), hs["dy"].data_ptr(), wgp, gp + 4 * hs["w_off"],
+                                          B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
+                                          self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kp"], self.head_npad, 0,
+                                          A * (5 + nc), 0, 1.0, s), hu.name + ".wgrad")
+            elif op.kind == "up":
+                h, w = H // op.src.stride, W // op.src.stride
+                chk(lib.kodhip_upsample2x_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
+                                              self._ptr(op.src, True), op.src.buf.C, op.src.coff,
+                                              acc_flag(op.src), B, h, w, op.src.C, s), "upsample_bwd")
+            elif op.kind == "pool":
+                pool_i -= 1
+                h, w = H // op.src.stride, W // op.src.stride
+                # src and dst are slices of the same (already initialised) concat gradient buffer
+                chk(lib.kodhip_maxpool5_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
+                                            self.pool_idx[pool_i].data_ptr(), self._ptr(op.src, True),
+                                            op.src.buf.C, op.src.coff, B, h, w, op.src.C, s), "maxpool_bwd")
+            else:
+                u: ConvUnit = op.unit
+                st = self.ustate[u.name]
+                C_ = u.cout
+                aff = st.aff.data_ptr()
+                dA = u.dst
+                chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
+                                                  aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
+                                                  st.bpart.data_ptr(), st.M, C_, s), u.name)
+                chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), C_, st.T2, s), u.name)
+                count = float(st.M)
+                gsum = st.bsums
+                if self.sync_bn and self.world_size > 1:
+                    st.bsums_g.copy_(st.bsums)
+                    self._allreduce(st.bsums_g)
+                    gsum = st.bsums_g
+                    count *= self.world_size
+                chk(lib.kodhip_bn_bwd_coeffs(st.bsums.data_ptr(), gsum.data_ptr(), count, pa + 4 * st.g_off,
+                                             aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off, gp + 4 * st.b_off,
+                                             st.coef.data_ptr(), C_, s), u.name)
+                res = u.residual
+                chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
+                                                 aff, aff + 4 * C_, st.coef.data_ptr(),
+                                                 self._ptr(res, True) if res else None,
+                                                 res.buf.C if res else 0, res.coff if res else 0,
+                                                 acc_flag(res) if res else 0, st.M, C_, s), u.name)
+                # st.raw now holds dY
+                if u.stem:
+                    geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1)
+                else:
+                    geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p)
+                    chk(lib.kodhip_conv_dgrad(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
+                                              *geo, st.Kdp, C_, 0, acc_flag(u.src), s), u.name + ".dgrad")
+                chk(lib.kodhip_conv_wgrad(self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
+                                          *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0, s), u.name + ".wgrad")
+            # gradient buckets complete from the arena's end toward its start
+            if self.world_size > 1 and op.kind in ("conv", "head"):
+                lo = st.w_off if op.kind == "conv" else hs["w_off"]
+                if (bucket_hi - lo) * 4 >= self.bucket_bytes or lo == 0:
+                    self._launch_bucket(ga, lo, bucket_hi)
+                    bucket_hi = lo
+        if self.world_size > 1 and bucket_hi > 0:
+            self._launch_bucket(ga, 0, bucket_hi)
+        self._publish_grads()
+
+    def _launch_bucket(self, ga, lo, hi):
+        self._pending.append(torch.distributed.all_reduce(ga[lo:hi], group=self.process_group, async_op=True))
+
+    def wait_grads(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def _publish_grads(self):
+        """Expose the arena slices as .grad (accumulating into an existing .grad like autograd would)."""
+        cur = self.g_arena[self.g_cur]
+        other = self.g_arena[self.g_cur ^ 1]
+        first = next(iter(self.layout))
+        existing = self.params[first].grad
+        if existing is not None and existing.data_ptr() == self._grad_view(first, other).data_ptr():
+            self.wait_grads()
+            other.add_(cur)                      # gradient accumulation across backward() calls
+            return
+        for n in self.layout:
+            p = self.params[n]
+            if p.grad is not None and p.grad.data_ptr() != self._grad_view(n, cur).data_ptr():
+                raise RuntimeError("mixed external .grad tensors are not supported; call zero_grad(set_to_none=True)")
+            p.grad = self._grad_view(n, cur)
+        self.g_cur ^= 1
+
+    def current_grad_arena(self):
+        """Arena holding the gradients published by the last backward()."""
+        return self.g_arena[self.g_cur ^ 1]
+
+    # ------------------------------------------------------------------ optimizer
+    def sgd_step(self, lr, momentum, weight_decay, grad_scale: float = 1.0):
+        """lr / momentum / weight_decay: 3-tuples for (bias_params, decay_params, norm_params)."""
+        self.wait_grads()
+        hyper = (C.c_float * 10)(*lr, *momentum, *weight_decay, grad_scale)
+        _lib.check(self.lib.kodhip_sgd_nesterov(self.p_arena.data_ptr(), self.current_grad_arena().data_ptr(),
+                                                self.m_arena.data_ptr(), self.gid.data_ptr(), self.n_arena,
+                                                hyper, self._stream()), "sgd")
+        self.param_version += 1
+
+    def mark_params_changed(self):
+        self.param_version += 1

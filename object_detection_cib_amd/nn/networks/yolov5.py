@@ -1,0 +1,147 @@
+"""Yolov5Network - drop-in for kod.nn.networks.yolov5.Yolov5Network (kod/nn/networks/yolov5.py:40-108).
+
+Same constructor signature, same ``state_dict()`` (360 keys for yv5s: ``backbone.stem.0.weight`` ...
+``hl_head.cls_head.conv.bias``), same seeded initial weights (parameters are created with the same
+torch modules in the same order), same output structure - but ``forward`` runs the static HIP program of
+``engine/`` instead of tracing nn.Modules, and the whole network is ONE autograd node whose backward is
+the explicit HIP backward program.  There is no CPU path: forward raises off-GPU.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Callable, NamedTuple
+
+import torch
+import torch.nn as nn
+
+from ...engine.graph import build_graph, P5_STAGES  # noqa: F401
+from ...engine.executor import Engine, BN_EPS, BN_MOMENTUM
+from ..heads.types import DetectionHeadResult
+
+Yolov5BatchNorm2d = partial(nn.BatchNorm2d, eps=BN_EPS, momentum=BN_MOMENTUM)     # networks/yolov5.py:24
+
+
+class Yolov5NetworkResult(NamedTuple):
+    ll: DetectionHeadResult
+    ml: DetectionHeadResult
+    hl: DetectionHeadResult
+
+
+class _Slot(nn.Module):
+    """Name-space node: only holds children so parameter paths equal the reference's."""
+
+    def forward(self, *a, **k):       # pragma: no cover
+        raise RuntimeError("holder module: the network runs through the HIP engine, not nn.Module.forward")
+
+
+def _ensure(root: nn.Module, path: str) -> nn.Module:
+    node = root
+    for part in path.split("."):
+        if part not in node._modules:
+            node.add_module(part, _Slot())
+        node = node._modules[part]
+    return node
+
+
+class _NetFn(torch.autograd.Function):
+    """Whole-network autograd node: forward/backward are the engine's op lists."""
+
+    @staticmethod
+    def forward(ctx, net, x, _anchor):
+        ctx.net = net
+        outs = net._engine.forward(x, training=True)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.net._engine.backward(list(grads))
+        return None, None, None
+
+
+class Yolov5Network(nn.Module):
+    def __init__(
+        self,
+        num_anchors_per_cell: int,
+        num_classes: int,
+        norm_layer: Callable[..., nn.Module] = Yolov5BatchNorm2d,
+        activation_layer: Callable[..., nn.Module] = None,
+        widen_factor: float = 1.0,
+        deepen_factor: float = 1.0,
+    ):
+        super().__init__()
+        if norm_layer is not Yolov5BatchNorm2d:
+            probe = norm_layer(8)
+            if not (isinstance(probe, nn.BatchNorm2d) and probe.eps == BN_EPS and probe.momentum == BN_MOMENTUM):
+                raise ValueError("the HIP path implements BatchNorm2d(eps=1e-3, momentum=0.03) + SiLU only")
+        self.num_classes = num_classes
+        self.num_anchors_per_cell = num_anchors_per_cell
+        self.widen_factor, self.deepen_factor = widen_factor, deepen_factor
+        self.graph = build_graph(num_anchors_per_cell, num_classes, widen_factor, deepen_factor)
+        # parameters: real torch modules as holders, created in the reference's construction order
+        for u in self.graph.units:
+            slot = _ensure(self, u.name)
+            cin = 3 if u.stem else u.cin
+            slot.add_module("0", nn.Conv2d(cin, u.cout, 6 if u.stem else u.k, u.s, u.p, bias=False))
+            slot.add_module("1", norm_layer(u.cout))
+        A, nc = num_anchors_per_cell, num_classes
+        for h in self.graph.heads:
+            for key, p, shift in (("box", 4, 0.0), ("obj", 1, math.log(8 / (640 / h.stride) ** 2)),
+                                  ("cls", nc, math.log(0.6 / (nc - 0.99999)))):     # heads/yolov5.py:65-73,113-121
+                conv = nn.Conv2d(h.cin, A * p, 1)
+                if shift:
+                    with torch.no_grad():
+                        conv.bias.add_(shift)
+                _ensure(self, f"{h.name}.{key}_head").add_module("conv", conv)
+        self._engine: Engine | None = None
+        self._engine_device = None
+
+    # ------------------------------------------------------------------ engine plumbing
+    def engine(self) -> Engine:
+        dev = next(self.parameters()).device
+        if self._engine is None or self._engine_device != dev:
+            if dev.type != "cuda":
+                raise RuntimeError("Yolov5Network (HIP) must be on an MI355X: call .cuda() first; no CPU fallback")
+            eng = Engine(self.graph, dict(self.named_parameters()), dict(self.named_buffers()))
+            eng._build_arenas(dev)
+            self._engine, self._engine_device = eng, dev
+        return self._engine
+
+    def configure_distributed(self, process_group=None, sync_batchnorm: bool = True, bucket_mb: float = 8.0):
+        """Data-parallel mode: RCCL all-reduce of gradient buckets overlapped with backward (+ SyncBN),
+        the equivalent of Lightning's strategy=ddp / sync_batchnorm=True (kod/configs/trainer/ddp.yaml:4-9)."""
+        import torch.distributed as dist
+        eng = self.engine()
+        eng.process_group = process_group
+        eng.world_size = dist.get_world_size(process_group)
+        eng.sync_bn = sync_batchnorm
+        eng.bucket_bytes = int(bucket_mb * (1 << 20))
+        if eng.world_size > 1:
+            dist.broadcast(eng.p_arena, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                           group=process_group)
+            dist.broadcast(eng.rm_arena, src=0, group=process_group)
+            dist.broadcast(eng.rv_arena, src=0, group=process_group)
+            eng.mark_params_changed()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        if self._engine is not None:
+            self._engine.mark_params_changed()
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward_raw(self, x: torch.Tensor):
+        """Three contiguous [B, A, h, w, 5+nc] fp32 tensors (ll, ml, hl)."""
+        eng = self.engine()
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        if self.training and torch.is_grad_enabled():
+            anchor = next(self.parameters())
+            return _NetFn.apply(self, x, anchor)
+        with torch.no_grad():
+            return tuple(eng.forward(x, training=self.training))
+
+    def forward(self, x: torch.Tensor) -> Yolov5NetworkResult:
+        raws = self.forward_raw(x)
+        return Yolov5NetworkResult(*[DetectionHeadResult(t[..., 0:4], t[..., 4:5], t[..., 5:]) for t in raws])

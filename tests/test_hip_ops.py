@@ -1,0 +1,295 @@
+"""GPU parity tests of the individual HIP kernels against plain torch fp32 on the same (bf16-rounded)
+inputs.  All calls go through the C ABI (ctypes).  Tolerances: the kernels accumulate in fp32 and round
+outputs to bf16 (rel 2^-9), so comparisons use rtol 1e-2 on bf16 outputs and 2e-3 on fp32 outputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from object_detection_cib_amd import _lib  # noqa: E402
+from hip_helpers import bf, nchw, nhwc, pack, pad, stream, conv_fwd_raw  # noqa: E402
+
+
+def _close(a, b, rtol, atol, what=""):
+    a, b = a.double(), b.double()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{a.numel()} off, max err {err.max().item():.4g}, ref max {b.abs().max().item():.4g}"
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, s, p
+    (2, 32, 16, 16, 32, 1, 1, 0),
+    (2, 64, 20, 12, 64, 1, 1, 0),
+    (1, 128, 8, 8, 256, 1, 1, 0),
+    (2, 32, 16, 16, 32, 3, 1, 1),
+    (2, 64, 12, 20, 128, 3, 1, 1),
+    (2, 32, 16, 16, 64, 3, 2, 1),
+    (1, 128, 10, 10, 128, 3, 2, 1),
+    (3, 48, 9, 7, 96, 3, 1, 1),          # yv5m-like channel counts, odd spatial dims
+    (1, 512, 4, 4, 512, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    B, Cin, H, W, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = bf(torch.randn(B, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, s, p)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    lib = _lib.lib()
+    pk = pack([w])
+    xb = nhwc(x)
+    yb, stats = conv_fwd_raw(xb, (0, Cin), pk, s, p)
+    got = nchw(yb)
+    _close(got, y.detach(), 1e-2, 2e-2, "fwd")
+    # BN partial statistics are sums over the stored (bf16-rounded) outputs
+    ssum = stats[0].sum(-1).cpu().double()
+    ssq = stats[1].sum(-1).cpu().double()
+    _close(ssum, got.double().sum((0, 2, 3)), 1e-4, 1e-2, "stats sum")
+    _close(ssq, (got.double() ** 2).sum((0, 2, 3)), 1e-4, 1e-2, "stats sumsq")
+    # dgrad
+    Ho, Wo = y.shape[2:]
+    dyb = nhwc(dy)
+    dxb = torch.zeros((B, H, W, Cin), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.kodhip_conv_dgrad(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
+                                     Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 0, stream()), "dgrad")
+    _close(nchw(dxb), xr.grad, 1e-2, 3e-2, "dgrad")
+    # accumulate form
+    _lib.check(lib.kodhip_conv_dgrad(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
+                                     Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 1, stream()), "dgrad acc")
+    _close(nchw(dxb), 2 * xr.grad, 2e-2, 6e-2, "dgrad accumulate")
+    # wgrad
+    M = B * Ho * Wo
+    splits = lib.kodhip_conv_wgrad_splits(M, Cout, pk["Kp"])
+    part = torch.zeros(splits * Cout * pk["Kp"], dtype=torch.float32, device="cuda")
+    gw = torch.zeros_like(w, device="cuda")
+    _lib.check(lib.kodhip_conv_wgrad(xb.data_ptr(), dyb.data_ptr(), part.data_ptr(), gw.data_ptr(), B, H, W, Cin, 0,
+                                     Cin, Cout, k, k, s, s, p, p, pk["Kp"], Cout, 0, Cout, 0, 1.0, stream()), "wgrad")
+    _close(gw.cpu(), wr.grad, 2e-3, 2e-3 * wr.grad.abs().max().item(), "wgrad")
+
+
+def test_conv_channel_slices():
+    """Input read from / output written into channel slices of wider buffers (concat elimination)."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 12, 12
+    x = bf(torch.randn(B, 64, H, W, generator=g))
+    w = bf(torch.randn(32, 32, 3, 3, generator=g) / 17)
+    ref = F.conv2d(x[:, 16:48], w, None, 1, 1)
+    pk = pack([w])
+    xb = nhwc(x)
+    out = torch.full((B, H, W, 96), 7.0, dtype=torch.bfloat16, device="cuda")
+    conv_fwd_raw(xb, (16, 32), pk, 1, 1, out=out, ycoff=40)
+    got = nchw(out)
+    _close(got[:, 40:72], ref, 1e-2, 2e-2, "slice conv")
+    assert (got[:, :40] == 7).all() and (got[:, 72:] == 7).all()
+
+
+def test_stem_conv():
+    """6x6/s2/p2 stem on a 3-channel image through the pixel-pair layout."""
+    g = torch.Generator().manual_seed(9)
+    B, H, W, Cout = 2, 32, 64, 32
+    x = bf(torch.rand(B, 3, H, W, generator=g))
+    w = bf(torch.randn(Cout, 3, 6, 6, generator=g) / 10)
+    xr, wr = x.clone(), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, 2, 2)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    lib = _lib.lib()
+    img = torch.empty((B, H, W // 2, 8), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.kodhip_nchw_to_nhwc4(x.cuda().data_ptr(), img.data_ptr(), B, 3, H, W, stream()), "nhwc4")
+    pk = pack([w], stem=True)
+    out = torch.zeros((B, H // 2, W // 2, Cout), dtype=torch.bfloat16, device="cuda")
+    T = lib.kodhip_conv_stats_slots(B * (H // 2) * (W // 2), Cout)
+    stats = torch.zeros(2 * Cout * T, dtype=torch.float32, device="cuda")
+    _lib.check(lib.kodhip_conv_fwd_raw(img.data_ptr(), pk["f"].data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                       B, H, W // 2, 8, 0, 8, Cout, 6, 3, 2, 1, 2, 1, pk["Kp"], Cout, 0, stream()), "stem")
+    _close(nchw(out), y.detach(), 1e-2, 2e-2, "stem fwd")
+    dyb = nhwc(dy)
+    M = B * (H // 2) * (W // 2)
+    splits = lib.kodhip_conv_wgrad_splits(M, Cout, pk["Kp"])
+    part = torch.zeros(splits * Cout * pk["Kp"], dtype=torch.float32, device="cuda")
+    gw = torch.zeros_like(w, device="cuda")
+    _lib.check(lib.kodhip_conv_wgrad(img.data_ptr(), dyb.data_ptr(), part.data_ptr(), gw.data_ptr(), B, H, W // 2, 8, 0,
+                                     8, Cout, 6, 3, 2, 1, 2, 1, pk["Kp"], Cout, 0, Cout, 1, 1.0, stream()), "stem wgrad")
+    _close(gw.cpu(), wr.grad, 2e-3, 2e-3 * wr.grad.abs().max().item(), "stem wgrad")
+
+
+def test_head_conv_fwd_bwd():
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W, A, nc = 2, 128, 8, 8, 3, 10
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    ws = [bf(torch.randn(n, C, 1, 1, generator=g) / C ** 0.5) for n in (4 * A, A, nc * A)]
+    bs = [torch.randn(n, generator=g) for n in (4 * A, A, nc * A)]
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    outs = []
+    for w, b, p in zip(wr, br, (4, 1, nc)):
+        y = F.conv2d(xr, w, b)
+        outs.append(y.view(B, A, p, H, W).permute(0, 1, 3, 4, 2))
+    ref = torch.cat(outs, -1)                                   # [B,A,H,W,15]
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    lib = _lib.lib()
+    npad = pad(A * (5 + nc), 8)
+    pk = pack(ws, ntot=npad)
+    xb = nhwc(x)
+    bias = torch.cat(bs).cuda()
+    out = torch.zeros((B, A, H, W, 5 + nc), dtype=torch.float32, device="cuda")
+    _lib.check(lib.kodhip_conv_fwd_head(xb.data_ptr(), pk["f"].data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                        B, H, W, C, 0, C, A, nc, pk["Kp"], stream()), "head")
+    _close(out.cpu(), ref.detach(), 2e-3, 2e-3, "head fwd")
+    # backward
+    dy = torch.zeros((B * H * W, npad), dtype=torch.bfloat16, device="cuda")
+    ws_ = torch.zeros(512 * npad, dtype=torch.float32, device="cuda")
+    db = [torch.zeros(n, device="cuda") for n in (4 * A, A, nc * A)]
+    _lib.check(lib.kodhip_head_bwd_prep(gout.cuda().contiguous().data_ptr(), dy.data_ptr(), ws_.data_ptr(),
+                                        db[0].data_ptr(), db[1].data_ptr(), db[2].data_ptr(), B, H * W, A, nc, npad,
+                                        stream()), "head prep")
+    for d, r in zip(db, br):
+        _close(d.cpu(), r.grad, 1e-4, 1e-4, "head bias grad")
+    dx = torch.zeros((B, H, W, C), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.kodhip_conv_dgrad(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, W, C, 0, C, npad, 1, 1, 1, 1,
+                                     0, 0, pk["Kdp"], npad, 0, 0, stream()), "head dgrad")
+    _close(nchw(dx), xr.grad, 2e-2, 3e-2, "head dgrad")
+    splits = lib.kodhip_conv_wgrad_splits(B * H * W, npad, pk["Kp"])
+    part = torch.zeros(splits * npad * pk["Kp"], dtype=torch.float32, device="cuda")
+    gw = torch.zeros(A * (5 + nc), C, device="cuda")
+    _lib.check(lib.kodhip_conv_wgrad(xb.data_ptr(), dy.data_ptr(), part.data_ptr(), gw.data_ptr(), B, H, W, C, 0, C, npad,
+                                     1, 1, 1, 1, 0, 0, pk["Kp"], npad, 0, A * (5 + nc), 0, 1.0, stream()), "head wgrad")
+    refw = torch.cat([w.grad.reshape(w.shape[0], C) for w in wr], 0)
+    _close(gw.cpu(), refw, 1e-2, 1e-2 * refw.abs().max().item(), "head wgrad")
+
+
+@pytest.mark.parametrize("C,res", [(32, False), (64, True), (48, True), (256, False)])
+def test_bn_silu_fwd_bwd(C, res):
+    g = torch.Generator().manual_seed(C)
+    B, H, W = 3, 10, 6
+    M = B * H * W
+    y = bf(torch.randn(B, C, H, W, generator=g) * 2 + 0.5)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    ident = bf(torch.randn(B, C, H, W, generator=g)) if res else None
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.03)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    yr = y.clone().requires_grad_(True)
+    ir = ident.clone().requires_grad_(True) if res else None
+    out = F.silu(bn(yr))
+    if res:
+        out = out + ir
+    dout = bf(torch.randn(out.shape, generator=g))
+    out.backward(dout)
+    lib = _lib.lib()
+    yb = nhwc(y)
+    # statistics from the tensor itself (the conv epilogue is tested separately)
+    y2 = yb.float().view(M, C)
+    stats = torch.stack((y2.sum(0), (y2 * y2).sum(0))).contiguous().view(2, C, 1)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    _lib.check(lib.kodhip_bn_reduce_partials(stats.data_ptr(), sums.data_ptr(), C, 1, stream()), "reduce")
+    aff = torch.zeros(4 * C, device="cuda")
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    gm, bt = gamma.cuda(), beta.cuda()
+    a = aff.data_ptr()
+    _lib.check(lib.kodhip_bn_finalize(sums.data_ptr(), float(M), gm.data_ptr(), bt.data_ptr(), rm.data_ptr(),
+                                      rv.data_ptr(), 0.03, 1e-3, a, a + 4 * C, a + 8 * C, a + 12 * C, C, 1, stream()), "fin")
+    _close(rm.cpu(), bn.running_mean, 1e-4, 1e-5, "running_mean")
+    _close(rv.cpu(), bn.running_var, 1e-4, 1e-5, "running_var")
+    ldo = C + 16
+    ob = torch.zeros((B, H, W, ldo), dtype=torch.bfloat16, device="cuda")
+    ib = nhwc(ident) if res else None
+    _lib.check(lib.kodhip_bn_silu_apply(yb.data_ptr(), a, a + 4 * C, ib.data_ptr() if res else None, C, 0,
+                                        ob.data_ptr(), ldo, 8, M, C, stream()), "apply")
+    _close(nchw(ob)[:, 8:8 + C], out.detach(), 1e-2, 1e-2, "bn+silu fwd")
+    # backward
+    dob = torch.zeros((B, H, W, ldo), dtype=torch.bfloat16, device="cuda")
+    dob[..., 8:8 + C] = nhwc(dout)
+    T2 = lib.kodhip_bn_bwd_slots(M, C)
+    bpart = torch.zeros(2 * C * T2, device="cuda")
+    _lib.check(lib.kodhip_bn_silu_bwd_reduce(dob.data_ptr(), ldo, 8, yb.data_ptr(), a, a + 4 * C, a + 8 * C, a + 12 * C,
+                                             bpart.data_ptr(), M, C, stream()), "bwd reduce")
+    bs = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    _lib.check(lib.kodhip_bn_reduce_partials(bpart.data_ptr(), bs.data_ptr(), C, T2, stream()), "bwd sums")
+    dg, dbt, coef = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(3 * C, device="cuda")
+    _lib.check(lib.kodhip_bn_bwd_coeffs(bs.data_ptr(), bs.data_ptr(), float(M), gm.data_ptr(), a + 8 * C, a + 12 * C,
+                                        dg.data_ptr(), dbt.data_ptr(), coef.data_ptr(), C, stream()), "coeffs")
+    _close(dg.cpu(), bn.weight.grad, 5e-3, 5e-3 * bn.weight.grad.abs().max().item(), "dgamma")
+    _close(dbt.cpu(), bn.bias.grad, 5e-3, 5e-3 * bn.bias.grad.abs().max().item(), "dbeta")
+    di = torch.ones((B, H, W, C), dtype=torch.bfloat16, device="cuda") if res else None
+    _lib.check(lib.kodhip_bn_silu_bwd_apply(dob.data_ptr(), ldo, 8, yb.data_ptr(), a, a + 4 * C, coef.data_ptr(),
+                                            di.data_ptr() if res else None, C, 0, 1, M, C, stream()), "bwd apply")
+    _close(nchw(yb), yr.grad, 2e-2, 2e-2 * yr.grad.abs().max().item(), "dY")
+    if res:
+        _close(nchw(di), ir.grad + 1.0, 1e-2, 1e-2, "identity grad (accumulated on ones)")
+
+
+def test_maxpool_chain_and_upsample():
+    g = torch.Generator().manual_seed(1)
+    B, C, H, W = 2, 16, 9, 11
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    pool = torch.nn.MaxPool2d(5, 1, 2)
+    y1 = pool(xr); y2 = pool(y1); y3 = pool(y2)
+    cat = torch.cat([xr, y1, y2, y3], 1)
+    dcat = bf(torch.randn(cat.shape, generator=g))
+    cat.backward(dcat)
+    lib = _lib.lib()
+    buf = torch.zeros((B, H, W, 4 * C), dtype=torch.bfloat16, device="cuda")
+    buf[..., :C] = nhwc(x)
+    idx = [torch.zeros((B, H, W, C), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    for q in range(3):
+        _lib.check(lib.kodhip_maxpool5_fwd(buf.data_ptr(), 4 * C, q * C, buf.data_ptr(), 4 * C, (q + 1) * C,
+                                           idx[q].data_ptr(), B, H, W, C, stream()), "pool")
+    assert torch.equal(nchw(buf), cat.detach())
+    gb = nhwc(dcat)
+    for q in (2, 1, 0):
+        _lib.check(lib.kodhip_maxpool5_bwd(gb.data_ptr(), 4 * C, (q + 1) * C, idx[q].data_ptr(), gb.data_ptr(), 4 * C,
+                                           q * C, B, H, W, C, stream()), "pool bwd")
+    _close(nchw(gb)[:, :C], xr.grad, 2e-2, 2e-2, "pool chain grad")
+    # upsample
+    up = F.interpolate(xr, scale_factor=2, mode="nearest")
+    dup = bf(torch.randn(up.shape, generator=g))
+    xr.grad = None
+    up.backward(dup)
+    xb = nhwc(x)
+    ub = torch.zeros((B, 2 * H, 2 * W, C + 8), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.kodhip_upsample2x_fwd(xb.data_ptr(), C, 0, ub.data_ptr(), C + 8, 8, B, H, W, C, stream()), "up")
+    assert torch.equal(nchw(ub)[:, 8:], up.detach())
+    dub = torch.zeros_like(ub)
+    dub[..., 8:] = nhwc(dup)
+    dx = torch.ones((B, H, W, C), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.kodhip_upsample2x_bwd(dub.data_ptr(), C + 8, 8, dx.data_ptr(), C, 0, 1, B, H, W, C, stream()), "up bwd")
+    _close(nchw(dx), xr.grad + 1, 1e-2, 2e-2, "upsample grad (accumulate)")
+
+
+def test_sgd_nesterov():
+    from oracle import optim as O
+    g = torch.Generator().manual_seed(2)
+    n = 64 * 7
+    p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g)
+    gid = torch.tensor([0, 1, 2, 1, 255, 0, 2], dtype=torch.uint8)
+    lr, mom, wd = (0.1, 0.01, 0.02), (0.8, 0.9, 0.937), (0.0, 5e-4, 0.0)
+    pc, buf = p.clone().cuda(), torch.zeros(n, device="cuda")
+    lib = _lib.lib()
+    import ctypes as C
+    refp, refb = p.clone(), [None] * 7
+    for step in range(3):
+        hyper = (C.c_float * 10)(*lr, *mom, *wd, 0.5)
+        _lib.check(lib.kodhip_sgd_nesterov(pc.data_ptr(), gr.cuda().data_ptr(), buf.data_ptr(), gid.cuda().data_ptr(), n,
+                                           hyper, stream()), "sgd")
+        for k in range(7):
+            gi = int(gid[k])
+            if gi > 2:
+                continue
+            sl = slice(64 * k, 64 * k + 64)
+            pk = refp[sl]
+            refb[k] = O.sgd_nesterov_step(pk, gr[sl] * 0.5, refb[k], lr[gi], mom[gi], wd[gi])
+    _close(pc.cpu(), refp, 1e-6, 1e-6, "sgd")
