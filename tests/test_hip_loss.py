@@ -96,11 +96,15 @@ def test_loss_full_size_properties():
     assert np.isfinite(outs[0][0]) and outs[0][0] == outs[1][0]
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
-    # oracle on CPU at this size takes a few seconds
+    # oracle on CPU at this size takes a few seconds; single thread so that torch's CPU index_put_ is
+    # sequential ("last row wins" on duplicate cells, the reference's small-batch behaviour)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
     ref_heads = [[t.clone().requires_grad_(True) for t in h] for h in heads]
     ro = D.yolo_loss(size, size, NetOut(*[HeadOut(*h) for h in ref_heads]), [D.Target(b, l) for b, l in tg])
     rt = D.train_step_total(ro, B)
     rt.backward()
+    torch.set_num_threads(nthreads)
     np.testing.assert_allclose(outs[0][0], rt.item(), rtol=1e-5)
     for h, gr in zip(ref_heads, outs[0][1]):
         ref = torch.cat([t.grad for t in h], -1)

@@ -253,7 +253,7 @@ def test_maxpool_chain_and_upsample():
     for q in (2, 1, 0):
         _lib.check(lib.kodhip_maxpool5_bwd(gb.data_ptr(), 4 * C, (q + 1) * C, idx[q].data_ptr(), gb.data_ptr(), 4 * C,
                                            q * C, B, H, W, C, stream()), "pool bwd")
-    _close(nchw(gb)[:, :C], xr.grad, 2e-2, 2e-2, "pool chain grad")
+    _close(nchw(gb)[:, :C], xr.grad, 2e-2, 5e-3 * xr.grad.abs().max().item(), "pool chain grad")
     # upsample
     up = F.interpolate(xr, scale_factor=2, mode="nearest")
     dup = bf(torch.randn(up.shape, generator=g))
@@ -281,9 +281,10 @@ def test_sgd_nesterov():
     lib = _lib.lib()
     import ctypes as C
     refp, refb = p.clone(), [None] * 7
+    grc, gidc = gr.cuda(), gid.cuda()
     for step in range(3):
         hyper = (C.c_float * 10)(*lr, *mom, *wd, 0.5)
-        _lib.check(lib.kodhip_sgd_nesterov(pc.data_ptr(), gr.cuda().data_ptr(), buf.data_ptr(), gid.cuda().data_ptr(), n,
+        _lib.check(lib.kodhip_sgd_nesterov(pc.data_ptr(), grc.data_ptr(), buf.data_ptr(), gidc.data_ptr(), n,
                                            hyper, stream()), "sgd")
         for k in range(7):
             gi = int(gid[k])
