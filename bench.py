@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native YOLOv5-s training step (BASELINE.json metric: images/sec, 640 px).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + target assignment + loss + backward + (gradient all-reduce) + Nesterov-SGD on a
+synthetic batch that is already resident in HBM (BASELINE configs[1]: yv5s, coco-zipf-like targets,
+batch 64 per GPU, 640 px, bf16 storage / fp32 accumulate).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per image, SURVEY.md 8(d) / BASELINE.md section 2 (yv5s, nc=10, 640x640)
+ALGO_BYTES_PER_IMG_BF16 = 371.5e6        # 3 * (sum conv inputs + sum conv outputs) * 2 B
+ALGO_FLOP_PER_IMG = 46.785e9             # fwd + dgrad + wgrad, 2*MAC
+HBM_PEAK = 8.0e12                        # B/s, MI355X_MICROARCH.md chip table
+
+
+def synth_batch(B, size, nc, seed, device):
+    from oracle import synth          # input generator only (no oracle compute in the timed path)
+    x, tg = synth.batch(B, size, nc, seed)
+    tg = synth.targets(B, size, nc, seed, nmin=4, nmax=30)     # mosaic-like box counts (4 source images)
+    from object_detection_cib_amd.data.detection import DetectionTarget
+    return x.to(device), tuple(DetectionTarget(b.to(device), l.to(device)) for b, l in tg)
+
+
+def build(nc, device, seed=2023):
+    from object_detection_cib_amd.core.anchors.info import voc_anchor_info
+    from object_detection_cib_amd.core.bbox.iou import IoUCalculator
+    from object_detection_cib_amd.core.label_assignment.yv5 import Yolov5LabelAssigner, AssignmentAnchorInfo
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.loss import Yolov5Loss, Yolov5LossParams
+    from object_detection_cib_amd.nn.networks.yolov5 import Yolov5Network
+    torch.manual_seed(seed)
+    net = Yolov5Network(3, nc, widen_factor=0.5, deepen_factor=0.33).to(device).train()
+    asg = Yolov5LabelAssigner(AssignmentAnchorInfo(voc_anchor_info(8), voc_anchor_info(16), voc_anchor_info(32)), 4.0)
+    loss = Yolov5Loss(asg, Yolov5LossParams.get_default(), IoUCalculator("ciou", 1e-7), None)
+    return net, loss
+
+
+def cpu_baseline(seconds=15.0):
+    """The CPU oracle (pure-torch fp32 restatement of the reference trainer step) timed on the host cores:
+    BASELINE configs[0] = yv5s, B=2, 640 px, fwd + assigner + loss + bwd + SGD."""
+    from oracle import detection as D, optim as O, synth
+    from oracle.network import OracleYolov5
+    torch.manual_seed(2023)
+    net = OracleYolov5(3, 10, 0.5, 0.33).train()
+    bias, decay, norm = O.param_groups(net)
+    opt = torch.optim.SGD([dict(params=bias, weight_decay=0.0), dict(params=decay, weight_decay=5e-4),
+                           dict(params=norm, weight_decay=0.0)], lr=0.01, momentum=0.937, nesterov=True)
+    x, tg = synth.batch(2, 640, 10, 2023)
+    tg = [D.Target(b, l) for b, l in synth.targets(2, 640, 10, 2023, nmin=4, nmax=30)]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        D.train_step_total(D.yolo_loss(640, 640, net(x), tg), 2).backward()
+        opt.step()
+    step()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(2 * n / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} train steps of yv5s B=2 640px fp32 (oracle/ CPU restatement) in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    nc, B, S = 10, args.batch, args.size
+    net, loss_fn = build(nc, device)
+    eng = net.engine()
+    if world > 1:
+        net.configure_distributed(None, sync_batchnorm=not args.no_sync_bn)
+    from object_detection_cib_amd.core.types import FeatureShape
+    x, targets = synth_batch(B, S, nc, 2023 + rank, device)
+    shape = FeatureShape(width=S, height=S)
+    # hyper-parameters of global step 0 of the reference schedule (warm-up start, warmup.py:39-58)
+    lr, mom, wd = (0.1, 0.0, 0.0), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0)
+    lr = (0.1, 1e-4, 1e-4)    # non-zero so every parameter really moves
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        res = net(x)
+        lr_ = loss_fn(shape, res, targets)
+        total = B * (lr_.localization + lr_.classification + lr_.objectness)
+        total.backward()
+        eng.sgd_step(lr, mom, wd, 1.0 / world)
+        return total
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # dominant-kernel timing with events on the launch stream (forward implicit-GEMM conv family)
+    eng.profile = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.profile
+    eng.profile = None
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(last.item())
+
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        # roofline of the dominant kernel family: algorithmic bytes = read input once + write output once
+        k_ms = sum(a.elapsed_time(b) for a, b, _ in prof)
+        k_bytes = sum(nb for _, _, nb in prof)
+        n_launch = max(len(prof), 1)
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "images/sec YOLOv5s 640px train", "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "yv5s coco-zipf-like synthetic, 640px, bf16 storage/fp32 accumulate, "
+                                   f"batch {B}/GPU, fwd+assign+loss+bwd+SGD, targets 4-30 boxes/img",
+                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if world > 1 and not args.no_sync_bn else "")},
+            "final_loss": final_loss,
+            "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_img": ALGO_BYTES_PER_IMG_BF16,
+                              "achieved": round(ips / world * ALGO_BYTES_PER_IMG_BF16 / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                              "unit": "GB/s", "frac": round(ips / world * ALGO_BYTES_PER_IMG_BF16 / HBM_PEAK, 4),
+                              "tflops": round(ips / world * ALGO_FLOP_PER_IMG / 1e12, 1)},
+            "roofline": {"kernel": "conv_igemm_kernel<MODE_RAW> (forward conv, all 57 layers)", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": None,
+                         "avg_launch_us": round(1e3 * k_ms / n_launch, 2), "launches": len(prof),
+                         "algorithmic_bytes_per_launch_avg": round(k_bytes / n_launch)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

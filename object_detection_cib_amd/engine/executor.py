@@ -50,6 +50,7 @@ class Engine:
         self._pending = []
         self._packed_version = -1
         self.param_version = 0
+        self.profile = None           # list of (start_event, end_event, algorithmic bytes) for forward convs
 
     # ------------------------------------------------------------------ arenas
     def _build_arenas(self, device):
@@ -271,8 +272,16 @@ class Engine:
                     geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1, st.Kp)
                 else:
                     geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p, st.Kp)
+                if self.profile is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 chk(lib.kodhip_conv_fwd_raw(self._ptr(u.src), fp + 2 * st.f_off, st.raw.data_ptr(),
                                             st.stats.data_ptr(), *geo, C_, 0, s), u.name)
+                if self.profile is not None:
+                    e1.record()
+                    cin_true = 3 if u.stem else u.cin
+                    in_px = B * H * W if u.stem else B * st.H * st.W
+                    self.profile.append((e0, e1, 2 * (in_px * cin_true + st.M * C_)))
                 aff = st.aff.data_ptr()
                 if training:
                     chk(lib.kodhip_bn_reduce_partials(st.stats.data_ptr(), st.sums.data_ptr(), C_, st.T, s), u.name)
