@@ -67,6 +67,14 @@ int kodhip_bn_finalize(const double* sums, double count, const float* gamma, con
                        float* running_mean, float* running_var, float momentum, float eps,
                        float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
                        kodStream_t stream);
+/* single-GPU forms: partial slabs -> constants in one launch (no cross-rank all-reduce in between) */
+int kodhip_bn_finalize_partials(const float* partials, int T, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps,
+                                float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
+                                kodStream_t stream);
+int kodhip_bn_bwd_coeffs_partials(const float* partials, int T, double count, const float* gamma, const float* mean,
+                                  const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
+                                  kodStream_t stream);
 int kodhip_bn_silu_apply(const void* y, const float* scale, const float* shift,
                          const void* residual, int ldr, int rcoff,
                          void* out, int ldo, int ocoff, long M, int C, kodStream_t stream);
@@ -112,7 +120,7 @@ int kodhip_assign_targets(const double* boxes, const long* labels, const int* sa
 typedef struct KodLossLevel {
   const float* logits; float* grad;
   const int* idx; const int* label; const float* gt; const float* anc; const int* count;
-  int* cellmaps; float* rowgrad; float* tobj;
+  int* cellmaps; int* rowprev; float* rowgrad; float* tobj;
   int fh, fw;
   float balance;
 } KodLossLevel;

@@ -18,7 +18,7 @@ class KodAssignLevel(C.Structure):
 
 class KodLossLevel(C.Structure):
     _fields_ = [("logits", vp), ("grad", vp), ("idx", vp), ("label", vp), ("gt", vp), ("anc", vp),
-                ("count", vp), ("cellmaps", vp), ("rowgrad", vp), ("tobj", vp),
+                ("count", vp), ("cellmaps", vp), ("rowprev", vp), ("rowgrad", vp), ("tobj", vp),
                 ("fh", i32), ("fw", i32), ("balance", f32)]
 
 
@@ -38,6 +38,8 @@ SIGNATURES = {
     "kodhip_conv_wgrad": (i32, [vp, vp, vp, vp] + [i32] * 18 + [f32, vp]),
     "kodhip_bn_reduce_partials": (i32, [vp, vp, i32, i32, vp]),
     "kodhip_bn_finalize": (i32, [vp, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
+    "kodhip_bn_finalize_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
+    "kodhip_bn_bwd_coeffs_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, vp]),
     "kodhip_bn_silu_apply": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, vp]),
     "kodhip_bn_bwd_slots": (i32, [i64, i32]),
     "kodhip_bn_silu_bwd_reduce": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i32, vp]),

@@ -47,6 +47,57 @@ __global__ void bn_finalize_kernel(const double* sums, double count, const float
   }
 }
 
+// single-GPU fast path: partial slabs -> constants in ONE launch (one wave per channel)
+__global__ void bn_finalize_fused_kernel(const float* part, int T, double count, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var,
+                                         float momentum, float eps, float* scale, float* shift, float* mean_out,
+                                         float* rstd_out, int C, int update_running) {
+  int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  int lane = threadIdx.x & 63;
+  const float* p0 = part + (size_t)c * T;
+  const float* p1 = part + (size_t)(C + c) * T;
+  double s0 = 0.0, s1 = 0.0;
+  for (int t = lane; t < T; t += 64) { s0 += (double)p0[t]; s1 += (double)p1[t]; }
+  s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+  if (lane != 0) return;
+  double mean = s0 / count;
+  double var = s1 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  if (update_running) {
+    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_bwd_coeffs_fused_kernel(const float* part, int T, double count, const float* gamma,
+                                           const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                           float* coef, int C) {
+  int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  int lane = threadIdx.x & 63;
+  const float* p0 = part + (size_t)c * T;
+  const float* p1 = part + (size_t)(C + c) * T;
+  double s0 = 0.0, s1 = 0.0;
+  for (int t = lane; t < T; t += 64) { s0 += (double)p0[t]; s1 += (double)p1[t]; }
+  s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+  if (lane != 0) return;
+  dbeta[c] = (float)s0;
+  dgamma[c] = (float)s1;
+  double g = gamma[c], rs = rstd[c], mu = mean[c];
+  double S0 = s0 / count, S1 = s1 / count;
+  coef[c] = (float)(g * rs);
+  coef[C + c] = (float)(-g * rs * rs * S1);
+  coef[2 * C + c] = (float)(-g * rs * S0 + g * rs * rs * mu * S1);
+}
+
 // ---------------------------------------------------------------- forward apply
 // out[m][ocoff + c] = silu(y[m][c]*scale[c] + shift[c]) (+ res[m][rcoff + c])
 __global__ void bn_silu_apply_kernel(const bf16_t* y, const float* scale, const float* shift,
@@ -215,6 +266,30 @@ int kodhip_bn_finalize(const double* sums, double count, const float* gamma, con
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, sums, count, gamma, beta,
                      running_mean, running_var, momentum, eps, scale, shift, mean, rstd, C, update_running);
   KOD_LAUNCH_CHECK("bn_finalize");
+  return KOD_OK;
+}
+
+int kodhip_bn_finalize_partials(const float* partials, int T, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps,
+                                float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
+                                hipStream_t stream) {
+  KOD_CHECK_ARG(partials && gamma && beta && scale && shift && mean && rstd && C > 0 && T > 0 && count > 0,
+                "bn_finalize_partials: bad args");
+  KOD_CHECK_ARG(!update_running || (running_mean && running_var), "bn_finalize_partials: running stats missing");
+  hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, T, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, scale, shift, mean, rstd, C, update_running);
+  KOD_LAUNCH_CHECK("bn_finalize_partials");
+  return KOD_OK;
+}
+
+int kodhip_bn_bwd_coeffs_partials(const float* partials, int T, double count, const float* gamma, const float* mean,
+                                  const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
+                                  hipStream_t stream) {
+  KOD_CHECK_ARG(partials && gamma && mean && rstd && dgamma && dbeta && coef && C > 0 && T > 0 && count > 0,
+                "bn_bwd_coeffs_partials: bad args");
+  hipLaunchKernelGGL(bn_bwd_coeffs_fused_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, T, count, gamma,
+                     mean, rstd, dgamma, dbeta, coef, C);
+  KOD_LAUNCH_CHECK("bn_bwd_coeffs_partials");
   return KOD_OK;
 }
 

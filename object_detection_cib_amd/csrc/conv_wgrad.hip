@@ -192,24 +192,39 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // grad[n][ci][kh][kw] = scale * sum_s part[s][n][k(kh,kw,ci)]   (stem: k = (kh, kw', dx, c4), see pack)
-__global__ void wgrad_reduce_kernel(const float* part, float* grad, int splits, int Nfull, int N, int K, int Kp,
-                                    int Cin, int KK, int stem, float scale) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * K) return;
-  int n = idx / K;
-  int k = idx - n * K;
+// block = 16 consecutive k x 16 split lanes: 64-byte coalesced slab reads, fixed-order LDS tree => deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* grad, int splits, int Nfull,
+                                                           int N, int K, int Kp, int Cin, int KK, int stem,
+                                                           float scale) {
+  __shared__ float sm[16][17];
+  const int kx = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long idx = (long)blockIdx.x * 16 + kx;
+  const long total = (long)N * K;
   float s = 0.f;
-  const float* p = part + (size_t)n * Kp + k;
-  for (int i = 0; i < splits; ++i) s += p[(size_t)i * Nfull * Kp];
-  if (stem) {
-    // k = (kh*3 + kwp)*8 + dx*4 + c, real weight [n][c(3)][kh(6)][kw = 2*kwp+dx (6)]
-    int c = k & 3, dx = (k >> 2) & 1, t = k >> 3;
-    int kh = t / 3, kwp = t - kh * 3;
-    if (c < 3) grad[(size_t)n * 108 + c * 36 + kh * 6 + 2 * kwp + dx] = s * scale;
-  } else {
-    int tap = k / Cin;
-    int ci = k - tap * Cin;
-    grad[(size_t)n * Cin * KK + ci * KK + tap] = s * scale;
+  int n = 0, k = 0;
+  if (idx < total) {
+    n = (int)(idx / K);
+    k = (int)(idx - (long)n * K);
+    const float* p = part + (size_t)n * Kp + k;
+    const size_t slab = (size_t)Nfull * Kp;
+    for (int i = sl; i < splits; i += 16) s += p[(size_t)i * slab];
+  }
+  sm[sl][kx] = s;
+  __syncthreads();
+  if (sl == 0 && idx < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sm[i][kx];
+    if (stem) {
+      // k = (kh*3 + kwp)*8 + dx*4 + c, real weight [n][c(3)][kh(6)][kw = 2*kwp+dx (6)]
+      int c = k & 3, dx = (k >> 2) & 1, tt = k >> 3;
+      int kh = tt / 3, kwp = tt - kh * 3;
+      if (c < 3) grad[(size_t)n * 108 + c * 36 + kh * 6 + 2 * kwp + dx] = t * scale;
+    } else {
+      int tap = k / Cin;
+      int ci = k - tap * Cin;
+      grad[(size_t)n * Cin * KK + ci * KK + tap] = t * scale;
+    }
   }
 }
 
@@ -238,7 +253,7 @@ int kodhip_conv_wgrad_splits(long M, int N, int Kp) {
   int tn, tk;
   tile_shape(N, Kp, &tn, &tk);
   int tiles = cdiv(N, tn) * cdiv(Kp, tk);
-  int s = 1024 / tiles;
+  int s = 512 / tiles;
   if (s < 1) s = 1;
   long maxs = (M + 255) / 256;
   if (s > maxs) s = (int)maxs;
@@ -280,7 +295,7 @@ int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* gra
   else rc = launch_cfg<1, 1, 1, 1>(a, stream);
   if (rc) return rc;
   int total = n_valid * a.K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 16)), dim3(256), 0, stream,
                      (const float*)partials, grad, a.splits, N, n_valid, a.K, Kp, stem ? 8 : Cin, KH * KW, stem, scale);
   KOD_LAUNCH_CHECK("wgrad_reduce");
   return KOD_OK;

@@ -153,9 +153,10 @@ struct LossLevel {
   const float* gt;
   const float* anc;
   const int* count;
-  int* last;            // [B*A*HW] init -1
-  int* first;           // init INT_MAX
-  int* cnt;             // init 0
+  int* last;            // [B*A*HW] init -1: highest row index on the cell (the surviving writer)
+  int* first;           // init -1: head of the per-cell row chain
+  int* cnt;             // unused scratch
+  int* prev;            // [cap] next row of the same cell (chain), -1 terminates
   float* G;             // [cap][4+nc] per-row logit gradients
   float* tobj;          // [cap] clamp(iou,0)
   int fh, fw;
@@ -184,8 +185,8 @@ __global__ void loss_mark_kernel(LossArgs a) {
   if (r >= *L.count || r >= a.cap) return;
   int c = cell_of(L, a.A, a.cap, r);
   atomicMax(&L.last[c], r);
-  atomicMin(&L.first[c], r);
-  atomicAdd(&L.cnt[c], 1);
+  // per-cell chain of rows (order of insertion is arbitrary; consumers walk it in row-index order)
+  L.prev[r] = atomicExch(&L.first[c], r);
 }
 
 __device__ __forceinline__ float tie_lt(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
@@ -337,7 +338,8 @@ __global__ __launch_bounds__(256) void loss_cells_kernel(LossArgs a) {
   if (threadIdx.x == 0) a.partials[((size_t)(lvl * 3 + 1)) * a.nblk + blockIdx.x] = s;
 }
 
-// last writer of each matched cell sums the row gradients of all rows on that cell (row order)
+// last writer of each matched cell sums the row gradients of all rows on that cell in ascending row order
+// (walks the cell's chain repeatedly, picking the next larger row index: chains are 1-3 rows long)
 __global__ void loss_scatter_kernel(LossArgs a) {
   const LossLevel& L = a.lv[blockIdx.y];
   const int m = min(*L.count, a.cap);
@@ -347,43 +349,69 @@ __global__ void loss_scatter_kernel(LossArgs a) {
   if (L.last[cell] != r) return;
   const int W = 4 + a.nc;
   float* g = L.grad + (size_t)cell * a.P;
-  const int n = L.cnt[cell];
-  const int f = L.first[cell];
-  for (int k = 0; k < W; ++k) {
-    float s;
-    if (n == 1) s = L.G[(size_t)r * W + k];
-    else if (n == 2) s = L.G[(size_t)f * W + k] + L.G[(size_t)r * W + k];
-    else {
-      s = 0.f;
-      for (int q = f; q <= r; ++q)
-        if (cell_of(L, a.A, a.cap, q) == cell) s += L.G[(size_t)q * W + k];
+  int rows[8];
+  int cnt = 0, done = -1;
+  for (;;) {
+    int nxt = INT_MAX;
+    for (int q = L.first[cell]; q >= 0; q = L.prev[q])
+      if (q > done && q < nxt) nxt = q;
+    if (nxt == INT_MAX) break;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i == cnt) rows[i] = nxt;
+    ++cnt;
+    done = nxt;
+  }
+  if (cnt <= 8) {
+    for (int k = 0; k < W; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < cnt) s += L.G[(size_t)rows[i] * W + k];
+      g[k < 4 ? k : k + 1] = s;
     }
-    g[k < 4 ? k : k + 1] = s;
+  } else {                                   // very crowded cell: re-walk per component
+    for (int k = 0; k < W; ++k) {
+      float s = 0.f;
+      int d2 = -1;
+      for (;;) {
+        int nxt = INT_MAX;
+        for (int q = L.first[cell]; q >= 0; q = L.prev[q])
+          if (q > d2 && q < nxt) nxt = q;
+        if (nxt == INT_MAX) break;
+        s += L.G[(size_t)nxt * W + k];
+        d2 = nxt;
+      }
+      g[k < 4 ? k : k + 1] = s;
+    }
   }
 }
 
 __global__ void loss_finalize_kernel(LossArgs a, int nblk_rows, int nblk_cells) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int lane = threadIdx.x;          // one wave
   double box = 0, obj = 0, cls = 0;
   for (int l = 0; l < 3; ++l) {
     const LossLevel& L = a.lv[l];
     double sb = 0, so = 0, sc = 0;
-    for (int i = 0; i < nblk_rows; ++i) {
+    for (int i = lane; i < nblk_rows; i += 64) {
       sb += (double)a.partials[(size_t)(l * 3 + 0) * a.nblk + i];
       sc += (double)a.partials[(size_t)(l * 3 + 2) * a.nblk + i];
     }
-    for (int i = 0; i < nblk_cells; ++i) so += (double)a.partials[(size_t)(l * 3 + 1) * a.nblk + i];
+    for (int i = lane; i < nblk_cells; i += 64) so += (double)a.partials[(size_t)(l * 3 + 1) * a.nblk + i];
+    sb = wave_sum_d(sb); sc = wave_sum_d(sc); so = wave_sum_d(so);
     int m = min(*L.count, a.cap);
     double ncells = (double)a.B * a.A * L.fh * L.fw;
     float lb = (float)(sb / (double)m);                 // 0/0 = NaN on an empty level, as the reference
     float lc = (float)(sc / ((double)m * a.nc));
     float lo = L.balance * (float)(so / ncells);
-    a.out[3 + l * 3 + 0] = lb; a.out[3 + l * 3 + 1] = lo; a.out[3 + l * 3 + 2] = lc;
+    if (lane == 0) { a.out[3 + l * 3 + 0] = lb; a.out[3 + l * 3 + 1] = lo; a.out[3 + l * 3 + 2] = lc; }
     box += lb; obj += lo; cls += lc;
   }
-  a.out[0] = a.lam_box * (float)box;
-  a.out[1] = a.lam_obj * (float)obj;
-  a.out[2] = a.lam_cls * (float)cls;
+  if (lane == 0) {
+    a.out[0] = a.lam_box * (float)box;
+    a.out[1] = a.lam_obj * (float)obj;
+    a.out[2] = a.lam_cls * (float)cls;
+  }
 }
 
 }  // namespace
@@ -422,7 +450,8 @@ int kodhip_assign_targets(const double* boxes, const long* labels, const int* sa
 struct KodLossLevel {
   const float* logits; float* grad;
   const int* idx; const int* label; const float* gt; const float* anc; const int* count;
-  int* cellmaps;       // 3 * ncells ints: last | first | cnt
+  int* cellmaps;       // 3 * ncells ints: last | chain head | scratch
+  int* rowprev;        // cap ints: per-row chain links
   float* rowgrad;      // cap * (4+nc)
   float* tobj;         // cap
   int fh, fw;
@@ -439,7 +468,7 @@ int kodhip_yolo_loss(const KodLossLevel* levels /*[3], host*/, int B, int A, int
   long max_cells = 0;
   for (int l = 0; l < 3; ++l) {
     const KodLossLevel& s = levels[l];
-    KOD_CHECK_ARG(s.logits && s.idx && s.label && s.gt && s.anc && s.count && s.cellmaps && s.rowgrad && s.tobj,
+    KOD_CHECK_ARG(s.logits && s.idx && s.label && s.gt && s.anc && s.count && s.cellmaps && s.rowprev && s.rowgrad && s.tobj,
                   "yolo_loss: null pointer in level %d", l);
     KOD_CHECK_ARG(!compute_grad || s.grad, "yolo_loss: grad buffer missing");
     long ncells = (long)B * A * s.fh * s.fw;
@@ -447,7 +476,7 @@ int kodhip_yolo_loss(const KodLossLevel* levels /*[3], host*/, int B, int A, int
     LossLevel& d = a.lv[l];
     d.logits = s.logits; d.grad = s.grad; d.idx = s.idx; d.label = s.label; d.gt = s.gt; d.anc = s.anc;
     d.count = s.count; d.last = s.cellmaps; d.first = s.cellmaps + ncells; d.cnt = s.cellmaps + 2 * ncells;
-    d.G = s.rowgrad; d.tobj = s.tobj; d.fh = s.fh; d.fw = s.fw; d.balance = s.balance;
+    d.G = s.rowgrad; d.tobj = s.tobj; d.prev = s.rowprev; d.fh = s.fh; d.fw = s.fw; d.balance = s.balance;
     if (ncells > max_cells) max_cells = ncells;
   }
   int nblk_rows = cdiv(cap, 256);
@@ -461,9 +490,8 @@ int kodhip_yolo_loss(const KodLossLevel* levels /*[3], host*/, int B, int A, int
   for (int l = 0; l < 3; ++l) {
     long ncells = (long)B * A * a.lv[l].fh * a.lv[l].fw;
     hipError_t e1 = hipMemsetAsync(a.lv[l].last, 0xFF, ncells * sizeof(int), stream);
-    hipError_t e2 = hipMemsetAsync(a.lv[l].first, 0x7F, ncells * sizeof(int), stream);
-    hipError_t e3 = hipMemsetAsync(a.lv[l].cnt, 0, ncells * sizeof(int), stream);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { kodhip_set_error("yolo_loss: memset failed"); return 1; }
+    hipError_t e2 = hipMemsetAsync(a.lv[l].first, 0xFF, ncells * sizeof(int), stream);
+    if (e1 != hipSuccess || e2 != hipSuccess) { kodhip_set_error("yolo_loss: memset failed"); return 1; }
   }
   hipLaunchKernelGGL(loss_mark_kernel, dim3(nblk_rows, 3), dim3(256), 0, stream, a);
   KOD_LAUNCH_CHECK("loss_mark");

@@ -235,11 +235,14 @@ __global__ void head_bwd_prep_kernel(const float* g, bf16_t* dy, float* bpart, i
 // bias grads of the three heads: db_box[4A], db_obj[A], db_cls[nc*A] are consecutive in n order.
 __global__ void head_bias_reduce_kernel(const float* bpart, int nblk, int Npad, float* db_box, float* db_obj,
                                         float* db_cls, int A, int nc) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wave per output channel
+  int lane = threadIdx.x & 63;
   int N = A * (5 + nc);
   if (n >= N) return;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)bpart[(size_t)b * Npad + n];
+  for (int b = lane; b < nblk; b += 64) s += (double)bpart[(size_t)b * Npad + n];
+  s = wave_sum_d(s);
+  if (lane != 0) return;
   if (n < 4 * A) db_box[n] = (float)s;
   else if (n < 5 * A) db_obj[n - 4 * A] = (float)s;
   else db_cls[n - 5 * A] = (float)s;
@@ -357,7 +360,7 @@ int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_b
   hipLaunchKernelGGL(head_bwd_prep_kernel, dim3(grid), dim3(threads), rpb * Npad * sizeof(float), stream, g,
                      (bf16_t*)dy, workspace, B, HW, A, nc, Npad);
   KOD_LAUNCH_CHECK("head_bwd_prep");
-  hipLaunchKernelGGL(head_bias_reduce_kernel, dim3(cdiv(A * (5 + nc), 64)), dim3(64), 0, stream,
+  hipLaunchKernelGGL(head_bias_reduce_kernel, dim3(cdiv(A * (5 + nc), 4)), dim3(256), 0, stream,
                      (const float*)workspace, grid, Npad, db_box, db_obj, db_cls, A, nc);
   KOD_LAUNCH_CHECK("head_bias_reduce");
   return KOD_OK;

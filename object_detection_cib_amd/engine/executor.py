@@ -283,12 +283,15 @@ class Engine:
                     in_px = B * H * W if u.stem else B * st.H * st.W
                     self.profile.append((e0, e1, 2 * (in_px * cin_true + st.M * C_)))
                 aff = st.aff.data_ptr()
-                if training:
+                if training and not (self.sync_bn and self.world_size > 1):
+                    chk(lib.kodhip_bn_finalize_partials(st.stats.data_ptr(), st.T, float(st.M), pa + 4 * st.g_off,
+                                                        pa + 4 * st.b_off, self.rm_arena.data_ptr() + 4 * st.rs_off,
+                                                        self.rv_arena.data_ptr() + 4 * st.rs_off, BN_MOMENTUM, BN_EPS,
+                                                        aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
+                elif training:
                     chk(lib.kodhip_bn_reduce_partials(st.stats.data_ptr(), st.sums.data_ptr(), C_, st.T, s), u.name)
-                    count = float(st.M)
-                    if self.sync_bn and self.world_size > 1:
-                        self._allreduce(st.sums)
-                        count *= self.world_size
+                    self._allreduce(st.sums)
+                    count = float(st.M) * self.world_size
                     chk(lib.kodhip_bn_finalize(st.sums.data_ptr(), count, pa + 4 * st.g_off, pa + 4 * st.b_off,
                                                self.rm_arena.data_ptr() + 4 * st.rs_off,
                                                self.rv_arena.data_ptr() + 4 * st.rs_off, BN_MOMENTUM, BN_EPS,
@@ -407,17 +410,18 @@ class Engine:
                 chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
                                                   aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
                                                   st.bpart.data_ptr(), st.M, C_, s), u.name)
-                chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), C_, st.T2, s), u.name)
-                count = float(st.M)
-                gsum = st.bsums
                 if self.sync_bn and self.world_size > 1:
+                    chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), C_, st.T2, s), u.name)
                     st.bsums_g.copy_(st.bsums)
                     self._allreduce(st.bsums_g)
-                    gsum = st.bsums_g
-                    count *= self.world_size
-                chk(lib.kodhip_bn_bwd_coeffs(st.bsums.data_ptr(), gsum.data_ptr(), count, pa + 4 * st.g_off,
-                                             aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off, gp + 4 * st.b_off,
-                                             st.coef.data_ptr(), C_, s), u.name)
+                    chk(lib.kodhip_bn_bwd_coeffs(st.bsums.data_ptr(), st.bsums_g.data_ptr(),
+                                                 float(st.M) * self.world_size, pa + 4 * st.g_off,
+                                                 aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off, gp + 4 * st.b_off,
+                                                 st.coef.data_ptr(), C_, s), u.name)
+                else:
+                    chk(lib.kodhip_bn_bwd_coeffs_partials(st.bpart.data_ptr(), st.T2, float(st.M), pa + 4 * st.g_off,
+                                                          aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off,
+                                                          gp + 4 * st.b_off, st.coef.data_ptr(), C_, s), u.name)
                 res = u.residual
                 chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
                                                  aff, aff + 4 * C_, st.coef.data_ptr(),

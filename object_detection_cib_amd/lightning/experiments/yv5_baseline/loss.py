@@ -45,8 +45,8 @@ def _run(mod, shape, raws, asg, cap, grads, upstream, work):
         lv.grad = grads[i].data_ptr() if grads is not None else None
         lv.idx, lv.label, lv.gt, lv.anc, lv.count = (d.idx.data_ptr(), d.label.data_ptr(), d.gt.data_ptr(),
                                                      d.anc.data_ptr(), d.count.data_ptr())
-        lv.cellmaps, lv.rowgrad, lv.tobj = (work["maps"][i].data_ptr(), work["rowgrad"][i].data_ptr(),
-                                            work["tobj"][i].data_ptr())
+        lv.cellmaps, lv.rowprev, lv.rowgrad, lv.tobj = (work["maps"][i].data_ptr(), work["prev"][i].data_ptr(),
+                                                        work["rowgrad"][i].data_ptr(), work["tobj"][i].data_ptr())
         lv.fh, lv.fw, lv.balance = t.shape[2], t.shape[3], bal
     lam_obj = hp.lambda_objectness * ((shape.width / 640) ** 2)          # loss.py:231-233
     lam_cls = hp.lambda_classification * (nc / 80)                        # loss.py:235-237
@@ -69,6 +69,7 @@ class _LossFn(torch.autograd.Function):
         nslots = max((cap + 255) // 256, 1024)
         work = dict(
             maps=[torch.empty(3 * B * A * t.shape[2] * t.shape[3], dtype=torch.int32, device=dev) for t in raws],
+            prev=[torch.empty(cap, dtype=torch.int32, device=dev) for _ in raws],
             rowgrad=[torch.empty(cap * (P - 1), dtype=torch.float32, device=dev) for _ in raws],
             tobj=[torch.empty(cap, dtype=torch.float32, device=dev) for _ in raws],
             partials=torch.zeros(9 * nslots, dtype=torch.float32, device=dev), nslots=nslots,
