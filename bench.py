@@ -33,7 +33,9 @@ def synth_batch(B, size, nc, seed, device):
     x, tg = synth.batch(B, size, nc, seed)
     tg = synth.targets(B, size, nc, seed, nmin=4, nmax=30)     # mosaic-like box counts (4 source images)
     from object_detection_cib_amd.data.detection import DetectionTarget
-    return x.to(device), tuple(DetectionTarget(b.to(device), l.to(device)) for b, l in tg)
+    from object_detection_cib_amd.core.label_assignment.yv5 import BatchedTargets
+    tg = tuple(DetectionTarget(b, l) for b, l in tg)
+    return x.to(device), BatchedTargets.from_targets(tg, device)
 
 
 def build(nc, device, seed=2023):
@@ -86,6 +88,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,14 +117,18 @@ def main():
     lr, mom, wd = (0.1, 0.0, 0.0), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0)
     lr = (0.1, 1e-4, 1e-4)    # non-zero so every parameter really moves
 
+    eng.sgd_step(lr, mom, wd, 1.0 / world)        # uploads the hyper-parameters to the device buffer
+    params = list(net.parameters())
+
     def step():
-        for p in net.parameters():
+        for p in params:
             p.grad = None
         res = net(x)
         lr_ = loss_fn(shape, res, targets)
         total = B * (lr_.localization + lr_.classification + lr_.objectness)
         total.backward()
-        eng.sgd_step(lr, mom, wd, 1.0 / world)
+        eng.wait_grads()
+        eng.sgd_step_device()
         return total
 
     def barrier():
@@ -129,18 +136,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    use_graph = world == 1 and not args.no_graph
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(max(args.warmup, 2) if use_graph else args.warmup):
+            last = step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = None
+    if use_graph:
+        # the whole step (~650 launches) becomes one hipGraph
+        barrier()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            last = step()
+        graph.replay()
     barrier()
-    # dominant-kernel timing with events on the launch stream (forward implicit-GEMM conv family)
-    eng.profile = []
+    if graph is None:
+        eng.profile = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        last = step()
+        if graph is not None:
+            graph.replay()
+        else:
+            last = step()
     barrier()
     dt = time.perf_counter() - t0
-    prof = eng.profile
-    eng.profile = None
+    if graph is None:
+        prof = eng.profile
+        eng.profile = None
+    else:
+        # per-kernel durations of the dominant family: one extra eager step on the launch stream, outside the
+        # timed region (events cannot be read back from inside a replayed graph)
+        eng.profile = []
+        step()
+        torch.cuda.synchronize()
+        prof = eng.profile
+        eng.profile = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,7 +193,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "yv5s coco-zipf-like synthetic, 640px, bf16 storage/fp32 accumulate, "
                                    f"batch {B}/GPU, fwd+assign+loss+bwd+SGD, targets 4-30 boxes/img",
-                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if world > 1 and not args.no_sync_bn else "")},
+                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if world > 1 and not args.no_sync_bn else ""),
+                       "launch": "hipGraph replay" if graph is not None else "eager"},
             "final_loss": final_loss,
             "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_img": ALGO_BYTES_PER_IMG_BF16,
                               "achieved": round(ips / world * ALGO_BYTES_PER_IMG_BF16 / 1e9, 1), "peak": HBM_PEAK / 1e9,

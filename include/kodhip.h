@@ -104,7 +104,8 @@ int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_b
 
 /* ---- optimizer (torch.optim.SGD nesterov as grouped by kod/nn/optim/smart.py:36-58) --------------- */
 int kodhip_sgd_nesterov(float* params, const float* grads, float* momentum_buf, const void* group_ids,
-                        long n, const float* hyper /* host, 10 floats */, kodStream_t stream);
+                        long n, const float* hyper /* device, 10 floats: lr[3] momentum[3] wd[3] grad_scale */,
+                        kodStream_t stream);
 int kodhip_fill_u32(void* p, uint32_t value, long n, kodStream_t stream);
 
 /* ---- target assignment + loss (kod/core/label_assignment/yv5.py:45-319,

@@ -53,6 +53,29 @@ class DeviceAssignment(NamedTuple):
     stride: int
 
 
+class BatchedTargets(NamedTuple):
+    """All boxes of a batch, already concatenated on the device (what the collate function of a device data
+    pipeline hands over; also makes the train step capturable in a hipGraph: no host tensors involved)."""
+    boxes: torch.Tensor      # f64 [n, 4] xyxy pixels
+    labels: torch.Tensor     # i64 [n]
+    samples: torch.Tensor    # i32 [n] image index of every box
+    n: int
+
+    @staticmethod
+    def from_targets(targets, device) -> "BatchedTargets":
+        lens = [int(t.boxes.shape[0]) for t in targets]
+        n = sum(lens)
+        if n == 0:
+            z = torch.zeros((0, 4), dtype=torch.float64, device=device)
+            return BatchedTargets(z, torch.zeros(0, dtype=torch.int64, device=device),
+                                  torch.zeros(0, dtype=torch.int32, device=device), 0)
+        boxes = torch.cat([t.boxes.reshape(-1, 4).to(torch.float64) for t in targets], 0)
+        labels = torch.cat([t.labels.reshape(-1).to(torch.int64) for t in targets], 0)
+        samples = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32),
+                                          torch.tensor(lens, dtype=torch.int64))
+        return BatchedTargets(boxes.to(device).contiguous(), labels.to(device).contiguous(), samples.to(device), n)
+
+
 class Yolov5LabelAssigner(object):
     def __init__(self, anchor_info: AssignmentAnchorInfo, threshold: float = 4.0):
         self.anchor_info = anchor_info
@@ -66,19 +89,10 @@ class Yolov5LabelAssigner(object):
     def assign_device(self, input_image_shape: FeatureShape, targets, device) -> tuple:
         _lib.require_gpu()
         lib = _lib.lib()
-        lens = [int(t.boxes.shape[0]) for t in targets]
-        n = sum(lens)
+        bt = targets if isinstance(targets, BatchedTargets) else BatchedTargets.from_targets(targets, device)
+        n = bt.n
         cap = max(15 * n, 16)
-        if n:
-            boxes = torch.cat([t.boxes.reshape(-1, 4).to(torch.float64) for t in targets], 0)
-            labels = torch.cat([t.labels.reshape(-1).to(torch.int64) for t in targets], 0)
-            samples = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32),
-                                              torch.tensor(lens, dtype=torch.int64))
-            boxes = boxes.to(device, non_blocking=True).contiguous()
-            labels = labels.to(device, non_blocking=True).contiguous()
-            samples = samples.to(device, non_blocking=True)
-        else:
-            boxes = labels = samples = None
+        boxes, labels, samples = bt.boxes, bt.labels, bt.samples
         levels = (_lib.KodAssignLevel * 3)()
         outs = []
         for i, info in enumerate(self.anchor_info):

@@ -250,21 +250,20 @@ __global__ void head_bias_reduce_kernel(const float* bpart, int nblk, int Npad, 
 
 // ------------------------------------------------------------------ SGD
 // group id per 64-element granule: 0 bias, 1 decay, 2 norm, 255 padding
-struct SgdHyper { float lr[3], momentum[3], wd[3]; float grad_scale; };
-
+// hyper (device memory, so a captured hipGraph sees per-step schedules): lr[3] | momentum[3] | wd[3] | grad_scale
 __global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, const unsigned char* gid, long n,
-                                    SgdHyper h) {
+                                    const float* hyper) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   unsigned char grp = gid[i >> 6];
   if (grp > 2) return;
-  float lr = h.lr[grp], mu = h.momentum[grp], wd = h.wd[grp];
+  const float lr = hyper[grp], mu = hyper[3 + grp], wd = hyper[6 + grp], gscale = hyper[9];
   f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
   f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
   f32x4 bv = *reinterpret_cast<const f32x4*>(buf + i);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float gg = gv[e] * h.grad_scale;
+    float gg = gv[e] * gscale;
     if (wd != 0.f) gg = gg + wd * pv[e];
     float b = mu * bv[e] + gg;
     bv[e] = b;
@@ -366,15 +365,12 @@ int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_b
   return KOD_OK;
 }
 
-// hyper: 10 floats = lr[3], momentum[3], weight_decay[3], grad_scale  (groups: bias, decay, norm)
+// hyper: DEVICE pointer to 10 floats = lr[3], momentum[3], weight_decay[3], grad_scale  (groups: bias, decay, norm)
 int kodhip_sgd_nesterov(float* params, const float* grads, float* momentum_buf, const void* group_ids,
                         long n, const float* hyper, hipStream_t stream) {
   KOD_CHECK_ARG(params && grads && momentum_buf && group_ids && hyper && n > 0 && n % 64 == 0, "sgd_nesterov: bad args");
-  SgdHyper h;
-  for (int i = 0; i < 3; ++i) { h.lr[i] = hyper[i]; h.momentum[i] = hyper[3 + i]; h.wd[i] = hyper[6 + i]; }
-  h.grad_scale = hyper[9];
   hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, params, grads, momentum_buf,
-                     (const unsigned char*)group_ids, n, h);
+                     (const unsigned char*)group_ids, n, hyper);
   KOD_LAUNCH_CHECK("sgd_nesterov");
   return KOD_OK;
 }

@@ -166,6 +166,9 @@ class Engine:
         self.pack_blocks = blk
         self.exec_units = exec_units
         self.device = device
+        self.hyper = torch.zeros(10, dtype=torch.float32, device=device)
+        self._hyper_host = torch.zeros(10, dtype=torch.float32).pin_memory()
+        self._hyper_vals = None
 
     def _grad_view(self, name, arena=None):
         o, k = self.layout[name]
@@ -480,10 +483,18 @@ class Engine:
     def sgd_step(self, lr, momentum, weight_decay, grad_scale: float = 1.0):
         """lr / momentum / weight_decay: 3-tuples for (bias_params, decay_params, norm_params)."""
         self.wait_grads()
-        hyper = (C.c_float * 10)(*lr, *momentum, *weight_decay, grad_scale)
+        vals = (*lr, *momentum, *weight_decay, grad_scale)
+        if vals != self._hyper_vals:                       # only touch the device copy when the schedule moved
+            self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
+            self.hyper.copy_(self._hyper_host, non_blocking=True)
+            self._hyper_vals = vals
+        self.sgd_step_device()
+
+    def sgd_step_device(self):
+        """SGD with whatever is in self.hyper (device, 10 floats) - the graph-capturable form."""
         _lib.check(self.lib.kodhip_sgd_nesterov(self.p_arena.data_ptr(), self.current_grad_arena().data_ptr(),
                                                 self.m_arena.data_ptr(), self.gid.data_ptr(), self.n_arena,
-                                                hyper, self._stream()), "sgd")
+                                                self.hyper.data_ptr(), self._stream()), "sgd")
         self.param_version += 1
 
     def mark_params_changed(self):

@@ -283,9 +283,9 @@ def test_sgd_nesterov():
     refp, refb = p.clone(), [None] * 7
     grc, gidc = gr.cuda(), gid.cuda()
     for step in range(3):
-        hyper = (C.c_float * 10)(*lr, *mom, *wd, 0.5)
+        hyper = torch.tensor([*lr, *mom, *wd, 0.5], dtype=torch.float32, device="cuda")
         _lib.check(lib.kodhip_sgd_nesterov(pc.data_ptr(), grc.data_ptr(), buf.data_ptr(), gidc.data_ptr(), n,
-                                           hyper, stream()), "sgd")
+                                           hyper.data_ptr(), stream()), "sgd")
         for k in range(7):
             gi = int(gid[k])
             if gi > 2:
