@@ -1,0 +1,54 @@
+"""Data-parallel helpers: gradient-bucket planning over the flat arena and rank sharding of sample indices.
+
+Replaces what Lightning's `strategy: ddp` does implicitly for the reference
+(kod/configs/trainer/ddp.yaml:4-9): torch DistributedDataParallel's reducer (bucketed all-reduce overlapped
+with backward) and the DistributedSampler injection.  Pure host logic: testable on CPU with gloo.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+
+
+def plan_buckets(unit_starts: Sequence[int], n_arena: int, bucket_elems: int) -> List[Tuple[int, int, int]]:
+    """unit_starts[i] = arena offset where exec unit i's parameters begin (forward order, ascending).
+
+    Gradients complete back-to-front.  Returns [(trigger_unit_index, lo, hi)]: once unit `trigger`'s wgrad has
+    been enqueued, arena[lo:hi] is final and can be all-reduced.  Buckets tile [0, n_arena) exactly."""
+    out = []
+    hi = n_arena
+    for i in range(len(unit_starts) - 1, -1, -1):
+        lo = unit_starts[i]
+        if hi - lo >= bucket_elems or i == 0:
+            lo = 0 if i == 0 else lo
+            out.append((i, lo, hi))
+            hi = lo
+    assert hi == 0
+    return out
+
+
+def launch_bucket(flat: torch.Tensor, lo: int, hi: int, group=None):
+    """Async sum all-reduce of a contiguous arena slice (RCCL on GPU tensors, gloo in tests)."""
+    return torch.distributed.all_reduce(flat[lo:hi], group=group, async_op=True)
+
+
+def shard_indices(n: int, rank: int, world: int, seed: int = 0, epoch: int = 0, shuffle: bool = True,
+                  drop_last: bool = False) -> List[int]:
+    """torch.utils.data.DistributedSampler semantics (what Lightning injects): a seeded
+    permutation per epoch, padded by wrap-around to a multiple of `world`, rank-strided."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g).tolist()
+    else:
+        idx = list(range(n))
+    if drop_last and n % world:
+        total = (n // world) * world
+        idx = idx[:total]
+    else:
+        total = -(-n // world) * world
+        pad = total - len(idx)
+        if pad:
+            idx += (idx * (pad // max(len(idx), 1) + 1))[:pad]
+    return idx[rank:total:world]

@@ -18,6 +18,7 @@ import torch
 
 from .. import _lib
 from .graph import Graph, ConvUnit, HeadUnit, View, Buf
+from .ddp import plan_buckets, launch_bucket
 
 BN_EPS, BN_MOMENTUM = 1e-3, 0.03        # kod/nn/networks/yolov5.py:24
 
@@ -82,6 +83,8 @@ class Engine:
             place([f"{h.name}.{k}_head.conv.bias" for k in ("box", "obj", "cls")], 0)
         self.n_arena = off
         self.layout = layout
+        self.unit_starts = ([layout[u.name + '.0.weight'][0] for u in exec_units]
+                            + [layout[f'{h.name}.box_head.conv.weight'][0] for h in g.heads])
         self.p_arena = torch.zeros(off, dtype=torch.float32, device=device)
         self.g_arena = [torch.zeros(off, dtype=torch.float32, device=device) for _ in range(2)]
         self.g_cur = 0
@@ -368,7 +371,11 @@ class Engine:
             return 0
 
         self._pending = []
-        bucket_hi = self.n_arena
+        buckets = {}
+        if self.world_size > 1:
+            buckets = {trig: (lo, hi) for trig, lo, hi in plan_buckets(self.unit_starts, self.n_arena,
+                                                                        max(self.bucket_bytes // 4, 1))}
+        unit_i = len(self.unit_starts)
         pool_i = len(self.pool_idx)
         head_i = len(self.g.heads)
         for op in reversed(self.g.ops):
@@ -441,17 +448,12 @@ class Engine:
                 chk(lib.kodhip_conv_wgrad(self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
                                           *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0, s), u.name + ".wgrad")
             # gradient buckets complete from the arena's end toward its start
-            if self.world_size > 1 and op.kind in ("conv", "head"):
-                lo = st.w_off if op.kind == "conv" else hs["w_off"]
-                if (bucket_hi - lo) * 4 >= self.bucket_bytes or lo == 0:
-                    self._launch_bucket(ga, lo, bucket_hi)
-                    bucket_hi = lo
-        if self.world_size > 1 and bucket_hi > 0:
-            self._launch_bucket(ga, 0, bucket_hi)
+            if op.kind in ("conv", "head"):
+                unit_i -= 1
+                if unit_i in buckets:
+                    lo, hi = buckets[unit_i]
+                    self._pending.append(launch_bucket(ga, lo, hi, self.process_group))
         self._publish_grads()
-
-    def _launch_bucket(self, ga, lo, hi):
-        self._pending.append(torch.distributed.all_reduce(ga[lo:hi], group=self.process_group, async_op=True))
 
     def wait_grads(self):
         for w in self._pending:

@@ -1,0 +1,69 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/kodhip.h
+declares, and the ctypes table matches the header one to one (no compute calls: no GPU here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "kodhip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kodhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def _params(name):
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    m = re.search(r"\b%s\s*\((.*?)\)\s*;" % re.escape(name), src, flags=re.S)
+    args = m.group(1).strip()
+    return 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
+
+
+@pytest.fixture(scope="module")
+def built():
+    from object_detection_cib_amd import build
+    return build.build(verbose=False)
+
+
+def test_header_symbols_exported(built):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", built]).decode()
+    exported = set(re.findall(r" T (kodhip_[a-z0-9_]+)", out))
+    missing = [s for s in _declared() if s not in exported]
+    assert not missing, missing
+
+
+def test_ctypes_table_matches_header(built):
+    from object_detection_cib_amd import _lib
+    decl = set(_declared())
+    table = set(_lib.SIGNATURES)
+    assert table <= decl, sorted(table - decl)
+    assert decl - table <= {"kodhip_set_error"}, sorted(decl - table)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        assert len(args) == _params(name), (name, len(args), _params(name))
+
+
+def test_library_loads_and_reports(built):
+    from object_detection_cib_amd import _lib
+    h = _lib.lib()
+    assert h.kodhip_version() >= 100
+    assert h.kodhip_pack_desc_bytes() == 13 * 8
+    assert h.kodhip_device_count() >= 0
+    # argument validation happens before any launch, so it is testable without a GPU
+    rc = h.kodhip_bn_silu_apply(None, None, None, None, 0, 0, None, 0, 0, 0, 0, None)
+    assert rc < 0 and b"bn_silu_apply" in h.kodhip_last_error()
+    rc = h.kodhip_conv_fwd_raw(1, 1, 1, 1, 1, 8, 8, 12, 0, 12, 8, 1, 1, 1, 1, 0, 0, 32, 8, 0, None)
+    assert rc < 0 and b"multiples of 8" in h.kodhip_last_error()
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from object_detection_cib_amd.nn.networks.yolov5 import Yolov5Network
+    net = Yolov5Network(3, 10, widen_factor=0.25, deepen_factor=0.33)
+    with pytest.raises(RuntimeError, match="MI355X|GPU|cuda"):
+        net(torch.zeros(1, 3, 64, 64))

@@ -1,0 +1,90 @@
+"""Data-parallel path with two ranks sharing the one GPU of the test box (gloo transport, CUDA tensors):
+SyncBN + bucketed gradient all-reduce must reproduce the single-process step on the concatenated batch.
+(RCCL itself needs one GPU per rank; the collective CALL SITES are identical under backend "nccl".)"""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(seed):
+    from object_detection_cib_amd.core.anchors.info import voc_anchor_info
+    from object_detection_cib_amd.core.bbox.iou import IoUCalculator
+    from object_detection_cib_amd.core.label_assignment.yv5 import Yolov5LabelAssigner, AssignmentAnchorInfo
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.loss import Yolov5Loss, Yolov5LossParams
+    from object_detection_cib_amd.nn.networks.yolov5 import Yolov5Network
+    torch.manual_seed(seed)
+    net = Yolov5Network(3, 10, widen_factor=0.25, deepen_factor=0.33).cuda().train()
+    asg = Yolov5LabelAssigner(AssignmentAnchorInfo(voc_anchor_info(8), voc_anchor_info(16), voc_anchor_info(32)), 4.0)
+    return net, Yolov5Loss(asg, Yolov5LossParams.get_default(), IoUCalculator("ciou", 1e-7), None)
+
+
+def _data(size):
+    from oracle import synth
+    x, _ = synth.batch(4, size, 10, 3)
+    tg = synth.targets(2, size, 10, 3, nmin=6, nmax=12)
+    return x, tg + tg          # images 2,3 carry the same boxes as 0,1 => equal per-rank loss normalisers
+
+
+def _run(net, loss, x, tg, size):
+    from object_detection_cib_amd.core.types import FeatureShape
+    from object_detection_cib_amd.data.detection import DetectionTarget
+    res = net(x.cuda())
+    lr = loss(FeatureShape(width=size, height=size), res, tuple(DetectionTarget(b, l) for b, l in tg))
+    total = x.shape[0] * (lr.localization + lr.classification + lr.objectness)
+    total.backward()
+    net.engine().wait_grads()
+    return total.item()
+
+
+def _worker(rank, world, port, size, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        net, loss = _build(5)
+        net.configure_distributed(None, sync_batchnorm=True, bucket_mb=0.5)
+        x, tg = _data(size)
+        _run(net, loss, x[2 * rank:2 * rank + 2], tg[2 * rank:2 * rank + 2], size)
+        g = torch.cat([p.grad.flatten() for p in net.parameters()]).cpu()
+        rm = net.engine().rm_arena.cpu()
+        net.engine().sgd_step((0.1, 0.01, 0.01), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0), 1.0 / world)
+        torch.cuda.synchronize()
+        p = torch.cat([q.detach().flatten() for q in net.parameters()]).cpu()
+        if rank == 0:
+            torch.save(dict(g=g, rm=rm, p=p), out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ddp_syncbn_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    size = 128
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "ddp.pt")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, size, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = torch.load(out)
+    # single process on all 4 images
+    net, loss = _build(5)
+    x, tg = _data(size)
+    _run(net, loss, x, tg, size)
+    g1 = torch.cat([p.grad.flatten() for p in net.parameters()]).cpu()
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    # summed DDP gradients = sum of per-rank gradients; single-process total = 4*(...) = 2x each rank's scaling
+    assert rel(got["g"], g1) < 2e-2, rel(got["g"], g1)
+    assert rel(got["rm"], net.engine().rm_arena.cpu()) < 1e-3
+    net.engine().sgd_step((0.1, 0.01, 0.01), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0), 0.5)
+    p1 = torch.cat([q.detach().flatten() for q in net.parameters()]).cpu()
+    assert rel(got["p"], p1) < 1e-4
