@@ -54,6 +54,10 @@ int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
                       int B, int H, int W, int ldx, int xcoff, int Cin,
                       int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
                       int ldy, int ycoff, int accumulate, kodStream_t stream);
+/* dX of a 3x3/s2/p1 conv by output-pixel parity classes (9 instead of 36 taps of MFMA work) */
+int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
+                         int B, int H, int W, int ldx, int xcoff, int Cin, int N,
+                         int ldy, int ycoff, int accumulate, kodStream_t stream);
 int kodhip_conv_wgrad_splits(long M, int N, int Kp);
 int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* grad,
                       int B, int H, int W, int ldx, int xcoff, int Cin,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "kodhip_conv_fwd_raw": (i32, [vp, vp, vp, vp] + [i32] * 16 + [vp]),
     "kodhip_conv_fwd_head": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp]),
     "kodhip_conv_dgrad": (i32, [vp, vp, vp] + [i32] * 17 + [vp]),
+    "kodhip_conv_dgrad_s2": (i32, [vp, vp, vp] + [i32] * 10 + [vp]),
     "kodhip_conv_wgrad_splits": (i32, [i64, i32, i32]),
     "kodhip_conv_wgrad": (i32, [vp, vp, vp, vp] + [i32] * 18 + [f32, vp]),
     "kodhip_bn_reduce_partials": (i32, [vp, vp, i32, i32, vp]),

@@ -39,6 +39,7 @@ struct ConvArgs {
   int KH, KW;
   int mul_h, mul_w, add_h, add_w, tap_sign, sh_shift, sw_shift;
   int ldy, ycoff, accumulate;
+  int out_mul, out_off_y, out_off_x, out_H, out_W;   // PLAIN: output pixel (oy,ox) -> (oy*mul+off_y, ox*mul+off_x) of an out_H x out_W image
   int head_A, head_P, head_nc;
   uint32_t magic_cin, magic_kw;
   int tiles_m, tiles_n, groups_m;
@@ -245,7 +246,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         int m = m0 + row;
         if (m < a.M && n < a.N) {
           bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS_ROW + c * 8);
-          bf16_t* dst = a.y + (size_t)m * a.ldy + a.ycoff + n;
+          size_t opix = (size_t)m;
+          if constexpr (MODE == MODE_PLAIN) {
+            if (a.out_mul != 1) {
+              int b = m / HWo;
+              int rem = m - b * HWo;
+              int oy = rem / a.Wo;
+              int ox = rem - oy * a.Wo;
+              opix = ((size_t)b * a.out_H + oy * a.out_mul + a.out_off_y) * a.out_W + ox * a.out_mul + a.out_off_x;
+            }
+          }
+          bf16_t* dst = a.y + opix * a.ldy + a.ycoff + n;
           if constexpr (MODE == MODE_PLAIN) {
             if (a.accumulate) {
               bf16x8 o = *reinterpret_cast<const bf16x8*>(dst);
@@ -344,6 +355,7 @@ static int fill_common(ConvArgs& a, const void* x, const void* w, int B, int Hs,
   a.B = B; a.Hs = Hs; a.Ws = Ws; a.ldx = ldx; a.xcoff = xcoff; a.Cin = Cin;
   a.Ho = Ho; a.Wo = Wo; a.M = B * Ho * Wo; a.N = N; a.K = KH * KW * Cin; a.Kp = Kp; a.KH = KH; a.KW = KW;
   a.magic_cin = magic_u32((uint32_t)Cin); a.magic_kw = magic_u32((uint32_t)KW);
+  a.out_mul = 1;
   return KOD_OK;
 }
 
@@ -396,6 +408,35 @@ int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
   a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff; a.accumulate = accumulate;
   a.mul_h = 1; a.mul_w = 1; a.add_h = PH; a.add_w = PW; a.tap_sign = -1; a.sh_shift = ssh; a.sw_shift = ssw;
   return launch<MODE_PLAIN>(a, stream);
+}
+
+// Data gradient of a 3x3 / stride 2 / pad 1 convolution, decomposed by output-pixel parity: class (py,px)
+// only meets taps kh = 1 (py=0) or kh in {0,2} (py=1) (same for kw), so the four classes are stride-1 gathers
+// with 1, 2, 2 and 4 taps - 9 taps of MFMA work instead of 36.  w_dgrad_s2 holds the four class packs
+// back to back: class c = 2*py+px is [Cin][Kdp_c], Kdp_c = round_up(ntaps_c * N, 32), k = (kh', kw', n).
+int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
+                         int B, int H, int W, int ldx, int xcoff, int Cin, int N,
+                         int ldy, int ycoff, int accumulate, hipStream_t stream) {
+  KOD_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "conv_dgrad_s2: input dims must be even");
+  const int Ho = H / 2, Wo = W / 2;
+  size_t woff = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int py = c >> 1, px = c & 1;
+    const int KH = 1 + py, KW = 1 + px;
+    const int Kp = (KH * KW * N + 31) / 32 * 32;
+    ConvArgs a = {};
+    // gather source dy [B,Ho,Wo,N]; class outputs form a Ho x Wo grid scattered into dx with stride 2
+    int rc = fill_common(a, dy, (const bf16_t*)w_dgrad_s2 + woff, B, Ho, Wo, ldy, ycoff, N, Ho, Wo, Cin, KH, KW, Kp);
+    if (rc) return rc;
+    KOD_CHECK_ARG(dx && Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0 && xcoff + Cin <= ldx, "conv_dgrad_s2: bad output slice");
+    a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff; a.accumulate = accumulate;
+    a.mul_h = 1; a.mul_w = 1; a.add_h = py; a.add_w = px; a.tap_sign = -1; a.sh_shift = 0; a.sw_shift = 0;
+    a.out_mul = 2; a.out_off_y = py; a.out_off_x = px; a.out_H = H; a.out_W = W;
+    rc = launch<MODE_PLAIN>(a, stream);
+    if (rc) return rc;
+    woff += (size_t)Cin * Kp;
+  }
+  return KOD_OK;
 }
 
 }  // extern "C"

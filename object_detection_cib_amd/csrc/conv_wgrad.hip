@@ -79,6 +79,17 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_kernel(WgradArgs a) {
   const int HWo = a.Ho * a.Wo;
 
   u32x4 xreg[XL], yreg[YL];
+  // incremental (b, oy, ox) of each gather row: one division at the start, then +32 rows per step
+  int sb[XL], soy[XL], sox[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    int m = m_begin + xrow0 + i * XRS;
+    int b = m / HWo;
+    int rem = m - b * HWo;
+    soy[i] = rem / a.Wo;
+    sox[i] = rem - soy[i] * a.Wo;
+    sb[i] = b;
+  }
   auto load_tile = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
@@ -86,16 +97,17 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_kernel(WgradArgs a) {
       int m = mb + row;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (row < 32 && m < m_end && xkvalid) {
-        int b = m / HWo;
-        int rem = m - b * HWo;
-        int oy = rem / a.Wo;
-        int ox = rem - oy * a.Wo;
-        int iy = oy * a.SH - a.PH + xkh;
-        int ix = ox * a.SW - a.PW + xkw;
+        int iy = soy[i] * a.SH - a.PH + xkh;
+        int ix = sox[i] * a.SW - a.PW + xkw;
         if (iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws)
-          v = *reinterpret_cast<const u32x4*>(a.x + (size_t)((b * a.Hs + iy) * a.Ws + ix) * a.ldx + a.xcoff + xci);
+          v = *reinterpret_cast<const u32x4*>(a.x + (size_t)((sb[i] * a.Hs + iy) * a.Ws + ix) * a.ldx + a.xcoff + xci);
       }
       xreg[i] = v;
+      sox[i] += 32;
+      while (sox[i] >= a.Wo) {
+        sox[i] -= a.Wo;
+        if (++soy[i] >= a.Ho) { soy[i] = 0; ++sb[i]; }
+      }
     }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
@@ -242,6 +254,8 @@ int launch_cfg(WgradArgs a, hipStream_t stream) {
 void tile_shape(int N, int Kp, int* tn, int* tk) {
   *tn = N > 64 ? 128 : (N > 32 ? 64 : 32);
   *tk = Kp > 64 ? 128 : (Kp > 32 ? 64 : 32);
+  // narrow outputs: let one block cover all of K so dY is streamed once
+  if (*tn == 32 && (Kp == 160 || Kp == 288)) *tk = Kp;
 }
 
 }  // namespace
@@ -286,6 +300,8 @@ int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* gra
   tile_shape(N, Kp, &tn, &tk);
   if (tn == 128 && tk == 128) rc = launch_cfg<2, 2, 2, 2>(a, stream);
   else if (tn == 64 && tk == 128) rc = launch_cfg<2, 2, 1, 2>(a, stream);
+  else if (tn == 32 && tk == 160) rc = launch_cfg<1, 5, 1, 1>(a, stream);
+  else if (tn == 32 && tk == 288) rc = launch_cfg<1, 9, 1, 1>(a, stream);
   else if (tn == 32 && tk == 128) rc = launch_cfg<1, 4, 1, 1>(a, stream);
   else if (tn == 128 && tk == 64) rc = launch_cfg<2, 2, 2, 1>(a, stream);
   else if (tn == 64 && tk == 64) rc = launch_cfg<2, 2, 1, 1>(a, stream);

@@ -27,7 +27,7 @@ struct PackDesc {          // all int64 so the host can fill it as a plain int64
   long N, Cin, KH, KW;     // true weight dims [N][Cin][KH][KW]
   long Kp, Kdp;            // padded row lengths of the two packs
   long Ntot, n_off;        // dgrad pack: channels per tap (padded total) and this weight's first channel
-  long stem;               // 1: 6x6/s2 stem in pixel-pair form, k = (kh, kw', dx, c4)
+  long stem;               // 1: 6x6/s2 stem in pixel-pair form, k = (kh, kw', dx, c4); 2: 3x3/s2 parity-class dgrad packs
   long blk_begin;          // first block of this descriptor in the grid
 };
 
@@ -58,7 +58,24 @@ __global__ void pack_weights_kernel(const float* master, bf16_t* fpack, bf16_t* 
     fpack[d.f_off + n * d.Kp + k] = v;
   } else {
     fpack[d.f_off + n * d.Kp + tap * d.Cin + ci] = v;
-    if (d.d_off >= 0) dpack[d.d_off + ci * d.Kdp + tap * d.Ntot + d.n_off + n] = v;
+    if (d.d_off >= 0) {
+      if (d.stem == 2) {
+        // 3x3 stride-2 layer: four parity-class packs (see kodhip_conv_dgrad_s2)
+        long kh = tap / 3, kw = tap - kh * 3;
+        long py = kh != 1, px = kw != 1;
+        long khp = kh == 2, kwp = kw == 2;
+        long base = d.d_off;
+        for (long c = 0; c < 2 * py + px; ++c) {
+          long nt = (1 + (c >> 1)) * (1 + (c & 1));
+          base += d.Cin * ((nt * d.N + 31) / 32 * 32);
+        }
+        long KW = 1 + px;
+        long Kc = ((1 + py) * KW * d.N + 31) / 32 * 32;
+        dpack[base + ci * Kc + (khp * KW + kwp) * d.N + n] = v;
+      } else {
+        dpack[d.d_off + ci * d.Kdp + tap * d.Ntot + d.n_off + n] = v;
+      }
+    }
   }
 }
 

@@ -134,7 +134,10 @@ class Engine:
             st.Kdp = _pad(u.k * u.k * u.cout, 32)
             st.f_off, st.d_off = foff, (-1 if u.stem else doff)
             foff += u.cout * st.Kp
-            if not u.stem:
+            s2 = (not u.stem) and u.k == 3 and u.s == 2 and u.p == 1
+            if s2:
+                doff += u.cin * sum(_pad(nt * u.cout, 32) for nt in (1, 2, 2, 4))
+            elif not u.stem:
                 doff += u.cin * st.Kdp
             st.w_off = layout[u.name + ".0.weight"][0]
             st.g_off = layout[u.name + ".1.weight"][0]
@@ -144,7 +147,7 @@ class Engine:
                 add_desc(u.name + ".0.weight", st.f_off, -1, u.cout, 3, 6, 6, st.Kp, 0, 0, 0, 1)
             else:
                 add_desc(u.name + ".0.weight", st.f_off, st.d_off, u.cout, u.cin, u.k, u.k, st.Kp, st.Kdp,
-                         u.cout, 0, 0)
+                         u.cout, 0, 2 if s2 else 0)
             self.ustate[u.name] = st
         self.hstate = {}
         self.head_npad = _pad(A * (5 + nc), 8)
@@ -443,8 +446,13 @@ class Engine:
                     geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1)
                 else:
                     geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p)
-                    chk(lib.kodhip_conv_dgrad(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
-                                              *geo, st.Kdp, C_, 0, acc_flag(u.src), s), u.name + ".dgrad")
+                    if u.k == 3 and u.s == 2 and u.p == 1:
+                        chk(lib.kodhip_conv_dgrad_s2(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
+                                                     B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,
+                                                     acc_flag(u.src), s), u.name + ".dgrad")
+                    else:
+                        chk(lib.kodhip_conv_dgrad(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
+                                                  *geo, st.Kdp, C_, 0, acc_flag(u.src), s), u.name + ".dgrad")
                 chk(lib.kodhip_conv_wgrad(self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
                                           *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0, s), u.name + ".wgrad")
             # gradient buckets complete from the arena's end toward its start

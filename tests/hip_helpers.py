@@ -28,7 +28,7 @@ def bf(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).float()
 
 
-def pack(weights, stem=False, ntot=None):
+def pack(weights, stem=False, ntot=None, s2=False):
     """weights: list of fp32 [N,Cin,KH,KW] tensors forming one layer (heads: 3).  Returns dict with bf16
     packs + geometry, produced by the library's pack kernel."""
     lib = _lib.lib()
@@ -40,11 +40,12 @@ def pack(weights, stem=False, ntot=None):
     Kdp = pad(KH * KW * Ntot, 32)
     master = torch.cat([w.reshape(-1) for w in weights]).float().cuda()
     fpack = torch.zeros(Ntot * Kp, dtype=torch.bfloat16, device="cuda")
-    dpack = torch.zeros(max(Cin * Kdp, 8), dtype=torch.bfloat16, device="cuda")
+    dsize = Cin * sum(pad(nt * N, 32) for nt in (1, 2, 2, 4)) if s2 else Cin * Kdp
+    dpack = torch.zeros(max(dsize, 8), dtype=torch.bfloat16, device="cuda")
     descs, w_off, n_off, blk = [], 0, 0, 0
     for w in weights:
         n = w.shape[0]
-        descs.append([w_off, n_off * Kp, -1 if stem else 0, n, Cin, KH, KW, Kp, Kdp, Ntot, n_off, 1 if stem else 0, blk])
+        descs.append([w_off, n_off * Kp, -1 if stem else 0, n, Cin, KH, KW, Kp, Kdp, Ntot, n_off, 1 if stem else (2 if s2 else 0), blk])
         blk += (w.numel() + 255) // 256
         w_off += w.numel()
         n_off += n

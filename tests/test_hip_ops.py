@@ -77,6 +77,29 @@ def test_conv_fwd_dgrad_wgrad(case):
     _close(gw.cpu(), wr.grad, 2e-3, 2e-3 * wr.grad.abs().max().item(), "wgrad")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 16, 16, 64), (1, 128, 10, 12, 128), (3, 48, 6, 8, 96), (1, 256, 4, 4, 512)])
+def test_conv_dgrad_stride2_parity_classes(case):
+    """3x3/s2/p1 data gradient through the 4 parity-class launches (+ accumulate form, channel slice)."""
+    B, Cin, H, W, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = bf(torch.randn(B, Cin, H, W, generator=g)).requires_grad_(True)
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    y = F.conv2d(x, w, None, 2, 1)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    lib = _lib.lib()
+    pk = pack([w], s2=True)
+    dyb = nhwc(dy)
+    ld = Cin + 16
+    dxb = torch.zeros((B, H, W, ld), dtype=torch.bfloat16, device="cuda")
+    for acc, mult in ((0, 1.0), (1, 2.0)):
+        _lib.check(lib.kodhip_conv_dgrad_s2(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, ld, 8, Cin,
+                                            Cout, Cout, 0, acc, stream()), "dgrad_s2")
+        got = nchw(dxb)
+        _close(got[:, 8:8 + Cin], mult * x.grad, 1e-2 * mult, 3e-2 * mult, "dgrad s2")
+        assert (got[:, :8] == 0).all() and (got[:, 8 + Cin:] == 0).all()
+
+
 def test_conv_channel_slices():
     """Input read from / output written into channel slices of wider buffers (concat elimination)."""
     g = torch.Generator().manual_seed(5)
