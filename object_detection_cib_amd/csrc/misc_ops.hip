@@ -52,7 +52,7 @@ __global__ void pack_weights_kernel(const float* master, bf16_t* fpack, bf16_t* 
   long ci = rem / KK;
   long tap = rem - ci * KK;
   bf16_t v = (bf16_t)master[d.w_off + local];
-  if (d.stem) {
+  if (d.stem == 1) {
     long kh = tap / 6, kw = tap - kh * 6;
     long k = (kh * 3 + (kw >> 1)) * 8 + (kw & 1) * 4 + ci;
     fpack[d.f_off + n * d.Kp + k] = v;
