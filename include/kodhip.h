@@ -134,6 +134,12 @@ int kodhip_yolo_loss(const KodLossLevel* levels /* host[3] */, int B, int A, int
                      const float* upstream, float* partials, int nslots, float* out, int compute_grad,
                      kodStream_t stream);
 
+/* ---- device data path: mosaic + warpAffine + HSV + flip + /255 (+ mixup) in one gather kernel
+ *      (kod/data/mosaic.py:58-132, kod/data/augmentations/default.py:279-320,354-408,433-438) ------- */
+int kodhip_compose_desc_bytes(void);
+int kodhip_compose_batch(const void* pool, const void* descs, const float* mix, const void* bilinear_tab,
+                         float* out_f32, void* out_pairs, int B, int S, kodStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

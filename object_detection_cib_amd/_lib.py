@@ -53,6 +53,8 @@ SIGNATURES = {
     "kodhip_head_bwd_prep": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "kodhip_sgd_nesterov": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "kodhip_fill_u32": (i32, [vp, u32, i64, vp]),
+    "kodhip_compose_desc_bytes": (i32, []),
+    "kodhip_compose_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_assign_targets": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, C.POINTER(KodAssignLevel), vp]),
     "kodhip_yolo_loss": (i32, [C.POINTER(KodLossLevel), i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp,
                                i32, vp]),

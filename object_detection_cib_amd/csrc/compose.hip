@@ -1,0 +1,167 @@
+// Device data path: mosaic paste + affine warp + HSV jitter + flip + /255 (+ mixup) in ONE gather kernel.
+//
+// Reference (per sample, in DataLoader workers, numpy / OpenCV):
+//   mosaic   kod/data/mosaic.py:58-132          4 u8 HWC images pasted on a 2S x 2S canvas filled with 114
+//   affine   kod/data/augmentations/default.py:279-320   cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT 114) -> S x S
+//   hsv      default.py:354-383                 cvtColor(BGR2HSV) -> 3 LUTs -> cvtColor(HSV2BGR) (on RGB data: kept)
+//   flip     default.py:386-397                 np.fliplr
+//   tensor   default.py:433-438,482             ToFloat(255) + HWC->CHW
+//   mixup    default.py:400-408                 im1*r + im2*(1-r)
+//
+// Here the canvas is never materialised: every output pixel inverse-maps into canvas coordinates with
+// OpenCV's fixed-point arithmetic (AB_BITS=10, INTER_BITS=5, 15-bit bilinear weights), resolves each of the
+// four taps to a source-image pixel (or 114) through the mosaic rectangles, and runs the integer HSV round
+// trip in registers.  Source images live in one u8 pool in HBM (the RAM cache of kod/data/detection.py:66-76).
+// Host code supplies, per sample, the draws in the reference's RNG order (see data/device_pipeline.py).
+#include "kodhip_common.h"
+
+namespace {
+
+struct TileDesc {            // one mosaic tile
+  long off;                  // byte offset of the source image in the pool (HWC u8)
+  int h, w;                  // source image size
+  int x1a, y1a, x2a, y2a;    // destination rectangle on the canvas
+  int x1b, y1b;              // source rectangle origin
+};
+struct SampleDesc {
+  TileDesc tile[4];
+  double im[6];              // inverse affine matrix (row major 2x3), as OpenCV computes it
+  unsigned char lut_h[256], lut_s[256], lut_v[256];
+  int hsv_on;
+  int flip;
+  int canvas;                // 2S
+};
+
+__constant__ short c_tab_dummy;   // (keeps the TU non-empty for some toolchains)
+
+__device__ __forceinline__ int fetch(const unsigned char* pool, const SampleDesc& d, int y, int x, int c) {
+  if (x < 0 || y < 0 || x >= d.canvas || y >= d.canvas) return 114;
+  // quadrant by destination rectangles (tiles never overlap)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const TileDesc& t = d.tile[i];
+    if (x >= t.x1a && x < t.x2a && y >= t.y1a && y < t.y2a) {
+      int sy = y - t.y1a + t.y1b, sx = x - t.x1a + t.x1b;
+      return pool[t.off + ((long)sy * t.w + sx) * 3 + c];
+    }
+  }
+  return 114;
+}
+
+// OpenCV RGB2HSV_b (hsv_shift = 12, hrange = 180) on (b,g,r) = the three stored channels in order
+__device__ __forceinline__ void bgr2hsv(int b, int g, int r, int& h, int& s, int& v) {
+  v = max(max(b, g), r);
+  int vmin = min(min(b, g), r);
+  int diff = v - vmin;
+  int vr = (v == r) ? -1 : 0, vg = (v == g) ? -1 : 0;
+  int sdiv = v ? (int)__double2ll_rn((double)(255 << 12) / (double)v) : 0;
+  int hdiv = diff ? (int)__double2ll_rn((double)(180 << 12) / (6.0 * (double)diff)) : 0;
+  s = (diff * sdiv + (1 << 11)) >> 12;
+  int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+  hh = (hh * hdiv + (1 << 11)) >> 12;
+  hh += hh < 0 ? 180 : 0;
+  h = hh;
+}
+
+// OpenCV HSV2RGB_b for u8: float path, h*(6/180), s/255, v/255, result saturate_cast<uchar>(x*255)
+__device__ __forceinline__ void hsv2bgr(int h, int s, int v, int& b, int& g, int& r) {
+  float fh = (float)h * (6.f / 180.f), fs = (float)s * (1.f / 255.f), fv = (float)v * (1.f / 255.f);
+  float ob, og, orr;
+  if (fs == 0.f) {
+    ob = og = orr = fv;
+  } else {
+    if (fh < 0.f) fh += 6.f; else if (fh >= 6.f) fh -= 6.f;
+    int sector = (int)floorf(fh);
+    fh -= (float)sector;
+    if ((unsigned)sector >= 6u) { sector = 0; fh = 0.f; }
+    float tab[4];
+    tab[0] = fv;
+    tab[1] = fv * (1.f - fs);
+    tab[2] = fv * (1.f - fs * fh);
+    tab[3] = fv * (1.f - fs * (1.f - fh));
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    ob = tab[sd[sector][0]]; og = tab[sd[sector][1]]; orr = tab[sd[sector][2]];
+  }
+  b = min(max((int)rintf(ob * 255.f), 0), 255);
+  g = min(max((int)rintf(og * 255.f), 0), 255);
+  r = min(max((int)rintf(orr * 255.f), 0), 255);
+}
+
+// one composite pixel (3 channels, u8 domain) of sample d at output (y, x)
+__device__ __forceinline__ void composite(const unsigned char* pool, const SampleDesc& d, const short* tab,
+                                          int y, int xo, int S, int out[3]) {
+  const int x = d.flip ? S - 1 - xo : xo;
+  // cv::warpAffine: X0 = round((M01*y + M02)*1024) + 16, adelta = round(M00*x*1024); coords in 1/32 px
+  const long AB = 1024;
+  long X0 = __double2ll_rn((d.im[1] * y + d.im[2]) * (double)AB) + 16;
+  long Y0 = __double2ll_rn((d.im[4] * y + d.im[5]) * (double)AB) + 16;
+  long ad = __double2ll_rn(d.im[0] * x * (double)AB);
+  long bd = __double2ll_rn(d.im[3] * x * (double)AB);
+  int X = (int)((X0 + ad) >> 5), Y = (int)((Y0 + bd) >> 5);
+  int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+  const short* w = tab + (fy * 32 + fx) * 4;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int acc = fetch(pool, d, sy, sx, c) * w[0] + fetch(pool, d, sy, sx + 1, c) * w[1] +
+              fetch(pool, d, sy + 1, sx, c) * w[2] + fetch(pool, d, sy + 1, sx + 1, c) * w[3];
+    out[c] = (acc + (1 << 14)) >> 15;
+  }
+  if (d.hsv_on) {
+    int h, s, v, b, g, r;
+    bgr2hsv(out[0], out[1], out[2], h, s, v);
+    hsv2bgr(d.lut_h[h], d.lut_s[s], d.lut_v[v], b, g, r);
+    out[0] = b; out[1] = g; out[2] = r;
+  }
+}
+
+// grid: (ceil(S*S/256), B).  descs: [B][2] SampleDesc (second = mixup partner), mix[b] < 0 => no mixup.
+__global__ __launch_bounds__(256) void compose_kernel(const unsigned char* pool, const SampleDesc* descs,
+                                                      const float* mix, const short* tab, float* out_f32,
+                                                      bf16_t* out_pairs, int S) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= S * S) return;
+  const int y = p / S, x = p - y * S;
+  int px[3];
+  composite(pool, descs[b * 2], tab, y, x, S, px);
+  float v[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] = (float)px[c] / 255.f;
+  const float r = mix[b * 2];
+  if (r >= 0.f) {
+    int q[3];
+    composite(pool, descs[b * 2 + 1], tab, y, x, S, q);
+    const float r1 = mix[b * 2 + 1];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = v[c] * r + ((float)q[c] / 255.f) * r1;
+  }
+  if (out_f32) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out_f32[((size_t)(b * 3 + c) * S + y) * S + x] = v[c];
+  }
+  if (out_pairs) {   // network input layout [B][S][S/2][8] = pixel pairs x 4 channels
+    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)0.f};
+    *reinterpret_cast<bf16x4*>(out_pairs + ((size_t)(b * S + y) * S + x) * 4) = o;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int kodhip_compose_desc_bytes(void) { return (int)sizeof(SampleDesc); }
+
+// pool: u8 source images (HWC); descs: device [B][2] SampleDesc; mix: device [B][2] floats (r, 1-r) or (-1, 0);
+// bilinear_tab: device 32*32*4 int16 (OpenCV fixed-point table); out_f32 [B,3,S,S] and/or out_pairs (bf16).
+int kodhip_compose_batch(const void* pool, const void* descs, const float* mix, const void* bilinear_tab,
+                         float* out_f32, void* out_pairs, int B, int S, hipStream_t stream) {
+  KOD_CHECK_ARG(pool && descs && mix && bilinear_tab && (out_f32 || out_pairs) && B > 0 && S > 0 && S % 2 == 0,
+                "compose_batch: bad args");
+  hipLaunchKernelGGL(compose_kernel, dim3(cdiv((long)S * S, 256), B), dim3(256), 0, stream,
+                     (const unsigned char*)pool, (const SampleDesc*)descs, mix, (const short*)bilinear_tab, out_f32,
+                     (bf16_t*)out_pairs, S);
+  KOD_LAUNCH_CHECK("compose_batch");
+  return KOD_OK;
+}
+
+}  // extern "C"

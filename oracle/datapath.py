@@ -190,7 +190,9 @@ _TAB = None
 
 
 def _bilinear_tab():
-    """OpenCV initInterTab2D(INTER_LINEAR, fixpt=true): 32x32x(2x2) int16 weights summing to 32768."""
+    """OpenCV initInterTab2D(INTER_LINEAR, fixpt=true): 32x32x(2x2) short weights = saturate(wy*wx*32768).
+    Products are exact multiples of 32 => sums are 32768, except entry (0,0) whose 32768 saturates to 32767;
+    OpenCV's fix-up for that entry indexes past the 2x2 block (into the next entry, later overwritten)."""
     global _TAB
     if _TAB is None:
         n = 32
@@ -199,18 +201,7 @@ def _bilinear_tab():
         for i in range(n):
             for j in range(n):
                 f = (t1[i][:, None] * t1[j][None, :]).astype(np.float32)                  # [ky,kx]
-                it = np.array([[_sat16(np.rint(float(v) * 32768)) for v in row] for row in f], dtype=np.int64)
-                s = int(it.sum())
-                if s != 32768:                 # OpenCV nudges the largest/smallest central weight
-                    diff = s - 32768
-                    flat = it.reshape(-1)
-                    # ksize=2: candidate window is the whole 2x2 block
-                    if diff < 0:
-                        k = int(np.argmax(flat)); flat[k] -= diff
-                    else:
-                        k = int(np.argmin(flat)); flat[k] -= diff
-                    it = flat.reshape(2, 2)
-                tab[i, j] = it.reshape(-1)
+                tab[i, j] = np.array([_sat16(np.rint(float(v) * 32768)) for v in f.reshape(-1)], dtype=np.int64)
         _TAB = tab
     return _TAB
 
@@ -273,3 +264,41 @@ def augment_hsv_u8(img: np.ndarray, r3: np.ndarray) -> np.ndarray:
     lh, ls, lv = hsv_luts(r3)
     out = np.stack((lh[hsv[..., 0]], ls[hsv[..., 1]], lv[hsv[..., 2]]), -1)
     return hsv2bgr_u8(out)
+
+
+# ----------------------------------------------------------------------------- whole-sample protocol
+def augment_sample(canvas, boxes, labels, border, S, rng: np.random.Generator, hsv=(0.015, 0.7, 0.4),
+                   flip_prob=0.5, translate=0.1, scale=0.5):
+    """TrainSampleAugmentor.__call__ (default.py:440-488) without the four p=0.01 albumentations colour ops
+    (image_color_transforms=False, kod/configs/data/augmentations/no_aug_params.yaml:15)."""
+    draws = affine_draws(rng, translate=translate, scale=scale)
+    M, (wo, ho) = affine_matrix(draws, canvas.shape[1], canvas.shape[0], border)
+    img = warp_affine_u8(canvas, M[:2], wo, ho)
+    if len(labels):
+        nb, keep = affine_boxes(boxes, M, wo, ho, draws[3])
+        boxes, labels = nb[keep], labels[keep]
+    r3 = rng.uniform(-1, 1, 3) * np.array(hsv) + 1
+    img = augment_hsv_u8(img, r3)
+    if flip_prob > 0.0 and rng.random() < flip_prob:
+        img = np.fliplr(img)
+        boxes = flip_boxes(boxes, img.shape[1])
+    chw = np.ascontiguousarray(img.transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0)
+    return chw, boxes, labels
+
+
+def train_sample(cache, idx, S, rng: np.random.Generator, mixup_prob=0.0, rnd=random, nprnd=np.random):
+    """DetectionDataset.__getitem__ with mosaic on (detection.py:102-156).  cache: list of (u8 HWC, boxes, labels)."""
+    n = len(cache)
+    indices = [idx] + rnd.choices(range(n), k=3, weights=None)
+    rnd.shuffle(indices)
+    canvas, bb, lb, border, _ = mosaic([cache[i] for i in indices], S, rnd)
+    img, bb, lb = augment_sample(canvas, bb, lb, border, S, rng)
+    if rnd.random() < mixup_prob:
+        m_idx = rnd.choices(range(n), k=4, weights=None)
+        canvas2, bb2, lb2, border2, _ = mosaic([cache[i] for i in m_idx], S, rnd)
+        img2, bb2, lb2 = augment_sample(canvas2, bb2, lb2, border2, S, rng)
+        r = nprnd.beta(32.0, 32.0)
+        import torch
+        img = mixup_blend(torch.from_numpy(img), torch.from_numpy(img2), r).numpy()
+        bb, lb = np.concatenate((bb, bb2), 0), np.concatenate((lb, lb2), 0)
+    return img, bb, lb

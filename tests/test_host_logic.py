@@ -77,3 +77,34 @@ def test_iou_calculator_contract():
     assert IoUCalculator("ciou", 1e-7).iou_type is IoUType.ciou
     with pytest.raises(NotImplementedError):
         IoUCalculator("giou")
+
+
+def test_device_pipeline_host_math_matches_golden(golden):
+    """Box / matrix arithmetic of the device data path's host side (numpy f64) against the reference vectors."""
+    import random
+    from oracle import synth
+    from object_detection_cib_amd.data import device_pipeline as P
+    g = golden("mosaic")
+    for case, (S, seed) in synth.mosaic_cases().items():
+        samples = synth.source_samples(4, S, seed)
+        random.seed(seed)
+        border = (-S // 2, -S // 2)
+        yc, xc = (int(random.uniform(-x, 2 * S + x)) for x in border)
+        rects = P.mosaic_layout([s[0].shape[:2] for s in samples], xc, yc, S)
+        bb, lb = P.mosaic_boxes(samples, rects, S)
+        np.testing.assert_array_equal(bb, g[case + ".bboxes"])
+        np.testing.assert_array_equal(lb, g[case + ".labels"])
+    ga = golden("affine")
+    rng = np.random.default_rng(51)
+    for i in range(6):
+        draws = tuple(ga["rand_values"][i])
+        M, wo, ho = P.affine_matrix(draws, 128, 128, (-32, -32))
+        np.testing.assert_allclose(M, ga["matrices"][i], rtol=0, atol=1e-12)
+        nb, keep = P.affine_boxes(ga["boxes_in"], M, wo, ho, draws[3])
+        np.testing.assert_allclose(nb, ga["boxes_out"][i], rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(keep, ga["keep"][i])
+        inv = P.invert_affine(M)
+        np.testing.assert_allclose(np.vstack([inv, [0, 0, 1]]) @ M, np.eye(3), atol=1e-9)
+    tab = P.bilinear_table()
+    sums = tab.astype(np.int64).sum(1)
+    assert tab.shape == (1024, 4) and tab[0].tolist() == [32767, 0, 0, 0] and (sums[1:] == 32768).all()

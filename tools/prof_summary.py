@@ -1,0 +1,26 @@
+"""Summarise a rocprofv3 --kernel-trace --stats csv directory of bench.py: kernel families + per-layer conv table."""
+import csv, glob, sys
+sys.path.insert(0, '.')
+from object_detection_cib_amd.engine.graph import build_graph
+
+d = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rows = list(csv.DictReader(open(glob.glob(d + '/*/*kernel_stats.csv')[0])))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+print("== kernel stats (all dispatches)")
+for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:22]:
+    print("%6.2f%% calls=%5s avg=%9.1fus  %s" % (100 * float(r['TotalDurationNs']) / tot, r['Calls'], float(r['AverageNs']) / 1e3, r['Name'][:100]))
+tr = list(csv.DictReader(open(glob.glob(d + '/*/*kernel_trace.csv')[0])))
+tr.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(tr) if 'nchw_to_nhwc4' in r['Kernel_Name']]
+step = tr[idx[-2]:idx[-1]] if len(idx) > 1 else tr[idx[-1]:]
+dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+print("== last full step: %d dispatches, sum of kernel time %.2f ms, span %.2f ms" % (
+    len(step), sum(dur(r) for r in step) / 1e3, (int(step[-1]['End_Timestamp']) - int(step[0]['Start_Timestamp'])) / 1e6))
+fam = {}
+for r in step:
+    n = r['Kernel_Name']
+    key = n.split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')[:60]
+    fam.setdefault(key, [0, 0.0]); fam[key][0] += 1; fam[key][1] += dur(r)
+for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:25]:
+    print("   %8.1f us  x%-4d %s" % (t, c, k))
