@@ -140,6 +140,14 @@ int kodhip_compose_desc_bytes(void);
 int kodhip_compose_batch(const void* pool, const void* descs, const float* mix, const void* bilinear_tab,
                          float* out_f32, void* out_pairs, int B, int S, kodStream_t stream);
 
+/* ---- evaluation post-process (kod/lightning/experiments/yv5_baseline/layers.py:55-155, exp.py:70-102;
+ *      kod/core/nms.py:9-75 + torchvision.ops.nms) -------------------------------------------------- */
+typedef struct KodDecodeLevel { const float* raw; int h, w, stride; float anchor_w[3], anchor_h[3]; } KodDecodeLevel;
+int kodhip_decode(const KodDecodeLevel* levels /* host[3] */, float* det, int B, int A, int nc, kodStream_t stream);
+int kodhip_nms(const float* det, void* keys, int key_cap, int* ncand, float* out, int* nout,
+               int B, int rows, int nc, float conf_thres, float nms_thres, int max_det, int max_nms, float max_wh,
+               kodStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,10 @@ class KodAssignLevel(C.Structure):
                 ("anchor_w", f32 * 3), ("anchor_h", f32 * 3), ("stride", i32)]
 
 
+class KodDecodeLevel(C.Structure):
+    _fields_ = [("raw", vp), ("h", i32), ("w", i32), ("stride", i32), ("anchor_w", f32 * 3), ("anchor_h", f32 * 3)]
+
+
 class KodLossLevel(C.Structure):
     _fields_ = [("logits", vp), ("grad", vp), ("idx", vp), ("label", vp), ("gt", vp), ("anc", vp),
                 ("count", vp), ("cellmaps", vp), ("rowprev", vp), ("rowgrad", vp), ("tobj", vp),
@@ -55,6 +59,8 @@ SIGNATURES = {
     "kodhip_fill_u32": (i32, [vp, u32, i64, vp]),
     "kodhip_compose_desc_bytes": (i32, []),
     "kodhip_compose_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "kodhip_decode": (i32, [C.POINTER(KodDecodeLevel), vp, i32, i32, i32, vp]),
+    "kodhip_nms": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, f32, vp]),
     "kodhip_assign_targets": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, C.POINTER(KodAssignLevel), vp]),
     "kodhip_yolo_loss": (i32, [C.POINTER(KodLossLevel), i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp,
                                i32, vp]),

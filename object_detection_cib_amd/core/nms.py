@@ -1,0 +1,38 @@
+"""non_max_suppression - drop-in for kod.core.nms.non_max_suppression (kod/core/nms.py:9-75).
+
+Same signature and result (list of [n<=300, 6] tensors: x1, y1, x2, y2, conf, cls); the boolean-mask /
+nonzero / argsort / torchvision.ops.nms chain of the reference is three HIP kernels per batch
+(csrc/postproc.hip), so validation stays on the device.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+from .. import _lib
+
+
+def non_max_suppression(detections: torch.Tensor, conf_thres: float = 0.25, nms_thres: float = 0.45,
+                        classes=None) -> Sequence[torch.Tensor]:
+    if classes is not None:
+        raise NotImplementedError("class filtering is not on the HIP path (the reference never passes it)")
+    _lib.require_gpu()
+    det = detections.contiguous().float()
+    B, rows, P = det.shape
+    nc = P - 5
+    max_wh, max_det, max_nms = 4096.0, 300, 30000                  # nms.py:22-26
+    need = rows * nc
+    key_cap = 64
+    while key_cap < need:
+        key_cap <<= 1
+    dev = det.device
+    keys = torch.empty(B * key_cap, dtype=torch.int64, device=dev)
+    ncand = torch.empty(B, dtype=torch.int32, device=dev)
+    out = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
+    nout = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().kodhip_nms(det.data_ptr(), keys.data_ptr(), key_cap, ncand.data_ptr(), out.data_ptr(),
+                                     nout.data_ptr(), B, rows, nc, float(conf_thres), float(nms_thres), max_det,
+                                     max_nms, max_wh, torch.cuda.current_stream().cuda_stream), "nms")
+    counts = nout.tolist()                                           # one sync per batch (sizes the outputs)
+    return [out[b, :n] for b, n in enumerate(counts)]
