@@ -25,7 +25,8 @@ def test_decode_and_nms_golden(golden, case):
     det = get_detections(FeatureShape(width=size, height=size), net, ANCH)
     want = torch.from_numpy(g[case + ".det"])
     err = (det.cpu() - want).abs()
-    assert (err <= 1e-5 * want.abs() + 1e-6).all(), err.max()
+    # boxes are differences of O(image size) fp32 terms: 1 ulp of 640 is 6e-5
+    assert (err[..., :4] <= 2e-4).all() and (err[..., 4:] <= 1e-6 + 1e-5 * want[..., 4:]).all(), err.max()
     # NMS is comparison logic on fp32: feed the reference's own decoded tensor => bit-exact rows
     for conf, thr in ((0.001, 0.6), (0.25, 0.45)):
         res = non_max_suppression(want.cuda(), conf, thr)
@@ -39,8 +40,8 @@ def test_nms_full_size_vs_oracle():
     size, nc, B = 640, 10, 2
     heads = synth.head_logits(B, size, nc, seed=3, scale=2.5)
     det = D.decode(NetOut(*[HeadOut(*h) for h in heads]), size, size)
-    det[..., 4] = det[..., 4] * 20                           # push objectness up: many candidates
-    det[..., 4].clamp_(0, 1)
+    n_cand = int(((det[..., 5:] * det[..., 4:5] > 0.001) & (det[..., 4:5] > 0.001)).sum(-1).sum(-1).min())
+    assert n_cand > 30000                                    # exercises the top-30000 truncation
     ref = D.nms(det.clone(), 0.001, 0.6)
     got = non_max_suppression(det.cuda(), 0.001, 0.6)
     for r, g_ in zip(ref, got):
