@@ -148,6 +148,12 @@ int kodhip_nms(const float* det, void* keys, int key_cap, int* ncand, float* out
                int B, int rows, int nc, float conf_thres, float nms_thres, int max_det, int max_nms, float max_wh,
                kodStream_t stream);
 
+/* detection <-> ground-truth matching of COCO-style mAP (kod/lightning/callbacks/pycoco_map_eval.py:50-125 ->
+ * vision_evaluation -> pycocotools COCOeval.evaluateImg); tp [B][max_det][T] u8, counted [B][max_det] u8 */
+int kodhip_map_match(const float* det, const int* ndet, const double* gt_boxes, const long* gt_labels,
+                     const int* gt_start, void* tp, void* counted, int B, int max_det, int nc,
+                     const double* iou_thresholds /* host */, int T, int max_per_class, kodStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,7 @@ SIGNATURES = {
     "kodhip_compose_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_decode": (i32, [C.POINTER(KodDecodeLevel), vp, i32, i32, i32, vp]),
     "kodhip_nms": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, f32, vp]),
+    "kodhip_map_match": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(f64), i32, i32, vp]),
     "kodhip_assign_targets": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, C.POINTER(KodAssignLevel), vp]),
     "kodhip_yolo_loss": (i32, [C.POINTER(KodLossLevel), i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp,
                                i32, vp]),
