@@ -1,0 +1,96 @@
+"""DefaultYolov5Experiment without Lightning: the arithmetic and call order of
+kod/lightning/experiments/yv5_baseline/exp.py:36-185 (training_step, validation_step, configure_optimizers,
+on_before_optimizer_step) plus the epoch loop Lightning's Trainer.fit provides (automatic optimisation:
+zero_grad -> backward -> warm-up hook -> optimizer.step; LambdaLR.step per epoch).  `lightning` is not
+installed in the target image; a LightningModule shell can wrap these methods one to one.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from ....core.types import FeatureShape
+from ....core.nms import non_max_suppression
+from ....nn.optim.smart import SmartSGD
+from ....nn.optim.schedulers import sch_linear
+from ...callbacks.map_eval import DeviceMAPEvaluator
+from .layers import get_detections
+from .type_defs import LayerwiseAnchorInfo
+from .warmup import OptimizerWarmupUpdater
+
+
+class DefaultYolov5Experiment:
+    def __init__(self, net, loss, anchor_info: LayerwiseAnchorInfo, optimizer: Optional[SmartSGD] = None,
+                 sch_fn: Callable = None, optimizer_warmup_updater: Optional[OptimizerWarmupUpdater] = None,
+                 val_nms_conf_threshold: float = 0.001, val_nms_iou_threshold: float = 0.6, max_epochs: int = 300):
+        self.net, self.loss, self.anchor_info = net, loss, anchor_info
+        self.optimizer = optimizer or SmartSGD(net)
+        self.max_epochs = max_epochs
+        self.sch_fn = sch_fn or partial(sch_linear, max_epochs=max_epochs, lrf=0.01)   # configs/nn/schedulers/linear.yaml
+        self.optimizer_warmup_updater = optimizer_warmup_updater
+        self.val_nms_conf_threshold = val_nms_conf_threshold
+        self.val_nms_iou_threshold = val_nms_iou_threshold
+        self.global_step = 0
+        self.current_epoch = 0
+        self.logged = {}
+
+    def get_metrics_to_display(self):
+        return ["box", "cls", "obj"]
+
+    # exp.py:104-138
+    def training_step(self, batch, batch_idx: int = 0):
+        images, targets, _ = batch
+        net_result = self.net(images)
+        shape = FeatureShape(width=images.shape[3], height=images.shape[2])
+        lr = self.loss(shape, net_result, targets)
+        B = images.shape[0]
+        total = B * (lr.localization + lr.classification + lr.objectness)
+        self.logged = {"obj": lr.objectness.detach(), "cls": lr.classification.detach(), "box": lr.localization.detach()}
+        return total
+
+    # exp.py:140-154
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx: int = 0):
+        images, targets, _ = batch
+        was = self.net.training
+        self.net.eval()
+        res = self.net(images)
+        det = get_detections(FeatureShape(width=images.shape[3], height=images.shape[2]), res, self.anchor_info)
+        out = non_max_suppression(det, self.val_nms_conf_threshold, self.val_nms_iou_threshold)
+        self.net.train(was)
+        return targets, out
+
+    # exp.py:164-185 + Lightning automatic optimisation
+    def optimize(self, batch, num_training_batches: int):
+        self.optimizer.zero_grad(set_to_none=True)
+        total = self.training_step(batch)
+        total.backward()
+        if self.optimizer_warmup_updater is not None:
+            nw = max(round(num_training_batches * self.optimizer_warmup_updater.warmup_epochs), 100)
+            if self.global_step <= nw:
+                self.optimizer_warmup_updater(current_step=self.global_step, current_epoch=self.current_epoch,
+                                              max_warmup_steps=nw, sch_fn=self.sch_fn, optimizer=self.optimizer)
+        self.optimizer.step()
+        self.global_step += 1
+        return total
+
+    def end_epoch(self):
+        """LambdaLR.step(): lr = initial_lr * sch_fn(epoch) for the next epoch."""
+        self.current_epoch += 1
+        for pg in self.optimizer.param_groups:
+            pg["lr"] = pg["initial_lr"] * self.sch_fn(self.current_epoch)
+
+    def fit_epoch(self, batches: Sequence, num_training_batches: Optional[int] = None):
+        n = num_training_batches or len(batches)
+        losses = [self.optimize(b, n).detach() for b in batches]
+        self.end_epoch()
+        return torch.stack(losses)
+
+    def validate(self, batches: Sequence, num_classes: int, class_names=None) -> dict:
+        ev = DeviceMAPEvaluator(num_classes, class_names)
+        for b in batches:
+            targets, dets = self.validation_step(b)
+            ev.add_batch(targets, dets)
+        return ev.get_report()

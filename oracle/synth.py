@@ -138,3 +138,31 @@ def source_samples(n: int, S: int, seed: int, nc: int = 10):
 
 def mosaic_cases():
     return {"m64_a": (64, 1), "m64_b": (64, 2), "m640": (640, 2023), "m416": (416, 11)}
+
+
+CLASS_COLORS = np.array([[220, 40, 40], [40, 200, 60], [50, 80, 230], [230, 210, 40], [200, 60, 200],
+                         [40, 210, 210], [240, 140, 30], [130, 70, 30], [160, 160, 160], [250, 250, 250]], dtype=np.uint8)
+
+
+def coco_zipf_like(n: int, S: int, seed: int, nc: int = 10):
+    """Synthetic detection set: class-coloured rectangles on low-contrast noise, 1-9 objects per image, class
+    frequencies ~ Zipf(1.01) (kod/data/builder.py:110-116).  Returns cached-sample tuples (u8 HWC with longest
+    side S, boxes f64 xyxy, labels i64)."""
+    rng = np.random.default_rng(seed)
+    pmf = zipf_pmf(nc)
+    out = []
+    for _ in range(n):
+        rw, rh = [(4, 3), (3, 4), (1, 1), (3, 2)][int(rng.integers(0, 4))]
+        w, h = (S, int(round(S * rh / rw))) if rw >= rh else (int(round(S * rw / rh)), S)
+        img = rng.integers(90, 140, (h, w, 3), dtype=np.uint8)
+        k = int(rng.integers(1, 10))
+        boxes, labels = [], []
+        for _ in range(k):
+            bw, bh = np.exp(rng.uniform(np.log(S / 16), np.log(S / 2.5), 2))
+            cx, cy = rng.uniform(bw / 2, w - bw / 2), rng.uniform(bh / 2, h - bh / 2)
+            x1, y1, x2, y2 = cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2
+            c = int(rng.choice(nc, p=pmf))
+            img[int(y1):int(y2), int(x1):int(x2)] = CLASS_COLORS[c % 10]
+            boxes.append([x1, y1, x2, y2]); labels.append(c)
+        out.append((img, np.array(boxes, dtype=np.float64), np.array(labels, dtype=np.int64)))
+    return out

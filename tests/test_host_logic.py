@@ -108,3 +108,41 @@ def test_device_pipeline_host_math_matches_golden(golden):
     tab = P.bilinear_table()
     sums = tab.astype(np.int64).sum(1)
     assert tab.shape == (1024, 4) and tab[0].tolist() == [32767, 0, 0, 0] and (sums[1:] == 32768).all()
+
+
+def test_samplers_and_schedule_host_mirrors(golden):
+    from object_detection_cib_amd.data import samplers as S
+    from object_detection_cib_amd.nn.optim.schedulers import sch_linear
+    from object_detection_cib_amd.nn.optim.smart import SmartSGD
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.warmup import OptimizerWarmupUpdater
+    from functools import partial
+    g = golden("optim")
+    # warm-up + schedule against the reference vectors (driving a SmartSGD-shaped group list)
+    class _Net:
+        def parameters(self):
+            return []
+    opt = SmartSGD(_Net())
+    assert [pg["name"] for pg in opt.param_groups] == g["group_names"].tolist()
+    assert [pg["weight_decay"] for pg in opt.param_groups] == g["group_wd"].tolist()
+    upd = OptimizerWarmupUpdater(3, 0.1, 0.8, 0.937)
+    fn = partial(sch_linear, max_epochs=300, lrf=0.01)
+    np.testing.assert_array_equal([fn(e) for e in (0, 1, 150, 299)], g["sch_linear"])
+    for st, lr, mom in zip(g["warmup_steps"], g["warmup_lr"], g["warmup_momentum"]):
+        upd(current_step=int(st), current_epoch=int(st) // 220, max_warmup_steps=660, sch_fn=fn, optimizer=opt)
+        np.testing.assert_array_equal([pg["lr"] for pg in opt.param_groups], lr)
+        np.testing.assert_array_equal([pg["momentum"] for pg in opt.param_groups], mom)
+    # samplers: class-aware covers classes uniformly; repeat factors follow the reference formula
+    torch.manual_seed(0)
+    cas = S.ClassAwareSampler([[0, 1, 2], [3], [4, 5]], 600)
+    idx = list(iter(cas))
+    assert len(idx) == 600 and cas.sampler_indices == idx
+    counts = np.bincount(idx, minlength=6)
+    assert abs(counts[3] - 200) <= 1 and abs(counts[:3].sum() - 200) <= 1
+    rf = S.image_repeat_factors([[0, 0, 1], [1], []], [30, 10], threshold=1.0, reduction=None)
+    r0, r1 = max(1.0, 1 / 0.75) ** 0.5, max(1.0, 1 / 0.25) ** 0.5
+    np.testing.assert_allclose(rf, [(2 * r0 + r1) / (3 + 1e-6), r1 / (1 + 1e-6), 0.0])
+    assert S.image_repeat_factors([[0, 1]], [30, 10], reduction="max") == [r1]
+    rs = S.RepeatFactorSampler([1.0, 2.0, 1.0, 4.0])
+    a = list(iter(rs))
+    rs2 = S.RepeatFactorSampler([1.0, 2.0, 1.0, 4.0])
+    assert a == list(iter(rs2)) and len(a) == 4
