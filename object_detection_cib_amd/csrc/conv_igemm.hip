@@ -21,6 +21,7 @@
 // registers and written once per block; block ids are laid out so the N tiles that share an M tile
 // land on the same XCD (same L2).
 #include "kodhip_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -43,13 +44,24 @@ struct ConvArgs {
   int head_A, head_P, head_nc;
   uint32_t magic_cin, magic_kw;
   int tiles_m, tiles_n, groups_m;
+  float rcp_hwo, rcp_wo;       // reciprocals for the row -> (b, oy, ox) decomposition (m < 2^24: one fix-up step)
+  uint32_t x_bytes, w_bytes;   // FAST path: byte extents of the gather source / weight pack (buffer descriptors)
 };
+
+// q = n / d, r = n % d via a float reciprocal + fix-up (exact: the loops absorb the fp32 rounding of large n)
+// instead of a 40-instruction integer divide
+__device__ __forceinline__ void fast_divmod(int n, int d, float rcp, int& q, int& r) {
+  q = (int)((float)n * rcp);
+  r = n - q * d;
+  while (r < 0) { --q; r += d; }
+  while (r >= d) { ++q; r -= d; }
+}
 
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDS_ROW = BK + 8;   // bf16 elements per staged row (80 bytes)
 
-template <int BN, int WAVES_M, int WAVES_N, int MODE>
+template <int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int WM = BM / WAVES_M;          // pixels per wave
   constexpr int WN = BN / WAVES_N;          // channels per wave
@@ -61,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int CS_ROW = BN + 8;            // epilogue staging row (bf16)
   constexpr int LDS_ELEMS = (2 * STAGE_ELEMS > BM * CS_ROW) ? 2 * STAGE_ELEMS : BM * CS_ROW;
   __shared__ __attribute__((aligned(16))) bf16_t lds[LDS_ELEMS];
-  __shared__ float sred[4 * BN * 2];
+  float* sred = reinterpret_cast<float*>(lds);     // BN partial statistics reuse the staging area after the tile loop
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,60 +101,122 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
 
   const int nk = a.Kp / BK;
+  // FAST path (Cin % 32 == 0, unit tap stride, no K tail): operands come through raw buffer loads - the tap of a
+  // K step is wave-uniform (scalar registers), invalid (padding) elements are fetched from an out-of-range offset
+  // that the buffer unit returns as zeros, so a step costs ~10 VALU instead of ~110 and has no branches.
+  __amdgpu_buffer_rsrc_t rs_x, rs_w;
+  if constexpr (FAST) {
+    rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  }
 
   for (int mt = gm; mt < a.tiles_m; mt += a.groups_m) {
     const int m0 = mt * BM;
-    // ---- per-thread gather rows
+    // ---- per-thread gather rows: base pointer + tap-validity bit mask, computed once per tile so the
+    //      K loop only adds a per-step tap offset (keeps the VALU out of the MFMA's way)
     int rbase[2], rby[2], rbx[2];
     bool rvalid[2];
+    const bf16_t* rptr[2];
+    uint32_t rmask[2];
+    const bool linear_taps = (a.sh_shift | a.sw_shift) == 0;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       int m = m0 + a_row + r * 64;
       rvalid[r] = m < a.M;
       int mm = rvalid[r] ? m : 0;
-      int b = mm / HWo;
-      int rem = mm - b * HWo;
-      int oy = rem / a.Wo;
-      int ox = rem - oy * a.Wo;
+      int b, rem, oy, ox;
+      fast_divmod(mm, HWo, a.rcp_hwo, b, rem);
+      fast_divmod(rem, a.Wo, a.rcp_wo, oy, ox);
       rbase[r] = b * HWs;
       rby[r] = oy * a.mul_h + a.add_h;
       rbx[r] = ox * a.mul_w + a.add_w;
+      rptr[r] = a.x + ((long)(rbase[r] + rby[r] * a.Ws + rbx[r]) * a.ldx + a.xcoff);
+      uint32_t xm = 0, mk = 0;
+      for (int kw = 0; kw < a.KW; ++kw)
+        if ((unsigned)(rbx[r] + a.tap_sign * kw) < (unsigned)a.Ws) xm |= 1u << kw;
+      for (int kh = 0; kh < a.KH; ++kh)
+        if ((unsigned)(rby[r] + a.tap_sign * kh) < (unsigned)a.Hs) mk |= xm << (kh * a.KW);
+      rmask[r] = rvalid[r] ? mk : 0u;
+    }
+    const bf16_t* bptr[B_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < B_PER_THREAD; ++q) {
+      int c = tid + q * 256;
+      int n = n0 + (c >> 2);
+      bptr[q] = (c < B_CHUNKS && n < a.N) ? a.w + (size_t)n * a.Kp + (c & 3) * 8 : nullptr;
+    }
+
+    uint32_t voff[2], bvoff[B_PER_THREAD];
+    int f_tap = 0, f_kh = 0, f_kw = 0, f_ci = 0;      // wave-uniform K-step state of the FAST path
+    if constexpr (FAST) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        voff[r] = (uint32_t)(((long)(rbase[r] + rby[r] * a.Ws + rbx[r]) * a.ldx + a.xcoff + a_chunk * 8) * 2);
+#pragma unroll
+      for (int q = 0; q < B_PER_THREAD; ++q) {
+        int c = tid + q * 256;
+        int n = n0 + (c >> 2);
+        bvoff[q] = (c < B_CHUNKS && n < a.N) ? (uint32_t)(((size_t)n * a.Kp + (c & 3) * 8) * 2) : 0xFFFFFFF0u;
+      }
     }
 
     u32x4 areg[2];
     u32x4 breg[B_PER_THREAD];
 
     auto load_tile = [&](int kt) {
+      if constexpr (FAST) {
+        const uint32_t soff = (uint32_t)((a.tap_sign * (f_kh * a.Ws + f_kw) * a.ldx + f_ci) * 2);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          uint32_t vo = ((rmask[r] >> f_tap) & 1u) ? voff[r] + soff : 0xFFFFFFF0u;
+          areg[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < B_PER_THREAD; ++q)
+          breg[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bvoff[q], kt * (BK * 2), 0);
+        f_ci += BK;
+        if (f_ci >= a.Cin) {
+          f_ci = 0; ++f_tap;
+          if (++f_kw == a.KW) { f_kw = 0; ++f_kh; }
+        }
+        return;
+      }
       const int k = kt * BK + a_chunk * 8;
       const uint32_t tap = __umulhi((uint32_t)k, a.magic_cin);
       const int ci = k - (int)tap * a.Cin;
       const uint32_t kh = (a.KW == 1) ? tap : __umulhi(tap, a.magic_kw);
       const int kw = (int)tap - (int)kh * a.KW;
       const bool kvalid = k < a.K;
+      if (linear_taps) {
+        const long toff = (long)(a.tap_sign * ((int)kh * a.Ws + kw)) * a.ldx + ci;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        int ty = rby[r] + a.tap_sign * (int)kh;
-        int tx = rbx[r] + a.tap_sign * kw;
-        bool ok = rvalid[r] && kvalid && ty >= 0 && tx >= 0 &&
-                  ((ty & ((1 << a.sh_shift) - 1)) == 0) && ((tx & ((1 << a.sw_shift) - 1)) == 0);
-        int iy = ty >> a.sh_shift;
-        int ix = tx >> a.sw_shift;
-        ok = ok && iy < a.Hs && ix < a.Ws;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) {
-          size_t off = (size_t)(rbase[r] + iy * a.Ws + ix) * a.ldx + a.xcoff + ci;
-          v = *reinterpret_cast<const u32x4*>(a.x + off);
+        for (int r = 0; r < 2; ++r) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (kvalid && ((rmask[r] >> tap) & 1u)) v = *reinterpret_cast<const u32x4*>(rptr[r] + toff);
+          areg[r] = v;
         }
-        areg[r] = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          int ty = rby[r] + a.tap_sign * (int)kh;
+          int tx = rbx[r] + a.tap_sign * kw;
+          bool ok = rvalid[r] && kvalid && ty >= 0 && tx >= 0 &&
+                    ((ty & ((1 << a.sh_shift) - 1)) == 0) && ((tx & ((1 << a.sw_shift) - 1)) == 0);
+          int iy = ty >> a.sh_shift;
+          int ix = tx >> a.sw_shift;
+          ok = ok && iy < a.Hs && ix < a.Ws;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (ok) {
+            size_t off = (size_t)(rbase[r] + iy * a.Ws + ix) * a.ldx + a.xcoff + ci;
+            v = *reinterpret_cast<const u32x4*>(a.x + off);
+          }
+          areg[r] = v;
+        }
       }
 #pragma unroll
       for (int q = 0; q < B_PER_THREAD; ++q) {
-        int c = tid + q * 256;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (c < B_CHUNKS) {
-          int n = n0 + (c >> 2);
-          if (n < a.N) v = *reinterpret_cast<const u32x4*>(a.w + (size_t)n * a.Kp + kt * BK + (c & 3) * 8);
-        }
+        if (bptr[q]) v = *reinterpret_cast<const u32x4*>(bptr[q] + kt * BK);
         breg[q] = v;
       }
     };
@@ -308,20 +382,53 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
+// resident blocks the chip holds for each tile width (LDS-limited: 40 / 30 / 25 KB per block of 160 KB, 256 CUs)
+int slots_for(int bn) { return bn == 128 ? 1024 : (bn == 64 ? 1280 : 1536); }
+
+// tile width: the widest tile that fits N, unless a narrower one removes a badly quantised last round
+// (e.g. 800 tiles on 768 resident blocks run two rounds; 1600 half-width tiles on 1280 run 1.25 -> 2 half rounds)
+int pick_bn(long M, int N) {
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("KODHIP_FORCE_BN"); force = e ? atoi(e) : 0; }
+  int widest = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
+  if (force && force <= widest) return force;
+  long tiles_m = (M + BM - 1) / BM;
+  int best = widest;
+  double best_cost = 1e30;
+  for (int bn = widest; bn >= 32 && bn >= widest / 2; bn >>= 1) {
+    long tiles = tiles_m * ((N + bn - 1) / bn);
+    long rounds = (tiles + slots_for(bn) - 1) / slots_for(bn);
+    double cost = (double)rounds * (128.0 + bn) / 256.0;       // per-round time ~ operand bytes staged per tile
+    if (cost < best_cost * 0.95) { best_cost = cost; best = bn; }
+  }
+  return best;
+}
+
 template <int MODE>
 int launch(const ConvArgs& a, hipStream_t stream) {
   ConvArgs args = a;
-  int bn = (a.N >= 128) ? 128 : (a.N > 32 ? 64 : 32);
+  int bn = pick_bn(a.M, a.N);
   args.tiles_n = cdiv(a.N, bn);
   args.tiles_m = cdiv(a.M, BM);
-  int target = 768 / args.tiles_n;
+  int target = slots_for(bn) / args.tiles_n;
   if (target < 8) target = 8;
   int gm = args.tiles_m < target ? args.tiles_m : target;
   args.groups_m = gm;
   int grid = cdiv(gm, 8) * 8 * args.tiles_n;
-  if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 2, MODE>), dim3(grid), dim3(256), 0, stream, args);
-  else if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, 2, 2, MODE>), dim3(grid), dim3(256), 0, stream, args);
-  else hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1, MODE>), dim3(grid), dim3(256), 0, stream, args);
+  const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, wb = (long)a.N * a.Kp * 2;
+  const bool fast = (a.Cin % 32 == 0) && (a.sh_shift | a.sw_shift) == 0 && a.K == a.Kp && xb < (1l << 32) - 64 &&
+                    wb < (1l << 32) - 64 && !getenv("KODHIP_NO_FAST");
+  args.x_bytes = (uint32_t)xb; args.w_bytes = (uint32_t)wb;
+  dim3 g(grid), b(256);
+  if (fast) {
+    if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 2, MODE, true>), g, b, 0, stream, args);
+    else if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, 2, 2, MODE, true>), g, b, 0, stream, args);
+    else hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1, MODE, true>), g, b, 0, stream, args);
+  } else {
+    if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 2, MODE, false>), g, b, 0, stream, args);
+    else if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, 2, 2, MODE, false>), g, b, 0, stream, args);
+    else hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1, MODE, false>), g, b, 0, stream, args);
+  }
   KOD_LAUNCH_CHECK("conv_igemm");
   return KOD_OK;
 }
@@ -335,10 +442,10 @@ extern "C" {
 // Number of per-channel partial slots the forward kernel writes: stats buffer must hold
 // 2 * N * kodhip_conv_stats_slots(M, N) floats.
 int kodhip_conv_stats_slots(long M, int N) {
-  int bn = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
+  int bn = pick_bn(M, N);
   int tiles_n = cdiv(N, bn);
   int tiles_m = cdiv(M, BM);
-  int target = 768 / tiles_n;
+  int target = slots_for(bn) / tiles_n;
   if (target < 8) target = 8;
   return tiles_m < target ? tiles_m : target;
 }
@@ -350,12 +457,14 @@ static int fill_common(ConvArgs& a, const void* x, const void* w, int B, int Hs,
   KOD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0, "conv: channels must be multiples of 8 (Cin=%d ldx=%d off=%d)", Cin, ldx, xcoff);
   KOD_CHECK_ARG(xcoff + Cin <= ldx, "conv: channel slice out of range");
   KOD_CHECK_ARG(Kp % 32 == 0 && Kp >= KH * KW * Cin, "conv: Kp=%d must be a multiple of 32 covering K=%d", Kp, KH * KW * Cin);
+  KOD_CHECK_ARG(KH * KW <= 32, "conv: at most 32 taps");
   KOD_CHECK_ARG((long)B * Hs * Ws < (1l << 31) / 1 && (long)B * Ho * Wo < (1l << 31), "conv: pixel count overflows int32");
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w;
   a.B = B; a.Hs = Hs; a.Ws = Ws; a.ldx = ldx; a.xcoff = xcoff; a.Cin = Cin;
   a.Ho = Ho; a.Wo = Wo; a.M = B * Ho * Wo; a.N = N; a.K = KH * KW * Cin; a.Kp = Kp; a.KH = KH; a.KW = KW;
   a.magic_cin = magic_u32((uint32_t)Cin); a.magic_kw = magic_u32((uint32_t)KW);
   a.out_mul = 1;
+  a.rcp_hwo = 1.0f / (float)(Ho * Wo); a.rcp_wo = 1.0f / (float)Wo;
   return KOD_OK;
 }
 
