@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkodhip.so")
+LIB_PATH = os.environ.get("KODHIP_LIB", os.path.join(_HERE, "libkodhip.so"))   # override: diagnostic builds
 
 vp, i32, i64, f32, f64, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint32
 

@@ -59,10 +59,14 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float rcp, int& q, int
 
 constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int LDS_ROW = BK + 8;   // bf16 elements per staged row (80 bytes)
 
+// launch bounds: 4 blocks per CU (one wave of each on every SIMD) => at most 128 VGPRs, so that one block's LDS /
+// global phases overlap another block's MFMA phase (measured: the phases of a single block do not overlap)
 template <int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_kernel(ConvArgs a) {
+  // staged row: generic path pads to 80 bytes (conflict-free b128 reads); the FAST path stages by LDS-DMA, whose
+  // image must be lane-linear (no padding) - conflicts are removed by an XOR swizzle applied on the SOURCE side
+  constexpr int LDS_ROW = FAST ? BK : BK + 8;
   constexpr int WM = BM / WAVES_M;          // pixels per wave
   constexpr int WN = BN / WAVES_N;          // channels per wave
   constexpr int TM = WM / 32;
@@ -146,41 +150,79 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       bptr[q] = (c < B_CHUNKS && n < a.N) ? a.w + (size_t)n * a.Kp + (c & 3) * 8 : nullptr;
     }
 
-    uint32_t voff[2], bvoff[B_PER_THREAD];
-    int f_tap = 0, f_kh = 0, f_kw = 0, f_ci = 0;      // wave-uniform K-step state of the FAST path
+    // FAST path: LDS-DMA staging.  One buffer_load..lds moves 64 lanes x 16 B = 16 rows x 64 B into a linear LDS
+    // block; wave w owns rows [32w, 32w+32) of the pixel tile (2 instructions) and its share of the weight tile.
+    // LDS slot (row, c') holds global chunk c = c' ^ ((row >> 2) & 3)  (the fragment reads undo the same XOR).
+    constexpr int B_INSTR = BN / 16;                  // weight-tile DMA instructions per K step (per block)
+    constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    uint32_t dvoff[2], dmask[2], dbvoff[B_PER_WAVE];
+    int f_tap = 0, f_kh = 0, f_kw = 0, f_ci = 0;      // wave-uniform K-step state
     if constexpr (FAST) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-        voff[r] = (uint32_t)(((long)(rbase[r] + rby[r] * a.Ws + rbx[r]) * a.ldx + a.xcoff + a_chunk * 8) * 2);
+      for (int i = 0; i < 2; ++i) {
+        int row = uwave * 32 + i * 16 + (lane >> 2);
+        int m = m0 + row;
+        bool valid = m < a.M;
+        int mm = valid ? m : 0;
+        int b, rem, oy, ox;
+        fast_divmod(mm, HWo, a.rcp_hwo, b, rem);
+        fast_divmod(rem, a.Wo, a.rcp_wo, oy, ox);
+        int by = oy * a.mul_h + a.add_h, bx = ox * a.mul_w + a.add_w;
+        int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        dvoff[i] = (uint32_t)(((long)(b * HWs + by * a.Ws + bx) * a.ldx + a.xcoff + chunk * 8) * 2);
+        uint32_t xm = 0, mk = 0;
+        for (int kw = 0; kw < a.KW; ++kw)
+          if ((unsigned)(bx + a.tap_sign * kw) < (unsigned)a.Ws) xm |= 1u << kw;
+        for (int kh = 0; kh < a.KH; ++kh)
+          if ((unsigned)(by + a.tap_sign * kh) < (unsigned)a.Hs) mk |= xm << (kh * a.KW);
+        dmask[i] = valid ? mk : 0u;
+      }
 #pragma unroll
-      for (int q = 0; q < B_PER_THREAD; ++q) {
-        int c = tid + q * 256;
-        int n = n0 + (c >> 2);
-        bvoff[q] = (c < B_CHUNKS && n < a.N) ? (uint32_t)(((size_t)n * a.Kp + (c & 3) * 8) * 2) : 0xFFFFFFF0u;
+      for (int q = 0; q < B_PER_WAVE; ++q) {
+        int row = (uwave * B_PER_WAVE + q) * 16 + (lane >> 2);
+        int n = n0 + row;
+        int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        dbvoff[q] = (row < BN && n < a.N) ? (uint32_t)(((size_t)n * a.Kp + chunk * 8) * 2) : 0xFFFFFFF0u;
       }
     }
+    auto dma_tile = [&](int kt, int buf) {
+      const uint32_t soff = (uint32_t)((a.tap_sign * (f_kh * a.Ws + f_kw) * a.ldx + f_ci) * 2);
+      char* As = reinterpret_cast<char*>(lds + buf * STAGE_ELEMS);
+      char* Bs = As + BM * LDS_ROW * 2;
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the kernel's stub, not these device builtins)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        uint32_t vo = ((dmask[i] >> f_tap) & 1u) ? dvoff[i] + soff : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(As + (uwave * 32 + i * 16) * 64),
+                                                 16, vo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < B_PER_WAVE; ++q) {
+        int blk = uwave * B_PER_WAVE + q;
+        if (blk < B_INSTR)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Bs + blk * 16 * 64),
+                                                   16, dbvoff[q], kt * (BK * 2), 0, 0);
+      }
+#else
+      (void)soff; (void)As; (void)Bs; (void)kt;
+#endif
+      f_ci += BK;
+      if (f_ci >= a.Cin) {
+        f_ci = 0; ++f_tap;
+        if (++f_kw == a.KW) { f_kw = 0; ++f_kh; }
+      }
+    };
 
     u32x4 areg[2];
     u32x4 breg[B_PER_THREAD];
 
     auto load_tile = [&](int kt) {
-      if constexpr (FAST) {
-        const uint32_t soff = (uint32_t)((a.tap_sign * (f_kh * a.Ws + f_kw) * a.ldx + f_ci) * 2);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          uint32_t vo = ((rmask[r] >> f_tap) & 1u) ? voff[r] + soff : 0xFFFFFFF0u;
-          areg[r] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < B_PER_THREAD; ++q)
-          breg[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, bvoff[q], kt * (BK * 2), 0);
-        f_ci += BK;
-        if (f_ci >= a.Cin) {
-          f_ci = 0; ++f_tap;
-          if (++f_kw == a.KW) { f_kw = 0; ++f_kh; }
-        }
-        return;
-      }
+#ifdef KOD_ABL_NOGLOAD
+      for (int r = 0; r < 2; ++r) areg[r] = u32x4{0u, 0u, 0u, 0u};
+      for (int q = 0; q < B_PER_THREAD; ++q) breg[q] = u32x4{0u, 0u, 0u, 0u};
+      return;
+#endif
       const int k = kt * BK + a_chunk * 8;
       const uint32_t tap = __umulhi((uint32_t)k, a.magic_cin);
       const int ci = k - (int)tap * a.Cin;
@@ -221,6 +263,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
     };
     auto store_tile = [&](int buf) {
+#ifdef KOD_ABL_NOLDSWRITE
+      return;
+#endif
       bf16_t* As = lds + buf * STAGE_ELEMS;
       bf16_t* Bs = As + BM * LDS_ROW;
 #pragma unroll
@@ -241,33 +286,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
+    if constexpr (FAST) {
+      dma_tile(0, 0);
+    } else {
+      load_tile(0);
+      store_tile(0);
+    }
     __syncthreads();
 
     const int fr = lane & 31;
     const int fh = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
-      if (kt + 1 < nk) load_tile(kt + 1);
+      if (kt + 1 < nk) {
+        if constexpr (FAST) dma_tile(kt + 1, buf ^ 1); else load_tile(kt + 1);
+      }
       const bf16_t* As = lds + buf * STAGE_ELEMS;
       const bf16_t* Bs = As + BM * LDS_ROW;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 wf[TN], xf[TM];
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
-          wf[i] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WN + i * 32 + fr) * LDS_ROW + ks * 16 + fh * 8);
+#ifdef KOD_ABL_NODSREAD
+        for (int i = 0; i < TN; ++i) { wf[i] = bf16x8{}; asm volatile("" : "+v"(wf[i])); }
+        for (int jj = 0; jj < TM; ++jj) { xf[jj] = bf16x8{}; asm volatile("" : "+v"(xf[jj])); }
+#else
+        for (int i = 0; i < TN; ++i) {
+          int row = wn * WN + i * 32 + fr;
+          int ch = FAST ? ((ks * 2 + fh) ^ ((row >> 2) & 3)) : (ks * 2 + fh);
+          wf[i] = *reinterpret_cast<const bf16x8*>(Bs + row * LDS_ROW + ch * 8);
+        }
 #pragma unroll
-        for (int jj = 0; jj < TM; ++jj)
-          xf[jj] = *reinterpret_cast<const bf16x8*>(As + (wm * WM + jj * 32 + fr) * LDS_ROW + ks * 16 + fh * 8);
+        for (int jj = 0; jj < TM; ++jj) {
+          int row = wm * WM + jj * 32 + fr;
+          int ch = FAST ? ((ks * 2 + fh) ^ ((row >> 2) & 3)) : (ks * 2 + fh);
+          xf[jj] = *reinterpret_cast<const bf16x8*>(As + row * LDS_ROW + ch * 8);
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int jj = 0; jj < TM; ++jj)
+#ifdef KOD_ABL_NOMFMA
+            asm volatile("" :: "v"(wf[i]), "v"(xf[jj]));
+#else
             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[jj], acc[i][jj], 0, 0, 0);
+#endif
       }
-      if (kt + 1 < nk) store_tile(buf ^ 1);
+      if constexpr (!FAST) { if (kt + 1 < nk) store_tile(buf ^ 1); }
       __syncthreads();
     }
 
