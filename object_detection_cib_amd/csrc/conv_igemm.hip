@@ -43,7 +43,7 @@ struct ConvArgs {
   int out_mul, out_off_y, out_off_x, out_H, out_W;   // PLAIN: output pixel (oy,ox) -> (oy*mul+off_y, ox*mul+off_x) of an out_H x out_W image
   int head_A, head_P, head_nc;
   uint32_t magic_cin, magic_kw;
-  int tiles_m, tiles_n, groups_m;
+  int tiles_m, tiles_n, groups_m, stats_slots;
   float rcp_hwo, rcp_wo;       // reciprocals for the row -> (b, oy, ox) decomposition (m < 2^24: one fix-up step)
   uint32_t x_bytes, w_bytes;   // FAST path: byte extents of the gather source / weight pack (buffer descriptors)
 };
@@ -57,13 +57,16 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float rcp, int& q, int
   while (r >= d) { ++q; r -= d; }
 }
 
-constexpr int BM = 128;
 constexpr int BK = 32;
 
 // launch bounds: 4 blocks per CU (one wave of each on every SIMD) => at most 128 VGPRs, so that one block's LDS /
 // global phases overlap another block's MFMA phase (measured: the phases of a single block do not overlap)
-template <int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
-__global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_kernel(ConvArgs a) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ || WAVES_M * WAVES_N > 4 ? 2 : (FAST ? 4 : 3)))
+void conv_igemm_kernel(ConvArgs a) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int NW = NT / 64;
+  static_assert(FAST || (BM == 128 && NT == 256), "register-staged path is written for 128-row tiles / 4 waves");
   // staged row: generic path pads to 80 bytes (conflict-free b128 reads); the FAST path stages by LDS-DMA, whose
   // image must be lane-linear (no padding) - conflicts are removed by an XOR swizzle applied on the SOURCE side
   constexpr int LDS_ROW = FAST ? BK : BK + 8;
@@ -72,10 +75,13 @@ __global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_
   constexpr int TM = WM / 32;
   constexpr int TN = WN / 32;
   constexpr int B_CHUNKS = BN * 4;          // 16-byte chunks in the weight tile
-  constexpr int B_PER_THREAD = (B_CHUNKS + 255) / 256;
+  constexpr int B_PER_THREAD = (B_CHUNKS + NT - 1) / NT;
   constexpr int STAGE_ELEMS = (BM + BN) * LDS_ROW;
   constexpr int CS_ROW = BN + 8;            // epilogue staging row (bf16)
-  constexpr int LDS_ELEMS = (2 * STAGE_ELEMS > BM * CS_ROW) ? 2 * STAGE_ELEMS : BM * CS_ROW;
+  // LDS stages: 256-row tiles (2 blocks per CU) keep two K tiles in flight behind the one computed; 128-row tiles
+  // keep one, so that four blocks fit a CU and hide each other's fill latency instead
+  constexpr int NST = (FAST && BM == 256) ? 3 : 2;
+  constexpr int LDS_ELEMS = (NST * STAGE_ELEMS > BM * CS_ROW) ? NST * STAGE_ELEMS : BM * CS_ROW;
   __shared__ __attribute__((aligned(16))) bf16_t lds[LDS_ELEMS];
   float* sred = reinterpret_cast<float*>(lds);     // BN partial statistics reuse the staging area after the tile loop
 
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_
     const bf16_t* bptr[B_PER_THREAD];
 #pragma unroll
     for (int q = 0; q < B_PER_THREAD; ++q) {
-      int c = tid + q * 256;
+      int c = tid + q * NT;
       int n = n0 + (c >> 2);
       bptr[q] = (c < B_CHUNKS && n < a.N) ? a.w + (size_t)n * a.Kp + (c & 3) * 8 : nullptr;
     }
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_
     // block; wave w owns rows [32w, 32w+32) of the pixel tile (2 instructions) and its share of the weight tile.
     // LDS slot (row, c') holds global chunk c = c' ^ ((row >> 2) & 3)  (the fragment reads undo the same XOR).
     constexpr int B_INSTR = BN / 16;                  // weight-tile DMA instructions per K step (per block)
-    constexpr int B_PER_WAVE = (B_INSTR + 3) / 4;
+    constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     uint32_t dvoff[2], dmask[2], dbvoff[B_PER_WAVE];
     int f_tap = 0, f_kh = 0, f_kw = 0, f_ci = 0;      // wave-uniform K-step state
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_
       const uint32_t soff = (uint32_t)((a.tap_sign * (f_kh * a.Ws + f_kw) * a.ldx + f_ci) * 2);
       char* As = reinterpret_cast<char*>(lds + buf * STAGE_ELEMS);
       char* Bs = As + BM * LDS_ROW * 2;
-#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the kernel's stub, not these device builtins)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KOD_ABL_NODMA)   // (the host pass only needs the kernel's stub)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         uint32_t vo = ((dmask[i] >> f_tap) & 1u) ? dvoff[i] + soff : 0xFFFFFFF0u;
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_
         *reinterpret_cast<u32x4*>(As + (a_row + r * 64) * LDS_ROW + a_chunk * 8) = areg[r];
 #pragma unroll
       for (int q = 0; q < B_PER_THREAD; ++q) {
-        int c = tid + q * 256;
+        int c = tid + q * NT;
         if (c < B_CHUNKS) *reinterpret_cast<u32x4*>(Bs + (c >> 2) * LDS_ROW + (c & 3) * 8) = breg[q];
       }
     };
@@ -286,31 +292,19 @@ __global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
 
-    if constexpr (FAST) {
-      dma_tile(0, 0);
-    } else {
-      load_tile(0);
-      store_tile(0);
-    }
-    __syncthreads();
-
     const int fr = lane & 31;
     const int fh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) {
-        if constexpr (FAST) dma_tile(kt + 1, buf ^ 1); else load_tile(kt + 1);
-      }
-      const bf16_t* As = lds + buf * STAGE_ELEMS;
+    auto compute = [&](int stage) {
+      const bf16_t* As = lds + stage * STAGE_ELEMS;
       const bf16_t* Bs = As + BM * LDS_ROW;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 wf[TN], xf[TM];
-#pragma unroll
 #ifdef KOD_ABL_NODSREAD
         for (int i = 0; i < TN; ++i) { wf[i] = bf16x8{}; asm volatile("" : "+v"(wf[i])); }
         for (int jj = 0; jj < TM; ++jj) { xf[jj] = bf16x8{}; asm volatile("" : "+v"(xf[jj])); }
 #else
+#pragma unroll
         for (int i = 0; i < TN; ++i) {
           int row = wn * WN + i * 32 + fr;
           int ch = FAST ? ((ks * 2 + fh) ^ ((row >> 2) & 3)) : (ks * 2 + fh);
@@ -333,8 +327,40 @@ __global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_
             acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[jj], acc[i][jj], 0, 0, 0);
 #endif
       }
-      if constexpr (!FAST) { if (kt + 1 < nk) store_tile(buf ^ 1); }
+    };
+
+    if constexpr (FAST) {
+      // LDS ring fed by LDS-DMA: while tile kt is multiplied, tiles kt+1 .. kt+NST-2 are in flight.  A wave's DMAs
+      // retire in order, so "all but the newer tiles' instructions" is a counted vmcnt; the raw s_barrier then
+      // publishes every wave's share of tile kt (and fences the stage that tile kt+NST-1 overwrites: it was last
+      // read in step kt-1, which every wave has left once it reaches this barrier).
+      const int my_b = (uwave * B_PER_WAVE < B_INSTR) ? ((B_INSTR - uwave * B_PER_WAVE) < B_PER_WAVE ? (B_INSTR - uwave * B_PER_WAVE) : B_PER_WAVE) : 0;
+      dma_tile(0, 0);
+      if (NST == 3 && nk > 1) dma_tile(1, 1);
+      for (int kt = 0; kt < nk; ++kt) {
+        if (NST == 3 && kt + 1 < nk) {
+          if (my_b == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else if (my_b == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + NST - 1 < nk) dma_tile(kt + NST - 1, (kt + NST - 1) % NST);
+        compute(kt % NST);
+      }
       __syncthreads();
+    } else {
+      load_tile(0);
+      store_tile(0);
+      __syncthreads();
+      for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        compute(buf);
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+      }
     }
 
     // ---- epilogue.  acc[i][jj][e]: pixel = wm*WM + jj*32 + (lane&31),
@@ -376,7 +402,7 @@ __global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_
           }
       __syncthreads();
       constexpr int CPR = BN / 8;            // 16-byte chunks per row
-      constexpr int RPP = 256 / CPR;         // rows per pass
+      constexpr int RPP = NT / CPR;          // rows per pass
       const int c = tid % CPR;
       const int r0 = tid / CPR;
       const int n = n0 + c * 8;
@@ -441,31 +467,57 @@ __global__ __launch_bounds__(256, (MODE == 2 /*HEAD*/ ? 2 : 4)) void conv_igemm_
       // thread t handles chunk t % CPR, so every wave holds every chunk (CPR <= 64).
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) s += sred[(w * BN + ch) * 2 + st];
+      for (int w = 0; w < NW; ++w) s += sred[(w * BN + ch) * 2 + st];
       int nn = n0 + ch;
-      if (nn < a.N) a.stats[((size_t)st * a.N + nn) * a.groups_m + gm] = s;
+      if (nn < a.N) {
+        float* slot = a.stats + ((size_t)st * a.N + nn) * a.stats_slots;
+        slot[gm] = s;
+        for (int t = gm + a.groups_m; t < a.stats_slots; t += a.groups_m) slot[t] = 0.f;   // slots this launch does not use
+      }
     }
   }
 }
 
-// resident blocks the chip holds for each tile width (LDS-limited: 40 / 30 / 25 KB per block of 160 KB, 256 CUs)
-int slots_for(int bn) { return bn == 128 ? 1024 : (bn == 64 ? 1280 : 1536); }
+// ---- launch planning --------------------------------------------------------------------------------
+// Resident blocks per chip (256 CUs) for each tile shape (FAST path: register-bound at 4 x 4 waves or 2 x 8 waves
+// per CU; register-staged path: LDS-bound, 2 stages of (128+BN)*80 B).
+struct Plan { int bm, bn, groups_m, tiles_m, tiles_n, grid; };
 
-// tile width: the widest tile that fits N, unless a narrower one removes a badly quantised last round
-// (e.g. 800 tiles on 768 resident blocks run two rounds; 1600 half-width tiles on 1280 run 1.25 -> 2 half rounds)
-int pick_bn(long M, int N) {
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("KODHIP_FORCE_BN"); force = e ? atoi(e) : 0; }
-  int widest = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
-  if (force && force <= widest) return force;
-  long tiles_m = (M + BM - 1) / BM;
-  int best = widest;
+int slots_for(int bm, int bn, bool fast) {
+  if (bm == 256) return 512;
+  if (fast) return 1024;                        // 4 blocks per CU (128-VGPR launch bound)
+  return bn == 128 ? 1024 : (bn == 64 ? 1280 : 1536);
+}
+
+constexpr int MAX_STATS_SLOTS = 1024;
+
+// Tile shape: the widest channel tile that fits N (or the next narrower one when that removes a badly quantised
+// last round).  256-pixel tiles (8 waves, 3-stage ring) when the reduction is long enough to amortise their deeper
+// pipeline fill (measured on gfx950: 3x3 layers with N >= 128 gain 15-25 %, short-K 1x1 layers lose ~5 %).
+Plan make_plan(long M, int N, int K, bool fast) {
+  static int force_bn = -1, force_bm = -1;
+  if (force_bn < 0) { const char* e = getenv("KODHIP_FORCE_BN"); force_bn = e ? atoi(e) : 0; }
+  if (force_bm < 0) { const char* e = getenv("KODHIP_FORCE_BM"); force_bm = e ? atoi(e) : 0; }
+  const int widest = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
+  const bool can256 = fast && widest == 128 && M >= 256 * 64;
+  const int bm = can256 && (force_bm ? force_bm == 256 : K >= 512) ? 256 : 128;
+  Plan best = {};
   double best_cost = 1e30;
   for (int bn = widest; bn >= 32 && bn >= widest / 2; bn >>= 1) {
-    long tiles = tiles_m * ((N + bn - 1) / bn);
-    long rounds = (tiles + slots_for(bn) - 1) / slots_for(bn);
-    double cost = (double)rounds * (128.0 + bn) / 256.0;       // per-round time ~ operand bytes staged per tile
-    if (cost < best_cost * 0.95) { best_cost = cost; best = bn; }
+    if (bm == 256 && bn != 128) continue;
+    if (force_bn && force_bn <= widest && bn != force_bn) continue;
+    long tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
+    int slots = slots_for(bm, bn, fast);
+    long rounds = (tiles_m * tiles_n + slots - 1) / slots;
+    double cost = (double)rounds * (bm + bn);       // per-round time ~ operand bytes staged per tile
+    if (cost < best_cost * 0.97) {
+      best_cost = cost;
+      int target = slots / (int)tiles_n;
+      if (target < 8) target = 8;
+      if (target > MAX_STATS_SLOTS) target = MAX_STATS_SLOTS;
+      int gm = tiles_m < target ? (int)tiles_m : target;
+      best = {bm, bn, gm, (int)tiles_m, (int)tiles_n, cdiv(gm, 8) * 8 * (int)tiles_n};
+    }
   }
   return best;
 }
@@ -473,27 +525,25 @@ int pick_bn(long M, int N) {
 template <int MODE>
 int launch(const ConvArgs& a, hipStream_t stream) {
   ConvArgs args = a;
-  int bn = pick_bn(a.M, a.N);
-  args.tiles_n = cdiv(a.N, bn);
-  args.tiles_m = cdiv(a.M, BM);
-  int target = slots_for(bn) / args.tiles_n;
-  if (target < 8) target = 8;
-  int gm = args.tiles_m < target ? args.tiles_m : target;
-  args.groups_m = gm;
-  int grid = cdiv(gm, 8) * 8 * args.tiles_n;
   const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, wb = (long)a.N * a.Kp * 2;
   const bool fast = (a.Cin % 32 == 0) && (a.sh_shift | a.sw_shift) == 0 && a.K == a.Kp && xb < (1l << 32) - 64 &&
                     wb < (1l << 32) - 64 && !getenv("KODHIP_NO_FAST");
   args.x_bytes = (uint32_t)xb; args.w_bytes = (uint32_t)wb;
-  dim3 g(grid), b(256);
+  const Plan p = make_plan(a.M, a.N, a.K, fast);
+  args.tiles_n = p.tiles_n; args.tiles_m = p.tiles_m; args.groups_m = p.groups_m;
+  if (MODE == MODE_RAW) {
+    KOD_CHECK_ARG(a.stats_slots >= p.groups_m, "conv: stats buffer has %d slots, launch needs %d", a.stats_slots, p.groups_m);
+  }
+  dim3 g(p.grid);
   if (fast) {
-    if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 2, MODE, true>), g, b, 0, stream, args);
-    else if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, 2, 2, MODE, true>), g, b, 0, stream, args);
-    else hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1, MODE, true>), g, b, 0, stream, args);
+    if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
+    else if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE, true>), g, dim3(256), 0, stream, args);
+    else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE, true>), g, dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, args);
   } else {
-    if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 2, MODE, false>), g, b, 0, stream, args);
-    else if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, 2, 2, MODE, false>), g, b, 0, stream, args);
-    else hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1, MODE, false>), g, b, 0, stream, args);
+    if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE, false>), g, dim3(256), 0, stream, args);
+    else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE, false>), g, dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, MODE, false>), g, dim3(256), 0, stream, args);
   }
   KOD_LAUNCH_CHECK("conv_igemm");
   return KOD_OK;
@@ -505,15 +555,12 @@ int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) =
 
 extern "C" {
 
-// Number of per-channel partial slots the forward kernel writes: stats buffer must hold
-// 2 * N * kodhip_conv_stats_slots(M, N) floats.
+// Per-channel partial slots of the statistics buffer: it must hold 2 * N * kodhip_conv_stats_slots(M, N) floats;
+// the kernel fills the slots it uses and zeroes the rest.
 int kodhip_conv_stats_slots(long M, int N) {
-  int bn = pick_bn(M, N);
-  int tiles_n = cdiv(N, bn);
-  int tiles_m = cdiv(M, BM);
-  int target = slots_for(bn) / tiles_n;
-  if (target < 8) target = 8;
-  return tiles_m < target ? tiles_m : target;
+  long tiles_m = (M + 127) / 128;                  // upper bound over every tile shape the launcher may pick
+  (void)N;
+  return tiles_m < MAX_STATS_SLOTS ? (int)tiles_m : MAX_STATS_SLOTS;
 }
 
 static int fill_common(ConvArgs& a, const void* x, const void* w, int B, int Hs, int Ws, int ldx, int xcoff,
@@ -546,6 +593,7 @@ int kodhip_conv_fwd_raw(const void* x, const void* w_packed, void* y, float* sta
   KOD_CHECK_ARG(y && stats, "conv_fwd_raw: null output");
   KOD_CHECK_ARG(N % 8 == 0 && ldy % 8 == 0 && ycoff % 8 == 0 && ycoff + N <= ldy, "conv_fwd_raw: bad output slice");
   a.y = (bf16_t*)y; a.stats = stats; a.ldy = ldy; a.ycoff = ycoff;
+  a.stats_slots = kodhip_conv_stats_slots(a.M, N);
   a.mul_h = SH; a.mul_w = SW; a.add_h = -PH; a.add_w = -PW; a.tap_sign = 1; a.sh_shift = 0; a.sw_shift = 0;
   return launch<MODE_RAW>(a, stream);
 }

@@ -31,6 +31,8 @@ CONV_CASES = [
     (1, 128, 10, 10, 128, 3, 2, 1),
     (3, 48, 9, 7, 96, 3, 1, 1),          # yv5m-like channel counts, odd spatial dims
     (1, 512, 4, 4, 512, 1, 1, 0),
+    (5, 64, 60, 56, 160, 3, 1, 1),       # M = 16800, K = 576: the 256-pixel-tile / 3-stage-ring configuration, ragged M and N
+    (4, 128, 64, 64, 128, 3, 2, 1),      # same configuration through the stride-2 forward and its parity-class dgrad
 ]
 
 
