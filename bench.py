@@ -99,17 +99,22 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # KODHIP_FORCE_COLLECTIVES=1: rehearse the N>1 code path (RCCL group, SyncBN sums, gradient buckets) on one GPU
+    use_dist = world > 1 or os.environ.get("KODHIP_FORCE_COLLECTIVES") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # control plane (rendezvous id, barriers, max-over-ranks of the clock) on gloo; every GPU collective of the
+        # step goes through the engine's own RCCL communicator, enqueued on the step's streams and captured with it
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     nc, B, S = 10, args.batch, args.size
     net, loss_fn = build(nc, device)
     eng = net.engine()
-    if world > 1:
-        net.configure_distributed(None, sync_batchnorm=not args.no_sync_bn)
+    if use_dist:
+        net.configure_distributed(None, sync_batchnorm=not args.no_sync_bn, native_rccl=True)
     from object_detection_cib_amd.core.types import FeatureShape
     x, targets = synth_batch(B, S, nc, 2023 + rank, device)
     shape = FeatureShape(width=S, height=S)
@@ -132,11 +137,12 @@ def main():
         return total
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not args.no_graph
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -144,13 +150,26 @@ def main():
             last = step()
     torch.cuda.current_stream().wait_stream(side)
     graph = None
+    launch_note = "eager"
     if use_graph:
-        # the whole step (~650 launches) becomes one hipGraph
+        # the whole step (~650 launches, and for N>1 the RCCL all-reduces between them) becomes one hipGraph
         barrier()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            last = step()
-        graph.replay()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                last = step()
+            graph.replay()
+            launch_note = "hipGraph replay"
+        except Exception as e:      # capture refused (e.g. a collective that cannot be captured): run eagerly, say so
+            if not use_dist:
+                raise
+            graph = None
+            torch.cuda.synchronize()
+            eng._pending = []
+            launch_note = f"eager (graph capture failed: {type(e).__name__})"
+            print(f"[bench rank {rank}] hipGraph capture failed, running eagerly: {e}", file=sys.stderr, flush=True)
+            for _ in range(2):
+                last = step()
     barrier()
     if graph is None:
         eng.profile = []
@@ -174,7 +193,7 @@ def main():
         prof = eng.profile
         eng.profile = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(last.item())
@@ -193,8 +212,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "yv5s coco-zipf-like synthetic, 640px, bf16 storage/fp32 accumulate, "
                                    f"batch {B}/GPU, fwd+assign+loss+bwd+SGD, targets 4-30 boxes/img",
-                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if world > 1 and not args.no_sync_bn else ""),
-                       "launch": "hipGraph replay" if graph is not None else "eager"},
+                       "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if use_dist and not args.no_sync_bn else ""),
+                       "launch": launch_note, "collectives": ("RCCL, native in-stream" if use_dist else "none")},
             "final_loss": final_loss,
             "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_img": ALGO_BYTES_PER_IMG_BF16,
                               "achieved": round(ips / world * ALGO_BYTES_PER_IMG_BF16 / 1e9, 1), "peak": HBM_PEAK / 1e9,
@@ -211,6 +230,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
+        if eng.comm is not None:
+            eng.comm.close()
         dist.destroy_process_group()
 
 

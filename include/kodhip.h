@@ -154,6 +154,16 @@ int kodhip_map_match(const float* det, const int* ndet, const double* gt_boxes, 
                      const int* gt_start, void* tp, void* counted, int B, int max_det, int nc,
                      const double* iou_thresholds /* host */, int T, int max_per_class, kodStream_t stream);
 
+/* ---- data-parallel collectives (Lightning strategy=ddp + sync_batchnorm=True, kod/configs/trainer/ddp.yaml:4-9:
+ *      torch DistributedDataParallel's bucketed gradient all-reduce, SyncBatchNorm's statistic exchange and the
+ *      initial parameter/buffer broadcast).  RCCL enqueued on the caller's stream; hipGraph-capturable. ------ */
+int kodhip_comm_load(const char* rccl_path /* NULL: the copy already loaded in the process */);
+int kodhip_comm_unique_id(void* id128 /* host, 128 bytes out */);
+int kodhip_comm_init(void** comm, const void* id128, int rank, int world);
+int kodhip_comm_destroy(void* comm);
+int kodhip_comm_allreduce_sum(void* comm, void* buf, long count, int elem_bytes /* 4: fp32, 8: fp64 */, kodStream_t stream);
+int kodhip_comm_broadcast(void* comm, void* buf, long bytes, int root, kodStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,12 @@ SIGNATURES = {
     "kodhip_head_bwd_prep": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "kodhip_sgd_nesterov": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "kodhip_fill_u32": (i32, [vp, u32, i64, vp]),
+    "kodhip_comm_load": (i32, [C.c_char_p]),
+    "kodhip_comm_unique_id": (i32, [vp]),
+    "kodhip_comm_init": (i32, [C.POINTER(vp), vp, i32, i32]),
+    "kodhip_comm_destroy": (i32, [vp]),
+    "kodhip_comm_allreduce_sum": (i32, [vp, vp, i64, i32, vp]),
+    "kodhip_comm_broadcast": (i32, [vp, vp, i64, i32, vp]),
     "kodhip_compose_desc_bytes": (i32, []),
     "kodhip_compose_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_decode": (i32, [C.POINTER(KodDecodeLevel), vp, i32, i32, i32, vp]),

@@ -28,8 +28,32 @@ def plan_buckets(unit_starts: Sequence[int], n_arena: int, bucket_elems: int) ->
     return out
 
 
-def launch_bucket(flat: torch.Tensor, lo: int, hi: int, group=None):
-    """Async sum all-reduce of a contiguous arena slice (RCCL on GPU tensors, gloo in tests)."""
+class _Joined:
+    """Handle of a bucket all-reduce issued on a side stream: wait() makes the current stream depend on it."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+def launch_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, stream=None, comm=None):
+    """Sum all-reduce of a contiguous arena slice, overlapped with the caller's stream.
+
+    On the GPU the collective goes on a side stream that first waits for the caller's stream - the dependency
+    lives in stream order only, so the same code is hipGraph-capturable - through the native RCCL communicator
+    `comm` (engine/comm.py), or synchronously through torch.distributed when there is none (gloo-backed GPU
+    tests).  CPU tensors (host-logic tests): a plain async_op Work."""
+    if flat.is_cuda and stream is not None:
+        stream.wait_stream(torch.cuda.current_stream())
+        if comm is not None:
+            comm.all_reduce(flat[lo:hi], stream.cuda_stream)
+        else:
+            with torch.cuda.stream(stream):
+                torch.distributed.all_reduce(flat[lo:hi], group=group)
+        return _Joined(stream)
     return torch.distributed.all_reduce(flat[lo:hi], group=group, async_op=True)
 
 

@@ -47,6 +47,9 @@ class Engine:
         self.sync_bn = False
         self.process_group = None
         self.world_size = 1
+        self.comm = None               # RcclComm when the process group is RCCL-backed (the product path)
+        self.comm_stream = None        # side stream of the gradient-bucket all-reduces
+        self.collectives = False       # True when gradients / BN sums go through the process group (world > 1)
         self.bucket_bytes = 8 << 20
         self._pending = []
         self._packed_version = -1
@@ -254,8 +257,11 @@ class Engine:
         self._packed_version = self.param_version
 
     def _allreduce(self, t):
-        if self.world_size > 1:
-            torch.distributed.all_reduce(t, group=self.process_group)
+        if self.collectives:
+            if self.comm is not None:
+                self.comm.all_reduce(t)
+            else:
+                torch.distributed.all_reduce(t, group=self.process_group)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, training: bool = True):
@@ -292,7 +298,7 @@ class Engine:
                     in_px = B * H * W if u.stem else B * st.H * st.W
                     self.profile.append((e0, e1, 2 * (in_px * cin_true + st.M * C_)))
                 aff = st.aff.data_ptr()
-                if training and not (self.sync_bn and self.world_size > 1):
+                if training and not (self.sync_bn and self.collectives):
                     chk(lib.kodhip_bn_finalize_partials(st.stats.data_ptr(), st.T, float(st.M), pa + 4 * st.g_off,
                                                         pa + 4 * st.b_off, self.rm_arena.data_ptr() + 4 * st.rs_off,
                                                         self.rv_arena.data_ptr() + 4 * st.rs_off, BN_MOMENTUM, BN_EPS,
@@ -375,7 +381,7 @@ class Engine:
 
         self._pending = []
         buckets = {}
-        if self.world_size > 1:
+        if self.collectives:
             buckets = {trig: (lo, hi) for trig, lo, hi in plan_buckets(self.unit_starts, self.n_arena,
                                                                         max(self.bucket_bytes // 4, 1))}
         unit_i = len(self.unit_starts)
@@ -423,7 +429,7 @@ class Engine:
                 chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
                                                   aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
                                                   st.bpart.data_ptr(), st.M, C_, s), u.name)
-                if self.sync_bn and self.world_size > 1:
+                if self.sync_bn and self.collectives:
                     chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), C_, st.T2, s), u.name)
                     st.bsums_g.copy_(st.bsums)
                     self._allreduce(st.bsums_g)
@@ -460,8 +466,13 @@ class Engine:
                 unit_i -= 1
                 if unit_i in buckets:
                     lo, hi = buckets[unit_i]
-                    self._pending.append(launch_bucket(ga, lo, hi, self.process_group))
+                    self._pending.append(launch_bucket(ga, lo, hi, self.process_group, self._comm_stream(), self.comm))
         self._publish_grads()
+
+    def _comm_stream(self):
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+        return self.comm_stream
 
     def wait_grads(self):
         for w in self._pending:

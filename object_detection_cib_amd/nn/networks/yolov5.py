@@ -12,6 +12,8 @@ import math
 from functools import partial
 from typing import Callable, NamedTuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -107,20 +109,35 @@ class Yolov5Network(nn.Module):
             self._engine, self._engine_device = eng, dev
         return self._engine
 
-    def configure_distributed(self, process_group=None, sync_batchnorm: bool = True, bucket_mb: float = 8.0):
+    def configure_distributed(self, process_group=None, sync_batchnorm: bool = True, bucket_mb: float = 8.0,
+                              native_rccl: bool | None = None):
         """Data-parallel mode: RCCL all-reduce of gradient buckets overlapped with backward (+ SyncBN),
-        the equivalent of Lightning's strategy=ddp / sync_batchnorm=True (kod/configs/trainer/ddp.yaml:4-9)."""
+        the equivalent of Lightning's strategy=ddp / sync_batchnorm=True (kod/configs/trainer/ddp.yaml:4-9).
+
+        native_rccl: True = collectives through this rank's own RCCL communicator (engine/comm.py; the group is
+        only used to exchange the rendezvous id, so it may be gloo); None = that when the group is NCCL/RCCL-backed;
+        False = torch.distributed calls on the group (gloo-backed tests with several ranks on one GPU)."""
         import torch.distributed as dist
         eng = self.engine()
         eng.process_group = process_group
         eng.world_size = dist.get_world_size(process_group)
         eng.sync_bn = sync_batchnorm
+        # KODHIP_FORCE_COLLECTIVES=1 keeps the collective code path on a 1-rank group (single-GPU rehearsal of the N>1 path)
+        eng.collectives = eng.world_size > 1 or os.environ.get("KODHIP_FORCE_COLLECTIVES") == "1"
         eng.bucket_bytes = int(bucket_mb * (1 << 20))
-        if eng.world_size > 1:
-            dist.broadcast(eng.p_arena, src=dist.get_global_rank(process_group, 0) if process_group else 0,
-                           group=process_group)
-            dist.broadcast(eng.rm_arena, src=0, group=process_group)
-            dist.broadcast(eng.rv_arena, src=0, group=process_group)
+        if native_rccl is None:
+            native_rccl = dist.get_backend(process_group) == "nccl"
+        if eng.collectives and native_rccl and eng.comm is None:
+            from ...engine.comm import RcclComm
+            eng.comm = RcclComm(process_group, eng.device)
+        if eng.collectives:
+            # rank 0's parameters and BatchNorm buffers everywhere (torch DDP does this at wrap time)
+            for t in (eng.p_arena, eng.rm_arena, eng.rv_arena):
+                if eng.comm is not None:
+                    eng.comm.broadcast(t, 0)
+                else:
+                    dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                                   group=process_group)
             eng.mark_params_changed()
 
     def load_state_dict(self, *a, **k):

@@ -88,3 +88,90 @@ def test_two_rank_ddp_syncbn_equals_single_process(tmp_path):
     net.engine().sgd_step((0.1, 0.01, 0.01), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0), 0.5)
     p1 = torch.cat([q.detach().flatten() for q in net.parameters()]).cpu()
     assert rel(got["p"], p1) < 1e-4
+
+
+def _native_worker(port, size, out):
+    """One rank, own RCCL communicator (the product transport): raw collectives + a captured training step."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["KODHIP_FORCE_COLLECTIVES"] = "1"          # keep the N>1 code path on a 1-rank group
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.cuda.set_device(0)
+        from object_detection_cib_amd.engine.comm import RcclComm
+        comm = RcclComm(None, torch.device("cuda", 0))
+        a = torch.arange(1000, dtype=torch.float32, device="cuda")
+        b = torch.arange(64, dtype=torch.float64, device="cuda") / 3
+        a0, b0 = a.clone(), b.clone()
+        comm.all_reduce(a); comm.all_reduce(b); comm.broadcast(a, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(a, a0) and torch.equal(b, b0)
+        comm.close()
+
+        x, tg = _data(size)
+        res = {}
+        for mode in ("plain", "collectives-eager", "collectives-graph"):
+            net, loss = _build(5)
+            eng = net.engine()
+            if mode != "plain":
+                net.configure_distributed(None, sync_batchnorm=True, bucket_mb=0.5, native_rccl=True)
+                assert eng.comm is not None and eng.collectives
+            eng.sgd_step((0.1, 0.01, 0.01), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0), 1.0)
+            from object_detection_cib_amd.core.label_assignment.yv5 import BatchedTargets
+            from object_detection_cib_amd.core.types import FeatureShape
+            from object_detection_cib_amd.data.detection import DetectionTarget
+            xb = x.cuda()
+            bt = BatchedTargets.from_targets(tuple(DetectionTarget(b_, l_) for b_, l_ in tg), torch.device("cuda", 0))
+            params = list(net.parameters())
+
+            def step():
+                for p in params:
+                    p.grad = None
+                lr = loss(FeatureShape(width=size, height=size), net(xb), bt)
+                total = 4 * (lr.localization + lr.classification + lr.objectness)
+                total.backward()
+                eng.wait_grads()
+                eng.sgd_step_device()
+                return total
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                losses = [step().item() for _ in range(2)]
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            if mode == "collectives-graph":
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    last = step()
+                for _ in range(3):
+                    g.replay()
+                    losses.append(last.item())
+            else:
+                losses += [step().item() for _ in range(3)]
+            res[mode] = (losses, torch.cat([q.detach().flatten() for q in net.parameters()]).cpu())
+            if eng.comm is not None:
+                eng.comm.close()
+        torch.save(res, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_rccl_comm_and_captured_step(tmp_path):
+    """The RCCL transport of the product path on the single GPU of the test box: a 1-rank communicator must be an
+    identity, and a training step with SyncBN sums + gradient buckets going through it - eagerly and replayed as
+    one hipGraph - must reproduce the plain single-GPU trajectory bit for bit."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "native.pt")
+    p = mp.get_context("spawn").Process(target=_native_worker, args=(port, 128, out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    res = torch.load(out)
+    ref_l, ref_p = res["plain"]
+    for mode in ("collectives-eager", "collectives-graph"):
+        l, prm = res[mode]
+        assert l == ref_l, (mode, l, ref_l)
+        assert torch.equal(prm, ref_p), mode
