@@ -79,6 +79,16 @@ def cpu_baseline(seconds=15.0):
             "sample": f"{n} train steps of yv5s B=2 640px fp32 (oracle/ CPU restatement) in {dt:.1f}s"}
 
 
+def pmc_traffic(B, S):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes (counters cannot
+    be read from inside this process; tools/pmc_traffic.py documents the collection and the gfx950 corrections)."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(p) or (B, S) != (64, 640):
+        return None
+    with open(p) as f:
+        return round(json.load(f)["traffic_bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,7 +231,7 @@ def main():
                               "tflops": round(ips / world * ALGO_FLOP_PER_IMG / 1e12, 1)},
             "roofline": {"kernel": "conv_igemm_kernel<MODE_RAW> (forward conv, all 57 layers)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": None,
+                         "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": pmc_traffic(B, S),
                          "avg_launch_us": round(1e3 * k_ms / n_launch, 2), "launches": len(prof),
                          "algorithmic_bytes_per_launch_avg": round(k_bytes / n_launch)},
         }
