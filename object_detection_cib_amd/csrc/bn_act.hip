@@ -98,9 +98,17 @@ __global__ void bn_bwd_coeffs_fused_kernel(const float* part, int T, double coun
   coef[2 * C + c] = (float)(-g * rs * S0 + g * rs * rs * mu * S1);
 }
 
+// The elementwise passes are pure HBM streams: each thread keeps U rows (U x 16 B per operand) in flight before it
+// touches the first one - with a single load per iteration the chip holds too few bytes in flight to cover the
+// HBM latency (measured 3.5-4.5 TB/s; Little's law wants >= 12 MB outstanding for 8 TB/s).
+constexpr int U = 4;
+
+// sigmoid / SiLU on the hardware reciprocal (1 ulp; the results are rounded to bf16 right after)
+__device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+
 // ---------------------------------------------------------------- forward apply
 // out[m][ocoff + c] = silu(y[m][c]*scale[c] + shift[c]) (+ res[m][rcoff + c])
-__global__ void bn_silu_apply_kernel(const bf16_t* y, const float* scale, const float* shift,
+__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, const float* scale, const float* shift,
                                      const bf16_t* res, int ldr, int rcoff,
                                      bf16_t* out, int ldo, int ocoff, long M, int C, int rows_per_block_iter) {
   const int CC = C >> 3;
@@ -110,27 +118,46 @@ __global__ void bn_silu_apply_kernel(const bf16_t* y, const float* scale, const 
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; }
-  for (long m = (long)blockIdx.x * rows_per_block_iter + rl; m < M; m += (long)gridDim.x * rows_per_block_iter) {
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
-    bf16x8 o;
-    if (res) {
-      bf16x8 r = *reinterpret_cast<const bf16x8*>(res + m * ldr + rcoff + cc * 8);
+  const long stride = (long)gridDim.x * rows_per_block_iter;
+  for (long m0 = (long)blockIdx.x * rows_per_block_iter + rl; m0 < M; m0 += stride * U) {
+    bf16x8 v[U], r[U];
 #pragma unroll
-      // the reference adds in fp32 on the fp32 activation; here the activation is rounded to bf16 first
-      // only when it is materialised, so add before the single rounding.
-      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(silu_f((float)v[e] * sc[e] + sh[e]) + (float)r[e]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)silu_f((float)v[e] * sc[e] + sh[e]);
+    for (int u = 0; u < U; ++u) {
+      const long m = m0 + u * stride;
+      if (m < M) {
+        v[u] = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+        if (res) r[u] = *reinterpret_cast<const bf16x8*>(res + m * ldr + rcoff + cc * 8);
+      }
     }
-    *reinterpret_cast<bf16x8*>(out + m * ldo + ocoff + cc * 8) = o;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long m = m0 + u * stride;
+      if (m >= M) break;
+      bf16x8 o;
+      if (res) {
+        // the reference adds in fp32 on the fp32 activation; here the activation is rounded to bf16 only when it
+        // is materialised, so add before the single rounding.
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = (float)v[u][e] * sc[e] + sh[e];
+          o[e] = (bf16_t)(z * fast_sigmoid(z) + (float)r[u][e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = (float)v[u][e] * sc[e] + sh[e];
+          o[e] = (bf16_t)(z * fast_sigmoid(z));
+        }
+      }
+      *reinterpret_cast<bf16x8*>(out + m * ldo + ocoff + cc * 8) = o;
+    }
   }
 }
 
 // ---------------------------------------------------------------- backward reduce
 // dz = dA * silu'(z), z = y*scale + shift ; xhat = (y - mean)*rstd
 // part[0][c][blk] = sum dz ; part[1][c][blk] = sum dz*xhat
-__global__ void bn_silu_bwd_reduce_kernel(const bf16_t* dA, int lda, int dacoff, const bf16_t* y,
+__global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const bf16_t* dA, int lda, int dacoff, const bf16_t* y,
                                           const float* scale, const float* shift, const float* mean,
                                           const float* rstd, float* part, long M, int C, int rpb) {
   extern __shared__ float sm[];   // [rpb][CC][16]
@@ -146,17 +173,29 @@ __global__ void bn_silu_bwd_reduce_kernel(const bf16_t* dA, int lda, int dacoff,
     for (int e = 0; e < 8; ++e) {
       sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; mu[e] = mean[cc * 8 + e]; rs[e] = rstd[cc * 8 + e];
     }
-    for (long m = (long)blockIdx.x * rpb + rl; m < M; m += (long)gridDim.x * rpb) {
-      bf16x8 g = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
-      bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+    const long stride = (long)gridDim.x * rpb;
+    for (long m0 = (long)blockIdx.x * rpb + rl; m0 < M; m0 += stride * U) {
+      bf16x8 g[U], v[U];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float yv = (float)v[e];
-        float z = yv * sc[e] + sh[e];
-        float sg = sigmoid_f(z);
-        float dz = (float)g[e] * sg * (1.f + z * (1.f - sg));
-        s0[e] += dz;
-        s1[e] += dz * (yv - mu[e]) * rs[e];
+      for (int u = 0; u < U; ++u) {
+        const long m = m0 + u * stride;
+        if (m < M) {
+          g[u] = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
+          v[u] = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (m0 + u * stride >= M) break;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float yv = (float)v[u][e];
+          float z = yv * sc[e] + sh[e];
+          float sg = fast_sigmoid(z);
+          float dz = (float)g[u][e] * sg * (1.f + z * (1.f - sg));
+          s0[e] += dz;
+          s1[e] += dz * (yv - mu[e]) * rs[e];
+        }
       }
     }
 #pragma unroll
@@ -193,7 +232,7 @@ __global__ void bn_bwd_coeffs_kernel(const double* sums_local, const double* sum
 }
 
 // dY (bf16, written in place over y) ; optional identity gradient: dI[m][c] (+)= dA[m][c]
-__global__ void bn_silu_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, bf16_t* y,
+__global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, bf16_t* y,
                                          const float* scale, const float* shift, const float* coef,
                                          bf16_t* dI, int ldi, int dicoff, int di_accum,
                                          long M, int C, int rpb) {
@@ -207,27 +246,41 @@ __global__ void bn_silu_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, 
     int c = cc * 8 + e;
     sc[e] = scale[c]; sh[e] = shift[c]; k1[e] = coef[c]; k2[e] = coef[C + c]; k3[e] = coef[2 * C + c];
   }
-  for (long m = (long)blockIdx.x * rpb + rl; m < M; m += (long)gridDim.x * rpb) {
-    bf16x8 g = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
-    bf16x8 o;
+  const long stride = (long)gridDim.x * rpb;
+  const bool acc = dI && di_accum;
+  for (long m0 = (long)blockIdx.x * rpb + rl; m0 < M; m0 += stride * U) {
+    bf16x8 g[U], v[U], old[U];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float yv = (float)v[e];
-      float z = yv * sc[e] + sh[e];
-      float sg = sigmoid_f(z);
-      float dz = (float)g[e] * sg * (1.f + z * (1.f - sg));
-      o[e] = (bf16_t)(k1[e] * dz + k2[e] * yv + k3[e]);
-    }
-    *reinterpret_cast<bf16x8*>(y + m * C + cc * 8) = o;
-    if (dI) {
-      bf16_t* d = dI + m * ldi + dicoff + cc * 8;
-      if (di_accum) {
-        bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = (bf16_t)((float)g[e] + (float)old[e]);
+    for (int u = 0; u < U; ++u) {
+      const long m = m0 + u * stride;
+      if (m < M) {
+        g[u] = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
+        v[u] = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+        if (acc) old[u] = *reinterpret_cast<const bf16x8*>(dI + m * ldi + dicoff + cc * 8);
       }
-      *reinterpret_cast<bf16x8*>(d) = g;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long m = m0 + u * stride;
+      if (m >= M) break;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float yv = (float)v[u][e];
+        float z = yv * sc[e] + sh[e];
+        float sg = fast_sigmoid(z);
+        float dz = (float)g[u][e] * sg * (1.f + z * (1.f - sg));
+        o[e] = (bf16_t)(k1[e] * dz + k2[e] * yv + k3[e]);
+      }
+      *reinterpret_cast<bf16x8*>(y + m * C + cc * 8) = o;
+      if (dI) {
+        bf16x8 gi = g[u];
+        if (acc) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gi[e] = (bf16_t)((float)gi[e] + (float)old[u][e]);
+        }
+        *reinterpret_cast<bf16x8*>(dI + m * ldi + dicoff + cc * 8) = gi;
+      }
     }
   }
 }

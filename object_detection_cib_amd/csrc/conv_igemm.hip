@@ -78,8 +78,10 @@ void conv_igemm_kernel(ConvArgs a) {
   constexpr int B_PER_THREAD = (B_CHUNKS + NT - 1) / NT;
   constexpr int STAGE_ELEMS = (BM + BN) * LDS_ROW;
   constexpr int CS_ROW = BN + 8;            // epilogue staging row (bf16)
-  // LDS stages: 256-row tiles (2 blocks per CU) keep two K tiles in flight behind the one computed; 128-row tiles
-  // keep one, so that four blocks fit a CU and hide each other's fill latency instead
+  // LDS stages.  The fill of the wide tiles is latency-bound - a CU moves (bytes in flight) / (L2-or-HBM latency) -
+  // so 256-row tiles (2 blocks per CU) run a 3-stage ring; 128-row tiles keep 2 stages and 4 blocks per CU (a third
+  // stage costs 128x128 its 4th block, and measured nothing on the narrow tiles, whose 3x3 layers are bound by the
+  // 9x im2col re-read through L2 instead).
   constexpr int NST = (FAST && BM == 256) ? 3 : 2;
   constexpr int LDS_ELEMS = (NST * STAGE_ELEMS > BM * CS_ROW) ? NST * STAGE_ELEMS : BM * CS_ROW;
   __shared__ __attribute__((aligned(16))) bf16_t lds[LDS_ELEMS];
