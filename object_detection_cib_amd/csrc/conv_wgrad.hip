@@ -8,6 +8,8 @@
 // (m up to 6.5M rows) is split across blocks; each split writes an fp32 partial slab, and a second
 // kernel sums the slabs in a fixed order (deterministic, no float atomics) while un-permuting k back
 // to torch's [Cout][Cin][KH][KW] fp32 layout.
+#include <stdlib.h>
+
 #include "kodhip_common.h"
 
 namespace {
@@ -24,6 +26,7 @@ struct WgradArgs {
   int m_per_split, splits;
   int tiles_n, tiles_k;
   uint32_t magic_cin, magic_kw;
+  uint32_t magic_hwo, magic_wo;      // ceil(2^32 / d); 0 encodes d == 1
 };
 
 __host__ __device__ constexpr int row_bytes(int T) { return (T * 2) % 128 == 0 ? T * 2 + 64 : T * 2; }
@@ -203,6 +206,248 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---- LDS-DMA variant --------------------------------------------------------------------------------------------
+// Same tiling and fragment reads, but the 32-row operand tiles go HBM -> LDS with buffer_load..lds (no VGPR staging)
+// through an NST-deep ring.  The loop is fill-latency-bound: a CU streams (bytes in flight) / latency, and two
+// resident blocks x one 16 KB register-staged tile (the kernel above) cover only a third of what the MFMAs can eat;
+// here NST-1 tiles per block are in flight.  A DMA instruction writes 64 lanes x 16 B linearly, so LDS rows are
+// unpadded; the transposed fragment reads stay conflict-free through an XOR of the 16-byte chunk index with the row
+// (applied on the source side: LDS slot (row, c') holds chunk c = c' ^ swz(row)).  Padding / ragged rows / ragged
+// channels are out-of-range buffer offsets, which the buffer unit zero-fills.
+__host__ __device__ constexpr int swz_mask(int row_b) { return row_b % 256 == 0 ? 3 : (row_b % 128 == 0 ? 2 : 0); }
+__device__ __forceinline__ int swz(int row, int mask) { return mask == 3 ? 4 * (row & 3) : (mask == 2 ? 4 * ((row >> 1) & 1) : 0); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int WN, int WK, int RN, int RK, int NST>
+__global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs a, uint32_t x_bytes, uint32_t dy_bytes) {
+  constexpr int NW = WN * WK;
+  constexpr int TNB = WN * RN * 32;
+  constexpr int TKB = WK * RK * 32;
+  constexpr int RBY = TNB * 2, RBX = TKB * 2;             // unpadded row bytes
+  constexpr int NIY = 32 * RBY / 1024, NIX = 32 * RBX / 1024;   // DMA instructions per tile
+  constexpr int NI = NIY + NIX;
+  constexpr int SLOTS = (NI + NW - 1) / NW;               // per wave
+  constexpr int STAGE = 32 * RBY + 32 * RBX;
+  constexpr int MY = swz_mask(RBY), MX = swz_mask(RBX);
+  static_assert((32 * RBY) % 1024 == 0 && (32 * RBX) % 1024 == 0, "tile rows must fill whole DMA instructions");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave / WK, wk = wave % WK;
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int j = bid >> 3;
+  const int tiles = a.tiles_n * a.tiles_k;
+  const int tile = j % tiles;
+  const int split = (j / tiles) * 8 + xcd;
+  if (split >= a.splits) return;
+  const int n0 = (tile % a.tiles_n) * TNB;
+  const int k0 = (tile / a.tiles_n) * TKB;
+  const int m_begin = split * a.m_per_split;
+  int m_end = m_begin + a.m_per_split;
+  if (m_end > a.M) m_end = a.M;
+  const int HWo = a.Ho * a.Wo;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, dy_bytes, 0x00020000);
+#endif
+
+  // ---- per-lane constants of this wave's DMA slots: instruction t = wave + i*NW; t < NIY feeds the dY tile, else X.
+  //      The gather address of a step is recomputed from the row index with two exact magic divisions (branch-free,
+  //      ~30 VALU per slot): the loop is instruction-issue-bound on address generation, not on MFMA or bandwidth.
+  int s_row[SLOTS];                 // tile row this lane fills
+  uint32_t s_off[SLOTS];            // dY: running byte offset; X: byte offset of (xcoff + ci)
+  bool s_ok[SLOTS];                 // channel / k column in range
+  int s_cy[SLOTS], s_cx[SLOTS];     // X: kh - PH, kw - PW
+  int my_slots = 0;
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int t = wave + i * NW;
+    s_row[i] = 0; s_off[i] = 0; s_ok[i] = false; s_cy[i] = s_cx[i] = 0;
+    if (t >= NI) continue;
+    ++my_slots;
+    if (t < NIY) {
+      const int L = t * 1024 + lane * 16;
+      const int row = L / RBY, pc = (L % RBY) >> 4;
+      const int c = pc ^ swz(row, MY);
+      s_row[i] = row;
+      s_ok[i] = (n0 + c * 8) < a.N;
+      s_off[i] = (uint32_t)(((long)(m_begin + row) * a.ldy + a.ycoff + n0 + c * 8) * 2);
+    } else {
+      const int L = (t - NIY) * 1024 + lane * 16;
+      const int row = L / RBX, pc = (L % RBX) >> 4;
+      const int c = pc ^ swz(row, MX);
+      const int k = k0 + c * 8;
+      const uint32_t tap = __umulhi((uint32_t)k, a.magic_cin);
+      const int ci = k - (int)tap * a.Cin;
+      const int kh = (a.KW == 1) ? (int)tap : (int)__umulhi(tap, a.magic_kw);
+      s_row[i] = row;
+      s_ok[i] = k < a.K;
+      s_cy[i] = kh - a.PH; s_cx[i] = ((int)tap - kh * a.KW) - a.PW;
+      s_off[i] = (uint32_t)((a.xcoff + ci) * 2);
+    }
+  }
+  const uint32_t magic_hwo = a.magic_hwo, magic_wo = a.magic_wo;
+  const uint32_t ldx2 = (uint32_t)a.ldx * 2u, ystep = (uint32_t)(32 * a.ldy * 2);
+
+  int issued = 0;                   // tiles issued so far (tile index = reduction step)
+  auto issue = [&](int stage) {
+    unsigned char* Ys = lds + stage * STAGE;
+    const int mb = m_begin + issued * 32;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int t = wave + i * NW;
+      if (t >= NI) continue;
+      const int m = mb + s_row[i];
+      uint32_t vo;
+      bool ok = s_ok[i] && m < m_end;
+      if (t < NIY) {
+        vo = s_off[i];
+        s_off[i] += ystep;
+      } else {
+        // q = m / d with magic = ceil(2^32 / d): the estimate is q or q + 1 for any 31-bit m
+        uint32_t b = magic_hwo ? __umulhi((uint32_t)m, magic_hwo) : (uint32_t)m;
+        int rem = m - (int)b * HWo;
+        if (rem < 0) { rem += HWo; --b; }
+        uint32_t oy = magic_wo ? __umulhi((uint32_t)rem, magic_wo) : (uint32_t)rem;
+        int ox = rem - (int)oy * a.Wo;
+        if (ox < 0) { ox += a.Wo; --oy; }
+        const int iy = (int)oy * a.SH + s_cy[i];
+        const int ix = ox * a.SW + s_cx[i];
+        ok = ok && (unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws;
+        vo = (((uint32_t)b * (uint32_t)a.Hs + (uint32_t)iy) * (uint32_t)a.Ws + (uint32_t)ix) * ldx2 + s_off[i];
+      }
+      vo = ok ? vo : 0xFFFFFFF0u;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WG_ABL_NODMA)
+      if (t < NIY)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (__attribute__((address_space(3))) void*)(Ys + t * 1024), 16, vo, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Ys + t * 1024), 16, vo, 0, 0, 0);
+#else
+      (void)vo; (void)Ys;
+#endif
+    }
+    ++issued;
+  };
+
+  f32x16 acc[RN][RK];
+#pragma unroll
+  for (int i = 0; i < RN; ++i)
+#pragma unroll
+    for (int jj = 0; jj < RK; ++jj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+  const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int sy = swz(tr_row, MY), sx = swz(tr_row, MX);    // the rows a lane reads differ by multiples of 4 only
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  uint32_t yoff[RN], xoff[RK];
+#pragma unroll
+  for (int i = 0; i < RN; ++i) {
+    const int col = (wn * RN + i) * 32 + tr_col;
+    yoff[i] = (uint32_t)(tr_row * RBY + (((col >> 3) ^ sy) << 4) + (col & 7) * 2);
+  }
+#pragma unroll
+  for (int jj = 0; jj < RK; ++jj) {
+    const int col = (wk * RK + jj) * 32 + tr_col;
+    xoff[jj] = (uint32_t)(tr_row * RBX + (((col >> 3) ^ sx) << 4) + (col & 7) * 2);
+  }
+
+  const int nsteps = (m_end - m_begin + 31) / 32;
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nsteps) issue(p);
+  for (int st = 0; st < nsteps; ++st) {
+    // tile st must have landed; up to NST-2 newer tiles (my_slots instructions each, SLOTS or SLOTS-1) stay in flight
+    const int newer = nsteps - 1 - st;
+    if (newer >= NST - 2) {
+      if (my_slots == SLOTS) wait_vm<(NST - 2) * SLOTS>(); else wait_vm<(NST - 2) * (SLOTS - 1)>();
+    } else if (newer == 1 && NST > 3) {
+      if (my_slots == SLOTS) wait_vm<SLOTS>(); else wait_vm<SLOTS - 1>();
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+#ifndef WG_ABL_NOISSUE
+    if (st + NST - 1 < nsteps) issue((st + NST - 1) % NST);
+#endif
+    // Fragment reads are issued as inline asm: the compiler cannot tell which ring stage a ds_read touches and
+    // would otherwise drain every outstanding LDS-DMA (s_waitcnt vmcnt(0)) in front of them, which serialises the
+    // ring.  Both k-halves are read up front; the first MFMA group waits for its half only (LDS returns in order).
+    const uint32_t ys = lds_base + (uint32_t)((st % NST) * STAGE);
+    const uint32_t xs = ys + 32 * RBY;
+    s16x4 ylo[2][RN], yhi[2][RN], xlo[2][RK], xhi[2][RK];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < RN; ++i) {
+        const uint32_t p = ys + yoff[i] + (uint32_t)(ks * 16 * RBY);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[ks][i]) : "v"(p) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(yhi[ks][i]) : "v"(p + 4 * RBY) : "memory");
+      }
+#pragma unroll
+      for (int jj = 0; jj < RK; ++jj) {
+        const uint32_t p = xs + xoff[jj] + (uint32_t)(ks * 16 * RBX);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[ks][jj]) : "v"(p) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xhi[ks][jj]) : "v"(p + 4 * RBX) : "memory");
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // wait for this half's reads; the registers are operands so that the MFMAs cannot be hoisted above the wait
+      if (ks == 0) {
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (RN + RK)) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int i = 0; i < RN; ++i) asm volatile("" : "+v"(ylo[ks][i]), "+v"(yhi[ks][i]));
+#pragma unroll
+      for (int jj = 0; jj < RK; ++jj) asm volatile("" : "+v"(xlo[ks][jj]), "+v"(xhi[ks][jj]));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      bf16x8 yf[RN], xf[RK];
+#pragma unroll
+      for (int i = 0; i < RN; ++i) {
+        s16x8 t = {ylo[ks][i][0], ylo[ks][i][1], ylo[ks][i][2], ylo[ks][i][3], yhi[ks][i][0], yhi[ks][i][1], yhi[ks][i][2], yhi[ks][i][3]};
+        yf[i] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int jj = 0; jj < RK; ++jj) {
+        s16x8 t = {xlo[ks][jj][0], xlo[ks][jj][1], xlo[ks][jj][2], xlo[ks][jj][3], xhi[ks][jj][0], xhi[ks][jj][1], xhi[ks][jj][2], xhi[ks][jj][3]};
+        xf[jj] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int i = 0; i < RN; ++i)
+#pragma unroll
+        for (int jj = 0; jj < RK; ++jj)
+#ifdef WG_ABL_NOMFMA
+          asm volatile("" ::"v"(yf[i]), "v"(xf[jj]));
+#else
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i], xf[jj], acc[i][jj], 0, 0, 0);
+#endif
+    }
+  }
+  // D[n][k]: k = lane & 31, n = 8*(e>>2) + 4*(lane>>5) + (e&3)
+  float* slab = a.part + (size_t)split * a.N * a.Kp;
+#pragma unroll
+  for (int i = 0; i < RN; ++i)
+#pragma unroll
+    for (int jj = 0; jj < RK; ++jj) {
+      int k = k0 + (wk * RK + jj) * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int n = n0 + (wn * RN + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        if (n < a.N && k < a.Kp) slab[(size_t)n * a.Kp + k] = acc[i][jj][e];
+      }
+    }
+}
+
 // grad[n][ci][kh][kw] = scale * sum_s part[s][n][k(kh,kw,ci)]   (stem: k = (kh, kw', dx, c4), see pack)
 // block = 16 consecutive k x 16 split lanes: 64-byte coalesced slab reads, fixed-order LDS tree => deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* grad, int splits, int Nfull,
@@ -240,12 +485,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
   }
 }
 
+constexpr int WGRAD_STAGES = 4;
+
 template <int WN, int WK, int RN, int RK>
 int launch_cfg(WgradArgs a, hipStream_t stream) {
   constexpr int TNB = WN * RN * 32, TKB = WK * RK * 32;
   a.tiles_n = cdiv(a.N, TNB);
   a.tiles_k = cdiv(a.Kp, TKB);
   int grid = cdiv(a.splits, 8) * 8 * a.tiles_n * a.tiles_k;
+  // LDS-DMA ring by default: +4-5 % on the whole training step over the register-staged kernel (in the network the
+  // operands come from HBM and the deeper prefetch pays; back-to-back microbenchmarks with L2-hot operands show
+  // mixed results for the 3x3 layers because an LDS-DMA piece costs 60+ issue cycles).  KODHIP_WGRAD_DMA=none
+  // selects the register-staged kernel for A/B runs; an operand that does not fit a 32-bit buffer range always
+  // takes it.
+  const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, yb = (long)a.M * a.ldy * 2;
+  static const char* mode = getenv("KODHIP_WGRAD_DMA");
+  if (!(mode && mode[0] == 'n') && xb < (1l << 32) - 64 && yb < (1l << 32) - 64) {
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<WN, WK, RN, RK, WGRAD_STAGES>), dim3(grid), dim3(64 * WN * WK), 0, stream, a,
+                       (uint32_t)xb, (uint32_t)yb);
+    KOD_LAUNCH_CHECK("conv_wgrad_dma");
+    return KOD_OK;
+  }
   hipLaunchKernelGGL((conv_wgrad_kernel<WN, WK, RN, RK>), dim3(grid), dim3(64 * WN * WK), 0, stream, a);
   KOD_LAUNCH_CHECK("conv_wgrad");
   return KOD_OK;
@@ -293,6 +553,7 @@ int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* gra
   a.M = (int)M; a.N = N; a.K = KH * KW * Cin; a.Kp = Kp;
   a.KH = KH; a.KW = KW; a.SH = SH; a.SW = SW; a.PH = PH; a.PW = PW; a.ldy = ldy; a.ycoff = ycoff;
   a.magic_cin = magic_u32((uint32_t)Cin); a.magic_kw = magic_u32((uint32_t)KW);
+  a.magic_hwo = magic_u32((uint32_t)(a.Ho * a.Wo)); a.magic_wo = magic_u32((uint32_t)a.Wo);
   a.splits = kodhip_conv_wgrad_splits(M, N, Kp);
   a.m_per_split = cdiv(cdiv(M, a.splits), 32) * 32;
   a.splits = cdiv(M, a.m_per_split);
