@@ -39,7 +39,7 @@ class _Joined:
             torch.cuda.current_stream().wait_stream(self.stream)
 
 
-def launch_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, stream=None, comm=None):
+def launch_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, stream=None, comm=None, also_after=None):
     """Sum all-reduce of a contiguous arena slice, overlapped with the caller's stream.
 
     On the GPU the collective goes on a side stream that first waits for the caller's stream - the dependency
@@ -48,6 +48,8 @@ def launch_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, stream=None,
     tests).  CPU tensors (host-logic tests): a plain async_op Work."""
     if flat.is_cuda and stream is not None:
         stream.wait_stream(torch.cuda.current_stream())
+        if also_after is not None:           # e.g. the weight-gradient stream that fills this bucket
+            stream.wait_stream(also_after)
         if comm is not None:
             comm.all_reduce(flat[lo:hi], stream.cuda_stream)
         else:

@@ -14,6 +14,8 @@ import ctypes as C
 from typing import Dict, List, Optional
 
 import numpy as np
+import os
+
 import torch
 
 from .. import _lib
@@ -47,6 +49,8 @@ class Engine:
         self.sync_bn = False
         self.process_group = None
         self.world_size = 1
+        self.wg_stream = None          # side stream of the weight-gradient kernels (see backward)
+        self.wgrad_overlap = os.environ.get("KODHIP_WGRAD_OVERLAP", "1") != "0"
         self.comm = None               # RcclComm when the process group is RCCL-backed (the product path)
         self.comm_stream = None        # side stream of the gradient-bucket all-reduces
         self.collectives = False       # True when gradients / BN sums go through the process group (world > 1)
@@ -367,6 +371,21 @@ class Engine:
         pa = self.p_arena.data_ptr()
         wgp = self.wg_part.data_ptr()
         touched = set()            # grad buffers already holding a (partial) sum
+        # Weight gradients run on a side stream: dW of a layer is off the critical path (bn-bwd -> dgrad -> next
+        # layer), so it fills the tails of the small kernels on the main stream and, under SyncBN, the latency of
+        # the per-layer statistic all-reduce.  All wgrads share one stream (and the split-K scratch) => ordered.
+        main = torch.cuda.current_stream()
+        wg = None
+        if self.wgrad_overlap:
+            if self.wg_stream is None:
+                self.wg_stream = torch.cuda.Stream(device=self.device)
+            wg = self.wg_stream
+
+        def wgrad_stream():
+            if wg is None:
+                return s
+            wg.wait_stream(main)
+            return wg.cuda_stream
 
         def acc_flag(v: View) -> int:
             """0 = first writer (overwrite), 1 = accumulate; zero-fills on a partial first touch."""
@@ -407,7 +426,7 @@ class Engine:
                 chk(lib.kodhip_conv_wgrad(self._ptr(src), hs["dy"].data_ptr(), wgp, gp + 4 * hs["w_off"],
                                           B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
                                           self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kp"], self.head_npad, 0,
-                                          A * (5 + nc), 0, 1.0, s), hu.name + ".wgrad")
+                                          A * (5 + nc), 0, 1.0, wgrad_stream()), hu.name + ".wgrad")
             elif op.kind == "up":
                 h, w = H // op.src.stride, W // op.src.stride
                 chk(lib.kodhip_upsample2x_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
@@ -460,13 +479,16 @@ class Engine:
                         chk(lib.kodhip_conv_dgrad(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
                                                   *geo, st.Kdp, C_, 0, acc_flag(u.src), s), u.name + ".dgrad")
                 chk(lib.kodhip_conv_wgrad(self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
-                                          *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0, s), u.name + ".wgrad")
+                                          *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0, wgrad_stream()), u.name + ".wgrad")
             # gradient buckets complete from the arena's end toward its start
             if op.kind in ("conv", "head"):
                 unit_i -= 1
                 if unit_i in buckets:
                     lo, hi = buckets[unit_i]
-                    self._pending.append(launch_bucket(ga, lo, hi, self.process_group, self._comm_stream(), self.comm))
+                    self._pending.append(launch_bucket(ga, lo, hi, self.process_group, self._comm_stream(), self.comm,
+                                                       also_after=wg))
+        if wg is not None:
+            main.wait_stream(wg)
         self._publish_grads()
 
     def _comm_stream(self):
