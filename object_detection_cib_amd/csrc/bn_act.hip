@@ -10,16 +10,27 @@
 
 namespace {
 
+// Sum of T fp32 partials in fp64 by one wave, fixed order: 16-byte loads, four independent accumulation chains so
+// that the loads of a pass are in flight together (these kernels are pure latency: one wave per channel).
+__device__ __forceinline__ double wave_sum_partials(const float* p, int T, int lane) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const int T4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (T & ~3) : 0;
+#pragma unroll 4
+  for (int t = lane * 4; t < T4; t += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p + t);
+    a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+  }
+  for (int t = T4 + lane; t < T; t += 64) a0 += (double)p[t];
+  return wave_sum_d((a0 + a1) + (a2 + a3));
+}
+
 // ---------------------------------------------------------------- partial slabs -> fp64 sums
 // in: part[2][C][T] fp32 ; out: sums[2][C] fp64.  One wave per (stat, channel).
 __global__ void bn_reduce_partials_kernel(const float* part, double* sums, int C, int T) {
   int idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (idx >= 2 * C) return;
   int lane = threadIdx.x & 63;
-  const float* p = part + (size_t)idx * T;
-  double s = 0.0;
-  for (int t = lane; t < T; t += 64) s += (double)p[t];
-  s = wave_sum_d(s);
+  double s = wave_sum_partials(part + (size_t)idx * T, T, lane);
   if (lane == 0) sums[idx] = s;
 }
 
@@ -57,9 +68,7 @@ __global__ void bn_finalize_fused_kernel(const float* part, int T, double count,
   int lane = threadIdx.x & 63;
   const float* p0 = part + (size_t)c * T;
   const float* p1 = part + (size_t)(C + c) * T;
-  double s0 = 0.0, s1 = 0.0;
-  for (int t = lane; t < T; t += 64) { s0 += (double)p0[t]; s1 += (double)p1[t]; }
-  s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+  double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
   if (lane != 0) return;
   double mean = s0 / count;
   double var = s1 / count - mean * mean;
@@ -85,9 +94,7 @@ __global__ void bn_bwd_coeffs_fused_kernel(const float* part, int T, double coun
   int lane = threadIdx.x & 63;
   const float* p0 = part + (size_t)c * T;
   const float* p1 = part + (size_t)(C + c) * T;
-  double s0 = 0.0, s1 = 0.0;
-  for (int t = lane; t < T; t += 64) { s0 += (double)p0[t]; s1 += (double)p1[t]; }
-  s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+  double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
   if (lane != 0) return;
   dbeta[c] = (float)s0;
   dgamma[c] = (float)s1;
@@ -364,14 +371,22 @@ int kodhip_bn_silu_apply(const void* y, const float* scale, const float* shift,
   return KOD_OK;
 }
 
-int kodhip_bn_bwd_slots(long M, int C) { return geo(M, C, 1024).grid; }
+// Reduction grid of the backward pass = number of partial slots: at most 1024 blocks, and no more than one block per
+// 64 KB of input, so that small layers do not pay for a partial slab (2*C*grid floats) as large as their data.
+static int bwd_reduce_blocks(long M, int C) {
+  long by_bytes = (M * C * 4 + 65535) / 65536;
+  if (by_bytes < 64) by_bytes = 64;
+  return (int)(by_bytes < 1024 ? by_bytes : 1024);
+}
+
+int kodhip_bn_bwd_slots(long M, int C) { return geo(M, C, bwd_reduce_blocks(M, C)).grid; }
 
 int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* partials,
                               long M, int C, hipStream_t stream) {
   KOD_CHECK_ARG(dA && y && scale && shift && mean && rstd && partials && M > 0, "bn_silu_bwd_reduce: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda, "bn_silu_bwd_reduce: bad geometry");
-  Geo g = geo(M, C, 1024);
+  Geo g = geo(M, C, bwd_reduce_blocks(M, C));
   size_t shm = (size_t)g.rpb * (C / 8) * 16 * sizeof(float);
   hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(g.grid), dim3(g.threads), shm, stream, (const bf16_t*)dA, lda,
                      dacoff, (const bf16_t*)y, scale, shift, mean, rstd, partials, M, C, g.rpb);

@@ -62,8 +62,7 @@ constexpr int BK = 32;
 // launch bounds: 4 blocks per CU (one wave of each on every SIMD) => at most 128 VGPRs, so that one block's LDS /
 // global phases overlap another block's MFMA phase (measured: the phases of a single block do not overlap)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ || WAVES_M * WAVES_N > 4 ? 2 : (FAST ? 4 : 3)))
-void conv_igemm_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int NW = NT / 64;
   static_assert(FAST || (BM == 128 && NT == 256), "register-staged path is written for 128-row tiles / 4 waves");
@@ -94,7 +93,6 @@ void conv_igemm_kernel(ConvArgs a) {
   const int wn = wave % WAVES_N;
 
   // XCD-aware block -> (m group, n tile): blocks b and b+8 share an XCD.
-  const int bid = blockIdx.x;
   const int xcd = bid & 7;
   const int j = bid >> 3;
   const int nt = j % a.tiles_n;
@@ -480,6 +478,25 @@ void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ || WAVES_M * WAVES_N > 4 ? 2 : (FAST ? 4 : 3)))
+void conv_igemm_kernel(ConvArgs a) {
+  conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(a, blockIdx.x);
+}
+
+// Four problems of identical tiling in one launch (the parity classes of a stride-2 dgrad): blocks 8j .. 8j+31 are
+// {XCD 0-7} x {class 0-3} of virtual block group j, so the four classes that gather the same dY rows run next to
+// each other on the same XCD and share them through its L2 instead of streaming dY from HBM four times.
+struct ConvArgs4 { ConvArgs c[4]; };
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ || WAVES_M * WAVES_N > 4 ? 2 : (FAST ? 4 : 3)))
+void conv_igemm_x4_kernel(ConvArgs4 p) {
+  const int bid = blockIdx.x;
+  const int cls = (bid >> 3) & 3;
+  conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(p.c[cls], ((bid >> 5) << 3) | (bid & 7));
+}
+
 // ---- launch planning --------------------------------------------------------------------------------
 // Resident blocks per chip (256 CUs) for each tile shape (FAST path: register-bound at 4 x 4 waves or 2 x 8 waves
 // per CU; register-staged path: LDS-bound, 2 stages of (128+BN)*80 B).
@@ -524,12 +541,13 @@ Plan make_plan(long M, int N, int K, bool fast) {
   return best;
 }
 
+bool fast_eligible(const ConvArgs& a);
+
 template <int MODE>
 int launch(const ConvArgs& a, hipStream_t stream) {
   ConvArgs args = a;
   const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, wb = (long)a.N * a.Kp * 2;
-  const bool fast = (a.Cin % 32 == 0) && (a.sh_shift | a.sw_shift) == 0 && a.K == a.Kp && xb < (1l << 32) - 64 &&
-                    wb < (1l << 32) - 64 && !getenv("KODHIP_NO_FAST");
+  const bool fast = fast_eligible(a);
   args.x_bytes = (uint32_t)xb; args.w_bytes = (uint32_t)wb;
   const Plan p = make_plan(a.M, a.N, a.K, fast);
   args.tiles_n = p.tiles_n; args.tiles_m = p.tiles_m; args.groups_m = p.groups_m;
@@ -549,6 +567,33 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   }
   KOD_LAUNCH_CHECK("conv_igemm");
   return KOD_OK;
+}
+
+// one launch for four FAST problems that share M, N and the tile plan (chosen for the longest reduction)
+int launch_x4_plain(ConvArgs c[4], hipStream_t stream) {
+  ConvArgs4 p;
+  int kmax = 0;
+  for (int i = 0; i < 4; ++i) kmax = c[i].K > kmax ? c[i].K : kmax;
+  const Plan pl = make_plan(c[0].M, c[0].N, kmax, true);
+  for (int i = 0; i < 4; ++i) {
+    p.c[i] = c[i];
+    p.c[i].x_bytes = (uint32_t)((long)c[i].B * c[i].Hs * c[i].Ws * c[i].ldx * 2);
+    p.c[i].w_bytes = (uint32_t)((long)c[i].N * c[i].Kp * 2);
+    p.c[i].tiles_n = pl.tiles_n; p.c[i].tiles_m = pl.tiles_m; p.c[i].groups_m = pl.groups_m;
+  }
+  dim3 g(pl.grid * 4);
+  if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE_PLAIN, true>), g, dim3(512), 0, stream, p);
+  else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE_PLAIN, true>), g, dim3(256), 0, stream, p);
+  else if (pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 2, MODE_PLAIN, true>), g, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 32, 4, 1, MODE_PLAIN, true>), g, dim3(256), 0, stream, p);
+  KOD_LAUNCH_CHECK("conv_igemm_x4");
+  return KOD_OK;
+}
+
+bool fast_eligible(const ConvArgs& a) {
+  const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, wb = (long)a.N * a.Kp * 2;
+  return (a.Cin % 32 == 0) && (a.sh_shift | a.sw_shift) == 0 && a.K == a.Kp && xb < (1l << 32) - 64 &&
+         wb < (1l << 32) - 64 && !getenv("KODHIP_NO_FAST");
 }
 
 int ilog2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; }
@@ -645,11 +690,14 @@ int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
   KOD_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "conv_dgrad_s2: input dims must be even");
   const int Ho = H / 2, Wo = W / 2;
   size_t woff = 0;
+  ConvArgs cls[4];
+  bool all_fast = !getenv("KODHIP_S2_SEPARATE");
   for (int c = 0; c < 4; ++c) {
     const int py = c >> 1, px = c & 1;
     const int KH = 1 + py, KW = 1 + px;
     const int Kp = (KH * KW * N + 31) / 32 * 32;
-    ConvArgs a = {};
+    ConvArgs& a = cls[c];
+    a = ConvArgs{};
     // gather source dy [B,Ho,Wo,N]; class outputs form a Ho x Wo grid scattered into dx with stride 2
     int rc = fill_common(a, dy, (const bf16_t*)w_dgrad_s2 + woff, B, Ho, Wo, ldy, ycoff, N, Ho, Wo, Cin, KH, KW, Kp);
     if (rc) return rc;
@@ -657,9 +705,13 @@ int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
     a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff; a.accumulate = accumulate;
     a.mul_h = 1; a.mul_w = 1; a.add_h = py; a.add_w = px; a.tap_sign = -1; a.sh_shift = 0; a.sw_shift = 0;
     a.out_mul = 2; a.out_off_y = py; a.out_off_x = px; a.out_H = H; a.out_W = W;
-    rc = launch<MODE_PLAIN>(a, stream);
-    if (rc) return rc;
+    all_fast = all_fast && fast_eligible(a);
     woff += (size_t)Cin * Kp;
+  }
+  if (all_fast) return launch_x4_plain(cls, stream);
+  for (int c = 0; c < 4; ++c) {
+    int rc = launch<MODE_PLAIN>(cls[c], stream);
+    if (rc) return rc;
   }
   return KOD_OK;
 }

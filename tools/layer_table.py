@@ -3,7 +3,7 @@ import csv, glob, sys
 sys.path.insert(0, '.')
 from object_detection_cib_amd.engine.graph import build_graph
 d = sys.argv[1]
-tr = list(csv.DictReader(open(glob.glob(d + '/*/*kernel_trace.csv')[0])))
+tr = list(csv.DictReader(open((glob.glob(d + '/*/*kernel_trace.csv') + glob.glob(d + '/*kernel_trace.csv'))[0])))
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(tr) if 'nchw_to_nhwc4' in r['Kernel_Name']]
 step = tr[idx[-2]:idx[-1]]
@@ -12,19 +12,22 @@ g = build_graph(3, 10, 0.5, 0.33)
 units = [op.unit for op in g.ops if op.kind == 'conv']
 B = 64
 isk = lambda r, s: s in r['Kernel_Name']
-fw = [r for r in step if isk(r, 'conv_igemm_kernel') and ', 0>' in r['Kernel_Name']]
-bw = [r for r in step if (isk(r, 'conv_igemm_kernel') and ', 1>' in r['Kernel_Name']) or isk(r, 'conv_wgrad_kernel')]
-# backward stream per unit (reverse order): [dgrad x(1 or 4)] wgrad
-pos = 0
-# skip heads: each head = dgrad + wgrad
-pos = 6
+import re
+def mode(r):
+    m = re.search(r'conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d), ', r['Kernel_Name'])
+    return int(m.group(1)) if m else -1
+fw = [r for r in step if mode(r) == 0]
+dg = [r for r in step if mode(r) == 1]
+wg = [r for r in step if isk(r, 'conv_wgrad')]
+# backward per unit in reverse order; the three heads come first (one dgrad + one wgrad each)
 ru = list(reversed(units))
 dmap, wmap = {}, {}
+dpos, wpos = 3, 3
 for u in ru:
     if not u.stem:
         n = 4 if (u.k == 3 and u.s == 2) else 1
-        dmap[u.name] = sum(dur(r) for r in bw[pos:pos + n]); pos += n
-    wmap[u.name] = dur(bw[pos]); pos += 1
+        dmap[u.name] = sum(dur(r) for r in dg[dpos:dpos + n]); dpos += n
+    wmap[u.name] = dur(wg[wpos]); wpos += 1
 tot = [0, 0, 0]
 for i, u in enumerate(units):
     st = u.dst.stride; Ho = 640 // st; M = B * Ho * Ho
