@@ -219,18 +219,19 @@ __device__ __forceinline__ int swz(int row, int mask) { return mask == 3 ? 4 * (
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int WN, int WK, int RN, int RK, int NST>
+template <int WN, int WK, int RN, int RK, int NST, int RS>
 __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs a, uint32_t x_bytes, uint32_t dy_bytes) {
   constexpr int NW = WN * WK;
   constexpr int TNB = WN * RN * 32;
   constexpr int TKB = WK * RK * 32;
   constexpr int RBY = TNB * 2, RBX = TKB * 2;             // unpadded row bytes
-  constexpr int NIY = 32 * RBY / 1024, NIX = 32 * RBX / 1024;   // DMA instructions per tile
+  constexpr int NIY = RS * RBY / 1024, NIX = RS * RBX / 1024;   // DMA instructions per tile (RS reduction rows)
+  constexpr int KS = RS / 16;                                   // MFMA k-groups per tile
   constexpr int NI = NIY + NIX;
   constexpr int SLOTS = (NI + NW - 1) / NW;               // per wave
-  constexpr int STAGE = 32 * RBY + 32 * RBX;
+  constexpr int STAGE = RS * RBY + RS * RBX;
   constexpr int MY = swz_mask(RBY), MX = swz_mask(RBX);
-  static_assert((32 * RBY) % 1024 == 0 && (32 * RBX) % 1024 == 0, "tile rows must fill whole DMA instructions");
+  static_assert((RS * RBY) % 1024 == 0 && (RS * RBX) % 1024 == 0, "tile rows must fill whole DMA instructions");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
 
   const int tid = threadIdx.x;
@@ -293,12 +294,12 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
     }
   }
   const uint32_t magic_hwo = a.magic_hwo, magic_wo = a.magic_wo;
-  const uint32_t ldx2 = (uint32_t)a.ldx * 2u, ystep = (uint32_t)(32 * a.ldy * 2);
+  const uint32_t ldx2 = (uint32_t)a.ldx * 2u, ystep = (uint32_t)(RS * a.ldy * 2);
 
   int issued = 0;                   // tiles issued so far (tile index = reduction step)
   auto issue = [&](int stage) {
     unsigned char* Ys = lds + stage * STAGE;
-    const int mb = m_begin + issued * 32;
+    const int mb = m_begin + issued * RS;
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int t = wave + i * NW;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
     xoff[jj] = (uint32_t)(tr_row * RBX + (((col >> 3) ^ sx) << 4) + (col & 7) * 2);
   }
 
-  const int nsteps = (m_end - m_begin + 31) / 32;
+  const int nsteps = (m_end - m_begin + RS - 1) / RS;
 #pragma unroll
   for (int p = 0; p < NST - 1; ++p)
     if (p < nsteps) issue(p);
@@ -381,10 +382,10 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
     // would otherwise drain every outstanding LDS-DMA (s_waitcnt vmcnt(0)) in front of them, which serialises the
     // ring.  Both k-halves are read up front; the first MFMA group waits for its half only (LDS returns in order).
     const uint32_t ys = lds_base + (uint32_t)((st % NST) * STAGE);
-    const uint32_t xs = ys + 32 * RBY;
-    s16x4 ylo[2][RN], yhi[2][RN], xlo[2][RK], xhi[2][RK];
+    const uint32_t xs = ys + RS * RBY;
+    s16x4 ylo[KS][RN], yhi[KS][RN], xlo[KS][RK], xhi[KS][RK];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
       for (int i = 0; i < RN; ++i) {
         const uint32_t p = ys + yoff[i] + (uint32_t)(ks * 16 * RBY);
@@ -399,13 +400,14 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
       }
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      // wait for this half's reads; the registers are operands so that the MFMAs cannot be hoisted above the wait
-      if (ks == 0) {
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (RN + RK)) : "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
+    for (int ks = 0; ks < KS; ++ks) {
+      // wait for this k-group's reads (LDS returns in order; the counter saturates at 15); the registers are
+      // operands of the empty asm below so that the MFMAs cannot be hoisted above the wait
+      constexpr int PER = 2 * (RN + RK);
+      if (ks == KS - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else if ((KS - 1 - ks) * PER >= 15) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+      else if (ks == KS - 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PER < 15 ? PER : 15) : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * PER < 15 ? 2 * PER : 15) : "memory");
 #pragma unroll
       for (int i = 0; i < RN; ++i) asm volatile("" : "+v"(ylo[ks][i]), "+v"(yhi[ks][i]));
 #pragma unroll
@@ -485,7 +487,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
   }
 }
 
-constexpr int WGRAD_STAGES = 4;
+#ifndef WG_NST
+#define WG_NST 4
+#endif
+#ifndef WG_RS
+#define WG_RS 32
+#endif
+constexpr int WGRAD_STAGES = WG_NST;     // LDS ring depth
+constexpr int WGRAD_ROWS = WG_RS;        // reduction rows per ring stage
 
 template <int WN, int WK, int RN, int RK>
 int launch_cfg(WgradArgs a, hipStream_t stream) {
@@ -501,7 +510,7 @@ int launch_cfg(WgradArgs a, hipStream_t stream) {
   const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, yb = (long)a.M * a.ldy * 2;
   static const char* mode = getenv("KODHIP_WGRAD_DMA");
   if (!(mode && mode[0] == 'n') && xb < (1l << 32) - 64 && yb < (1l << 32) - 64) {
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<WN, WK, RN, RK, WGRAD_STAGES>), dim3(grid), dim3(64 * WN * WK), 0, stream, a,
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<WN, WK, RN, RK, WGRAD_STAGES, WGRAD_ROWS>), dim3(grid), dim3(64 * WN * WK), 0, stream, a,
                        (uint32_t)xb, (uint32_t)yb);
     KOD_LAUNCH_CHECK("conv_wgrad_dma");
     return KOD_OK;
