@@ -58,6 +58,27 @@ int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
 int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
                          int B, int H, int W, int ldx, int xcoff, int Cin, int N,
                          int ldy, int ycoff, int accumulate, kodStream_t stream);
+/* Data gradient that also produces the BatchNorm-backward reduction of the conv units whose output gradient it
+ * completes (it must be the LAST writer of those channel ranges of dx): fuses aten::convolution_backward (dX) with
+ * the reduction half of native_batch_norm_backward + silu_backward of the producing Conv2dNormActivation
+ * (kod/nn/layers/csp.py:30-46).  Per segment: partials[2][ch_count][slots] = per-block sums of dz and dz*y. */
+typedef struct KodBnRedSeg {
+  int ch_begin, ch_count;       /* channel range of dx (relative to xcoff) owned by one producing unit */
+  const void* raw; int ldr;     /* that unit's pre-BN output y, bf16 [pixels of dx][ldr] */
+  const float* aff;             /* scale[ch_count] | shift[ch_count] */
+  float* partials;
+} KodBnRedSeg;
+int kodhip_conv_dgrad_bnred_slots(int B, int H, int W, int Cin, int N, int KH, int KW, int SH, int SW, int PH, int PW,
+                                  int ldy, int stride2 /* 1: the kodhip_conv_dgrad_s2 form */);  /* 0: cannot be fused */
+int kodhip_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* dx,
+                            int B, int H, int W, int ldx, int xcoff, int Cin,
+                            int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                            int ldy, int ycoff, int accumulate, const void* segments /* host KodBnRedSeg[nseg] */,
+                            int nseg, int slots, kodStream_t stream);
+int kodhip_conv_dgrad_s2_bnred(const void* dy, const void* w_dgrad_s2, void* dx,
+                               int B, int H, int W, int ldx, int xcoff, int Cin, int N,
+                               int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                               kodStream_t stream);
 int kodhip_conv_wgrad_splits(long M, int N, int Kp);
 int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* grad,
                       int B, int H, int W, int ldx, int xcoff, int Cin,
@@ -78,6 +99,7 @@ int kodhip_bn_finalize_partials(const float* partials, int T, double count, cons
                                 kodStream_t stream);
 int kodhip_bn_bwd_coeffs_partials(const float* partials, int T, double count, const float* gamma, const float* mean,
                                   const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
+                                  int raw_moment /* 1: partials[1] = sum dz*y (kodhip_conv_dgrad_bnred) */,
                                   kodStream_t stream);
 int kodhip_bn_silu_apply(const void* y, const float* scale, const float* shift,
                          const void* residual, int ldr, int rcoff,
@@ -88,7 +110,7 @@ int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y
                               long M, int C, kodStream_t stream);
 int kodhip_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const float* gamma,
                          const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
-                         kodStream_t stream);
+                         int raw_moment, kodStream_t stream);
 int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, const float* scale,
                              const float* shift, const float* coef, void* dI, int ldi, int dicoff, int di_accum,
                              long M, int C, kodStream_t stream);

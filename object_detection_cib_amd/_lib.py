@@ -20,6 +20,10 @@ class KodDecodeLevel(C.Structure):
     _fields_ = [("raw", vp), ("h", i32), ("w", i32), ("stride", i32), ("anchor_w", f32 * 3), ("anchor_h", f32 * 3)]
 
 
+class KodBnRedSeg(C.Structure):
+    _fields_ = [("ch_begin", i32), ("ch_count", i32), ("raw", vp), ("ldr", i32), ("aff", vp), ("partials", vp)]
+
+
 class KodLossLevel(C.Structure):
     _fields_ = [("logits", vp), ("grad", vp), ("idx", vp), ("label", vp), ("gt", vp), ("anc", vp),
                 ("count", vp), ("cellmaps", vp), ("rowprev", vp), ("rowgrad", vp), ("tobj", vp),
@@ -39,16 +43,19 @@ SIGNATURES = {
     "kodhip_conv_fwd_head": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp]),
     "kodhip_conv_dgrad": (i32, [vp, vp, vp] + [i32] * 17 + [vp]),
     "kodhip_conv_dgrad_s2": (i32, [vp, vp, vp] + [i32] * 10 + [vp]),
+    "kodhip_conv_dgrad_bnred_slots": (i32, [i32] * 13),
+    "kodhip_conv_dgrad_bnred": (i32, [vp, vp, vp] + [i32] * 17 + [vp, i32, i32, vp]),
+    "kodhip_conv_dgrad_s2_bnred": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, i32, vp]),
     "kodhip_conv_wgrad_splits": (i32, [i64, i32, i32]),
     "kodhip_conv_wgrad": (i32, [vp, vp, vp, vp] + [i32] * 18 + [f32, vp]),
     "kodhip_bn_reduce_partials": (i32, [vp, vp, i32, i32, vp]),
     "kodhip_bn_finalize": (i32, [vp, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_finalize_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
-    "kodhip_bn_bwd_coeffs_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "kodhip_bn_bwd_coeffs_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_silu_apply": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, vp]),
     "kodhip_bn_bwd_slots": (i32, [i64, i32]),
     "kodhip_bn_silu_bwd_reduce": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
-    "kodhip_bn_bwd_coeffs": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "kodhip_bn_bwd_coeffs": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_silu_bwd_apply": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i64, i32, vp]),
     "kodhip_maxpool5_fwd": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "kodhip_maxpool5_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

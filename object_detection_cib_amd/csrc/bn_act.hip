@@ -86,9 +86,11 @@ __global__ void bn_finalize_fused_kernel(const float* part, int T, double count,
   }
 }
 
+// raw_moment: the second partial is sum dz*y (produced by the data-gradient epilogue, conv_igemm.hip MODE_PLAIN_BN)
+// instead of sum dz*xhat; xhat = (y - mean)*rstd  =>  sum dz*xhat = rstd * (sum dz*y - mean * sum dz), in fp64.
 __global__ void bn_bwd_coeffs_fused_kernel(const float* part, int T, double count, const float* gamma,
                                            const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                                           float* coef, int C) {
+                                           float* coef, int C, int raw_moment) {
   int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
   int lane = threadIdx.x & 63;
@@ -96,6 +98,7 @@ __global__ void bn_bwd_coeffs_fused_kernel(const float* part, int T, double coun
   const float* p1 = part + (size_t)(C + c) * T;
   double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
   if (lane != 0) return;
+  if (raw_moment) s1 = (double)rstd[c] * (s1 - (double)mean[c] * s0);
   dbeta[c] = (float)s0;
   dgamma[c] = (float)s1;
   double g = gamma[c], rs = rstd[c], mu = mean[c];
@@ -231,13 +234,15 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const bf16_t* d
 //   dY = k1*dz + k2*y + k3,  k1 = g*rstd, k2 = -g*rstd^2*S1/n, k3 = -g*rstd*S0/n + g*rstd^2*mean*S1/n
 __global__ void bn_bwd_coeffs_kernel(const double* sums_local, const double* sums_global, double count,
                                      const float* gamma, const float* mean, const float* rstd,
-                                     float* dgamma, float* dbeta, float* coef, int C) {
+                                     float* dgamma, float* dbeta, float* coef, int C, int raw_moment) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  dbeta[c] = (float)sums_local[c];
-  dgamma[c] = (float)sums_local[C + c];
   double g = gamma[c], rs = rstd[c], mu = mean[c];
-  double S0 = sums_global[c] / count, S1 = sums_global[C + c] / count;
+  double l1 = sums_local[C + c], g1 = sums_global[C + c];
+  if (raw_moment) { l1 = rs * (l1 - mu * sums_local[c]); g1 = rs * (g1 - mu * sums_global[c]); }
+  dbeta[c] = (float)sums_local[c];
+  dgamma[c] = (float)l1;
+  double S0 = sums_global[c] / count, S1 = g1 / count;
   coef[c] = (float)(g * rs);
   coef[C + c] = (float)(-g * rs * rs * S1);
   coef[2 * C + c] = (float)(-g * rs * S0 + g * rs * rs * mu * S1);
@@ -349,11 +354,11 @@ int kodhip_bn_finalize_partials(const float* partials, int T, double count, cons
 
 int kodhip_bn_bwd_coeffs_partials(const float* partials, int T, double count, const float* gamma, const float* mean,
                                   const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
-                                  hipStream_t stream) {
+                                  int raw_moment, hipStream_t stream) {
   KOD_CHECK_ARG(partials && gamma && mean && rstd && dgamma && dbeta && coef && C > 0 && T > 0 && count > 0,
                 "bn_bwd_coeffs_partials: bad args");
   hipLaunchKernelGGL(bn_bwd_coeffs_fused_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, T, count, gamma,
-                     mean, rstd, dgamma, dbeta, coef, C);
+                     mean, rstd, dgamma, dbeta, coef, C, raw_moment);
   KOD_LAUNCH_CHECK("bn_bwd_coeffs_partials");
   return KOD_OK;
 }
@@ -396,11 +401,11 @@ int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y
 
 int kodhip_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const float* gamma,
                          const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
-                         hipStream_t stream) {
+                         int raw_moment, hipStream_t stream) {
   KOD_CHECK_ARG(sums_local && sums_global && gamma && mean && rstd && dgamma && dbeta && coef && C > 0 && count > 0,
                 "bn_bwd_coeffs: bad args");
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, sums_local, sums_global, count,
-                     gamma, mean, rstd, dgamma, dbeta, coef, C);
+                     gamma, mean, rstd, dgamma, dbeta, coef, C, raw_moment);
   KOD_LAUNCH_CHECK("bn_bwd_coeffs");
   return KOD_OK;
 }

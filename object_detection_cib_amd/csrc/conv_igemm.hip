@@ -25,7 +25,13 @@
 
 namespace {
 
-enum { MODE_RAW = 0, MODE_PLAIN = 1, MODE_HEAD = 2 };
+enum { MODE_RAW = 0, MODE_PLAIN = 1, MODE_HEAD = 2, MODE_PLAIN_BN = 3 };
+
+// MODE_PLAIN_BN: a data-gradient launch that is the LAST writer of some conv units' output gradients also produces
+// their BatchNorm-backward reduction (sum dz, sum dz*y per channel) in its epilogue - the tile it has just written
+// is the dA operand of that reduction, so the separate pass over (dA, y) disappears.  A segment = the channel range
+// of the launch's output that belongs to one such unit.
+constexpr int MAX_SEG = 3;
 
 struct ConvArgs {
   const bf16_t* x;
@@ -46,6 +52,12 @@ struct ConvArgs {
   int tiles_m, tiles_n, groups_m, stats_slots;
   float rcp_hwo, rcp_wo;       // reciprocals for the row -> (b, oy, ox) decomposition (m < 2^24: one fix-up step)
   uint32_t x_bytes, w_bytes;   // FAST path: byte extents of the gather source / weight pack (buffer descriptors)
+  // MODE_PLAIN_BN (stats_slots = slot capacity of every seg_part buffer)
+  int nseg, slot_base, slot_used;
+  int seg_begin[MAX_SEG], seg_end[MAX_SEG], seg_ldr[MAX_SEG], seg_C[MAX_SEG];
+  const bf16_t* seg_raw[MAX_SEG];      // the unit's pre-BN output y [M_out][ldr]
+  const float* seg_aff[MAX_SEG];       // scale[C] | shift[C]
+  float* seg_part[MAX_SEG];            // [2][C][stats_slots]: sum dz | sum dz*y
 };
 
 // q = n / d, r = n % d via a float reciprocal + fix-up (exact: the loops absorb the fp32 rounding of large n)
@@ -109,6 +121,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   float ssum[8], ssq[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
+  float bn_run = 0.f;                        // MODE_PLAIN_BN: running sum of (channel tid>>1, statistic tid&1)
 
   const int nk = a.Kp / BK;
   // FAST path (Cin % 32 == 0, unit tap stride, no K tail): operands come through raw buffer loads - the tap of a
@@ -406,6 +419,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       const int c = tid % CPR;
       const int r0 = tid / CPR;
       const int n = n0 + c * 8;
+      // MODE_PLAIN_BN: this thread's 8 channels belong to at most one segment (boundaries are multiples of 8)
+      const bf16_t* sg_raw = nullptr;
+      int sg_ldr = 0;
+      float sg_sc[8], sg_sh[8];
+      if constexpr (MODE == MODE_PLAIN_BN) {
+#pragma unroll
+        for (int sgi = 0; sgi < MAX_SEG; ++sgi)
+          if (sgi < a.nseg && n >= a.seg_begin[sgi] && n < a.seg_end[sgi]) {
+            const int cl = n - a.seg_begin[sgi];
+            sg_raw = a.seg_raw[sgi] + cl;
+            sg_ldr = a.seg_ldr[sgi];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sg_sc[e] = a.seg_aff[sgi][cl + e]; sg_sh[e] = a.seg_aff[sgi][a.seg_C[sgi] + cl + e]; }
+          }
+      }
 #pragma unroll
       for (int p = 0; p < BM / RPP; ++p) {
         int row = r0 + p * RPP;
@@ -413,7 +441,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         if (m < a.M && n < a.N) {
           bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS_ROW + c * 8);
           size_t opix = (size_t)m;
-          if constexpr (MODE == MODE_PLAIN) {
+          if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
             if (a.out_mul != 1) {
               int b = m / HWo;
               int rem = m - b * HWo;
@@ -423,11 +451,27 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             }
           }
           bf16_t* dst = a.y + opix * a.ldy + a.ycoff + n;
-          if constexpr (MODE == MODE_PLAIN) {
+          if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
             if (a.accumulate) {
               bf16x8 o = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)o[e]);
+            }
+            if constexpr (MODE == MODE_PLAIN_BN) {
+              if (sg_raw) {     // dz = dA * silu'(z), z = y*scale + shift, on the value as stored (bf16)
+                bf16x8 yv = *reinterpret_cast<const bf16x8*>(sg_raw + opix * sg_ldr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float y = (float)yv[e];
+                  const float z = y * sg_sc[e] + sg_sh[e];
+                  const float d = 1.0f + __expf(-z);
+                  float r = __builtin_amdgcn_rcpf(d);
+                  r = r * (2.0f - d * r);
+                  const float dz = (float)v[e] * r * (1.f + z * (1.f - r));
+                  ssum[e] += dz;
+                  ssq[e] += dz * y;
+                }
+              }
             }
           } else {
 #pragma unroll
@@ -441,9 +485,50 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         }
       }
       __syncthreads();
+      if constexpr (MODE == MODE_PLAIN_BN) {
+        // fold this tile's sums into one running value per (channel, statistic), held by thread tid < 2*BN: the
+        // 16 per-thread accumulators then live only inside the epilogue, where the MFMA accumulators are dead
+        // (fixed order: rows by shuffle, waves 0..NW-1 by the owner thread => deterministic)
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            ssum[e] += __shfl_xor(ssum[e], o, 64);
+            ssq[e] += __shfl_xor(ssq[e], o, 64);
+          }
+        if (lane < CPR) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            sred[(wave * BN + lane * 8 + e) * 2 + 0] = ssum[e];
+            sred[(wave * BN + lane * 8 + e) * 2 + 1] = ssq[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+        __syncthreads();
+        if (tid < BN * 2) {
+          const int ch = tid >> 1, st = tid & 1;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) bn_run += sred[(w * BN + ch) * 2 + st];
+        }
+        __syncthreads();      // the next tile's DMA overwrites sred
+      }
     }
   }
 
+  if constexpr (MODE == MODE_PLAIN_BN) {
+    if (tid < BN * 2) {
+      const int ch = tid >> 1, st = tid & 1;
+      const int nn = n0 + ch;
+#pragma unroll
+      for (int sgi = 0; sgi < MAX_SEG; ++sgi)
+        if (sgi < a.nseg && nn >= a.seg_begin[sgi] && nn < a.seg_end[sgi]) {
+          float* slot = a.seg_part[sgi] + ((size_t)st * a.seg_C[sgi] + (nn - a.seg_begin[sgi])) * a.stats_slots;
+          slot[a.slot_base + gm] = bn_run;
+          for (int t = a.slot_base + gm + a.slot_used; t < a.stats_slots; t += a.slot_used) slot[t] = 0.f;
+        }
+    }
+  }
   if constexpr (MODE == MODE_RAW) {
     constexpr int CPR = BN / 8;
 #pragma unroll
@@ -479,7 +564,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ || WAVES_M * WAVES_N > 4 ? 2 : (FAST ? 4 : 3)))
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ ? 2 : (FAST ? 4 : 3)))   /* waves per SIMD */
 void conv_igemm_kernel(ConvArgs a) {
   conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(a, blockIdx.x);
 }
@@ -490,7 +575,7 @@ void conv_igemm_kernel(ConvArgs a) {
 struct ConvArgs4 { ConvArgs c[4]; };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ || WAVES_M * WAVES_N > 4 ? 2 : (FAST ? 4 : 3)))
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ ? 2 : (FAST ? 4 : 3)))   /* waves per SIMD */
 void conv_igemm_x4_kernel(ConvArgs4 p) {
   const int bid = blockIdx.x;
   const int cls = (bid >> 3) & 3;
@@ -554,12 +639,18 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   if (MODE == MODE_RAW) {
     KOD_CHECK_ARG(a.stats_slots >= p.groups_m, "conv: stats buffer has %d slots, launch needs %d", a.stats_slots, p.groups_m);
   }
+  if (MODE == MODE_PLAIN_BN) {
+    KOD_CHECK_ARG(a.stats_slots >= p.groups_m, "conv: partial buffers have %d slots, launch needs %d", a.stats_slots, p.groups_m);
+    args.slot_base = 0; args.slot_used = p.groups_m;
+  }
   dim3 g(p.grid);
   if (fast) {
     if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
     else if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE, true>), g, dim3(256), 0, stream, args);
     else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE, true>), g, dim3(256), 0, stream, args);
     else hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, args);
+  } else if constexpr (MODE == MODE_PLAIN_BN) {
+    KOD_CHECK_ARG(false, "conv: the fused BatchNorm-backward reduction needs the FAST path (query the slots first)");
   } else {
     if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE, false>), g, dim3(256), 0, stream, args);
     else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE, false>), g, dim3(256), 0, stream, args);
@@ -570,7 +661,8 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 }
 
 // one launch for four FAST problems that share M, N and the tile plan (chosen for the longest reduction)
-int launch_x4_plain(ConvArgs c[4], hipStream_t stream) {
+template <int MODE>
+int launch_x4(ConvArgs c[4], hipStream_t stream) {
   ConvArgs4 p;
   int kmax = 0;
   for (int i = 0; i < 4; ++i) kmax = c[i].K > kmax ? c[i].K : kmax;
@@ -580,12 +672,16 @@ int launch_x4_plain(ConvArgs c[4], hipStream_t stream) {
     p.c[i].x_bytes = (uint32_t)((long)c[i].B * c[i].Hs * c[i].Ws * c[i].ldx * 2);
     p.c[i].w_bytes = (uint32_t)((long)c[i].N * c[i].Kp * 2);
     p.c[i].tiles_n = pl.tiles_n; p.c[i].tiles_m = pl.tiles_m; p.c[i].groups_m = pl.groups_m;
+    if (MODE == MODE_PLAIN_BN) {      // the four classes reduce into disjoint slot ranges of the same buffers
+      KOD_CHECK_ARG(c[i].stats_slots >= 4 * pl.groups_m, "conv: partial buffers have %d slots, launch needs %d", c[i].stats_slots, 4 * pl.groups_m);
+      p.c[i].slot_base = i * pl.groups_m; p.c[i].slot_used = 4 * pl.groups_m;
+    }
   }
   dim3 g(pl.grid * 4);
-  if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE_PLAIN, true>), g, dim3(512), 0, stream, p);
-  else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE_PLAIN, true>), g, dim3(256), 0, stream, p);
-  else if (pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 2, MODE_PLAIN, true>), g, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 32, 4, 1, MODE_PLAIN, true>), g, dim3(256), 0, stream, p);
+  if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
+  else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true>), g, dim3(256), 0, stream, p);
+  else if (pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 2, MODE, true>), g, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, p);
   KOD_LAUNCH_CHECK("conv_igemm_x4");
   return KOD_OK;
 }
@@ -660,13 +756,29 @@ int kodhip_conv_fwd_head(const void* x, const void* w_packed, const float* bias,
   return launch<MODE_HEAD>(a, stream);
 }
 
-// Data gradient: dx[B][H][W][ldx](+xcoff, Cin channels) (+)= conv_transpose(dy[B][Ho][Wo][ldy](+ycoff, N), w).
-// w_dgrad is packed [Cin][Kp] with k = (kh, kw, n).
-int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
-                      int B, int H, int W, int ldx, int xcoff, int Cin,
-                      int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
-                      int ldy, int ycoff, int accumulate, hipStream_t stream) {
-  ConvArgs a = {};
+// ---- data gradient ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct BnRedSeg { int ch_begin, ch_count; const void* raw; int ldr; const float* aff; float* partials; };
+
+int set_segments(ConvArgs& a, const BnRedSeg* segs, int nseg, int slots, int out_channels) {
+  KOD_CHECK_ARG(segs && nseg >= 1 && nseg <= MAX_SEG && slots > 0, "conv_dgrad_bnred: 1..%d segments and a slot count expected", MAX_SEG);
+  a.nseg = nseg; a.stats_slots = slots;
+  for (int i = 0; i < nseg; ++i) {
+    const BnRedSeg& g = segs[i];
+    KOD_CHECK_ARG(g.raw && g.aff && g.partials && g.ch_count > 0 && g.ch_begin >= 0 && g.ch_begin % 8 == 0 && g.ch_count % 8 == 0 &&
+                  g.ch_begin + g.ch_count <= out_channels && g.ldr % 8 == 0 && g.ldr >= g.ch_count, "conv_dgrad_bnred: bad segment %d", i);
+    a.seg_begin[i] = g.ch_begin; a.seg_end[i] = g.ch_begin + g.ch_count; a.seg_ldr[i] = g.ldr; a.seg_C[i] = g.ch_count;
+    a.seg_raw[i] = (const bf16_t*)g.raw; a.seg_aff[i] = g.aff; a.seg_part[i] = g.partials;
+  }
+  return KOD_OK;
+}
+
+int prep_dgrad(ConvArgs& a, const void* dy, const void* w_dgrad, void* dx, int B, int H, int W, int ldx, int xcoff, int Cin,
+               int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp, int ldy, int ycoff, int accumulate) {
+  a = ConvArgs{};
   int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
   // gather source is dy (channels N per tap), output pixels are the input pixels of the forward conv
   int rc = fill_common(a, dy, w_dgrad, B, Ho, Wo, ldy, ycoff, N, H, W, Cin, KH, KW, Kp);
@@ -677,21 +789,16 @@ int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
   KOD_CHECK_ARG(ssh >= 0 && ssw >= 0, "conv_dgrad: stride must be a power of two");
   a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff; a.accumulate = accumulate;
   a.mul_h = 1; a.mul_w = 1; a.add_h = PH; a.add_w = PW; a.tap_sign = -1; a.sh_shift = ssh; a.sw_shift = ssw;
-  return launch<MODE_PLAIN>(a, stream);
+  return KOD_OK;
 }
 
-// Data gradient of a 3x3 / stride 2 / pad 1 convolution, decomposed by output-pixel parity: class (py,px)
-// only meets taps kh = 1 (py=0) or kh in {0,2} (py=1) (same for kw), so the four classes are stride-1 gathers
-// with 1, 2, 2 and 4 taps - 9 taps of MFMA work instead of 36.  w_dgrad_s2 holds the four class packs
-// back to back: class c = 2*py+px is [Cin][Kdp_c], Kdp_c = round_up(ntaps_c * N, 32), k = (kh', kw', n).
-int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
-                         int B, int H, int W, int ldx, int xcoff, int Cin, int N,
-                         int ldy, int ycoff, int accumulate, hipStream_t stream) {
+// the four parity classes of a 3x3 / stride 2 / pad 1 data gradient (see kodhip_conv_dgrad_s2)
+int prep_dgrad_s2(ConvArgs cls[4], bool& all_fast, const void* dy, const void* w_dgrad_s2, void* dx, int B, int H, int W,
+                  int ldx, int xcoff, int Cin, int N, int ldy, int ycoff, int accumulate) {
   KOD_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "conv_dgrad_s2: input dims must be even");
   const int Ho = H / 2, Wo = W / 2;
   size_t woff = 0;
-  ConvArgs cls[4];
-  bool all_fast = !getenv("KODHIP_S2_SEPARATE");
+  all_fast = !getenv("KODHIP_S2_SEPARATE");
   for (int c = 0; c < 4; ++c) {
     const int py = c >> 1, px = c & 1;
     const int KH = 1 + py, KW = 1 + px;
@@ -708,12 +815,86 @@ int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
     all_fast = all_fast && fast_eligible(a);
     woff += (size_t)Cin * Kp;
   }
-  if (all_fast) return launch_x4_plain(cls, stream);
-  for (int c = 0; c < 4; ++c) {
-    int rc = launch<MODE_PLAIN>(cls[c], stream);
-    if (rc) return rc;
-  }
   return KOD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Data gradient: dx[B][H][W][ldx](+xcoff, Cin channels) (+)= conv_transpose(dy[B][Ho][Wo][ldy](+ycoff, N), w).
+// w_dgrad is packed [Cin][Kp] with k = (kh, kw, n).
+int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
+                      int B, int H, int W, int ldx, int xcoff, int Cin,
+                      int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                      int ldy, int ycoff, int accumulate, hipStream_t stream) {
+  ConvArgs a;
+  if (int rc = prep_dgrad(a, dy, w_dgrad, dx, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, accumulate)) return rc;
+  return launch<MODE_PLAIN>(a, stream);
+}
+
+// Data gradient of a 3x3 / stride 2 / pad 1 convolution, decomposed by output-pixel parity: class (py,px)
+// only meets taps kh = 1 (py=0) or kh in {0,2} (py=1) (same for kw), so the four classes are stride-1 gathers
+// with 1, 2, 2 and 4 taps - 9 taps of MFMA work instead of 36.  w_dgrad_s2 holds the four class packs
+// back to back: class c = 2*py+px is [Cin][Kdp_c], Kdp_c = round_up(ntaps_c * N, 32), k = (kh', kw', n).
+int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
+                         int B, int H, int W, int ldx, int xcoff, int Cin, int N,
+                         int ldy, int ycoff, int accumulate, hipStream_t stream) {
+  ConvArgs cls[4];
+  bool all_fast;
+  if (int rc = prep_dgrad_s2(cls, all_fast, dy, w_dgrad_s2, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate)) return rc;
+  if (all_fast) return launch_x4<MODE_PLAIN>(cls, stream);
+  for (int c = 0; c < 4; ++c)
+    if (int rc = launch<MODE_PLAIN>(cls[c], stream)) return rc;
+  return KOD_OK;
+}
+
+// ---- data gradient + BatchNorm-backward reduction of the units whose output gradient this launch completes.
+// The launch must be the LAST writer of dx's channel ranges named by the segments; per segment it leaves
+// partials[2][ch_count][slots] = per-block sums of dz and dz*y (dz = dx * silu'(y*scale + shift)), which
+// kodhip_bn_bwd_coeffs_partials(..., raw_moment = 1) turns into the BatchNorm-backward coefficients.
+// *_slots: slots a launch of this geometry writes (allocate partials with exactly that many); 0 = this geometry
+// cannot carry the fused reduction (run kodhip_bn_silu_bwd_reduce instead).  stride2 = the 3x3/s2/p1 form.
+int kodhip_conv_dgrad_bnred_slots(int B, int H, int W, int Cin, int N, int KH, int KW, int SH, int SW, int PH, int PW,
+                                  int ldy, int stride2) {
+  const void* fake = (const void*)64;      // never dereferenced: only the launch plan is computed
+  if (getenv("KODHIP_NO_BNRED")) return 0;
+  if (stride2) {
+    ConvArgs cls[4];
+    bool all_fast;
+    if (prep_dgrad_s2(cls, all_fast, fake, fake, (void*)fake, B, H, W, Cin, 0, Cin, N, ldy, 0, 0) || !all_fast) return 0;
+    int kmax = 0;
+    for (int i = 0; i < 4; ++i) kmax = cls[i].K > kmax ? cls[i].K : kmax;
+    return 4 * make_plan(cls[0].M, cls[0].N, kmax, true).groups_m;
+  }
+  ConvArgs a;
+  const int Kp = (KH * KW * N + 31) / 32 * 32;
+  if (prep_dgrad(a, fake, fake, (void*)fake, B, H, W, Cin, 0, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, 0, 0) || !fast_eligible(a)) return 0;
+  return make_plan(a.M, a.N, a.K, true).groups_m;
+}
+
+int kodhip_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* dx,
+                            int B, int H, int W, int ldx, int xcoff, int Cin,
+                            int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                            int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                            hipStream_t stream) {
+  ConvArgs a;
+  if (int rc = prep_dgrad(a, dy, w_dgrad, dx, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, accumulate)) return rc;
+  if (int rc = set_segments(a, (const BnRedSeg*)segments, nseg, slots, Cin)) return rc;
+  return launch<MODE_PLAIN_BN>(a, stream);
+}
+
+int kodhip_conv_dgrad_s2_bnred(const void* dy, const void* w_dgrad_s2, void* dx,
+                               int B, int H, int W, int ldx, int xcoff, int Cin, int N,
+                               int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                               hipStream_t stream) {
+  ConvArgs cls[4];
+  bool all_fast;
+  if (int rc = prep_dgrad_s2(cls, all_fast, dy, w_dgrad_s2, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate)) return rc;
+  KOD_CHECK_ARG(all_fast, "conv_dgrad_s2_bnred: this geometry cannot carry the fused reduction (query the slots first)");
+  for (int c = 0; c < 4; ++c)
+    if (int rc = set_segments(cls[c], (const BnRedSeg*)segments, nseg, slots, Cin)) return rc;
+  return launch_x4<MODE_PLAIN_BN>(cls, stream);
 }
 
 }  // extern "C"

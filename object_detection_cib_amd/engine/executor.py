@@ -31,7 +31,8 @@ def _pad(n: int, a: int = 64) -> int:
 
 class _UnitState:
     __slots__ = ("u", "w_off", "g_off", "b_off", "f_off", "d_off", "Kp", "Kdp", "rs_off", "stats", "T",
-                 "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho", "Wo")
+                 "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho", "Wo",
+                 "fused_red", "segs", "seg_slots")
 
 
 class Engine:
@@ -229,6 +230,7 @@ class Engine:
             st.coef = torch.empty(3 * u.cout, dtype=torch.float32, device=dev)
             splits = lib.kodhip_conv_wgrad_splits(st.M, u.cout, st.Kp)
             max_part = max(max_part, splits * u.cout * st.Kp)
+        self._plan_bn_fusion(B)
         for h in self.g.heads:
             hs = self.hstate[h.name]
             hh, ww = H // h.stride, W // h.stride
@@ -244,6 +246,66 @@ class Engine:
             if op.kind == "pool":
                 h, w = H // op.src.stride, W // op.src.stride
                 self.pool_idx.append(torch.empty((B, h, w, op.src.C), dtype=torch.uint8, device=dev))
+
+    def _plan_bn_fusion(self, B: int):
+        """Static analysis of the backward program: for every conv unit U find the LAST launch that writes U's
+        output-gradient slice before U's own BatchNorm backward.  When that launch is a (FAST-path) data gradient
+        whose output covers the slice, it also produces U's BN-backward reduction in its epilogue
+        (kodhip_conv_dgrad_bnred) and U skips its own reduce pass."""
+        lib = self.lib
+        for u in self.exec_units:
+            st = self.ustate[u.name]
+            st.fused_red, st.segs, st.seg_slots = False, None, 0
+        if os.environ.get("KODHIP_NO_BNRED") == "1":
+            return
+        writes, upos, pos = [], {}, 0      # (position, writer unit name | None, buffer, lo, hi)
+        for op in reversed(self.g.ops):
+            if op.kind == "conv":
+                u = op.unit
+                upos[u.name] = pos
+                pos += 1
+                if u.residual is not None:
+                    r = u.residual
+                    writes.append((pos, None, r.buf.name, r.coff, r.coff + r.C))
+                    pos += 1
+                if not u.stem:
+                    writes.append((pos, u.name, u.src.buf.name, u.src.coff, u.src.coff + u.src.C))
+                    pos += 1
+            else:
+                v = op.unit.src if op.kind == "head" else op.src
+                writes.append((pos, None, v.buf.name, v.coff, v.coff + v.C))
+                pos += 1
+        plan = {}
+        for u in self.exec_units:
+            lo, hi = u.dst.coff, u.dst.coff + u.dst.C
+            cand = [w for w in writes if w[0] < upos[u.name] and w[2] == u.dst.buf.name and w[3] < hi and w[4] > lo]
+            if not cand:
+                continue
+            last = max(cand, key=lambda w: w[0])
+            if last[1] is not None and last[3] <= lo and last[4] >= hi:
+                plan.setdefault(last[1], []).append((u, lo - last[3]))
+        units = {u.name: u for u in self.exec_units}
+        for wname, prods in plan.items():
+            w = units[wname]
+            ws = self.ustate[wname]
+            s2 = int(w.k == 3 and w.s == 2 and w.p == 1)
+            slots = lib.kodhip_conv_dgrad_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.k, w.k, w.s, w.s, w.p, w.p, w.cout, s2)
+            if slots <= 0:
+                continue
+            prods = prods[:3]                        # MAX_SEG of the kernel
+            segs = (_lib.KodBnRedSeg * len(prods))()
+            for i, (u, ch0) in enumerate(prods):
+                st = self.ustate[u.name]
+                st.fused_red, st.T2 = True, slots
+                st.bpart = torch.empty(2 * u.cout * slots, dtype=torch.float32, device=self.device)
+                segs[i].ch_begin, segs[i].ch_count = ch0, u.cout
+                segs[i].raw, segs[i].ldr = st.raw.data_ptr(), u.cout
+                segs[i].aff, segs[i].partials = st.aff.data_ptr(), st.bpart.data_ptr()
+            ws.segs, ws.seg_slots = segs, slots
+        if os.environ.get("KODHIP_DEBUG_PLAN"):
+            fused = [u.name for u in self.exec_units if self.ustate[u.name].fused_red]
+            print(f"[kodhip] BN-backward reduction fused into a data gradient for {len(fused)} of {len(self.exec_units)} units; "
+                  f"separate pass: {[u.name for u in self.exec_units if not self.ustate[u.name].fused_red]}", flush=True)
 
     # ------------------------------------------------------------------ helpers
     def _ptr(self, v: View, grad=False):
@@ -445,9 +507,11 @@ class Engine:
                 C_ = u.cout
                 aff = st.aff.data_ptr()
                 dA = u.dst
-                chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
-                                                  aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
-                                                  st.bpart.data_ptr(), st.M, C_, s), u.name)
+                rawm = 1 if st.fused_red else 0        # partials came from the last dgrad into this tensor
+                if not st.fused_red:
+                    chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
+                                                      aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
+                                                      st.bpart.data_ptr(), st.M, C_, s), u.name)
                 if self.sync_bn and self.collectives:
                     chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), C_, st.T2, s), u.name)
                     st.bsums_g.copy_(st.bsums)
@@ -455,11 +519,11 @@ class Engine:
                     chk(lib.kodhip_bn_bwd_coeffs(st.bsums.data_ptr(), st.bsums_g.data_ptr(),
                                                  float(st.M) * self.world_size, pa + 4 * st.g_off,
                                                  aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off, gp + 4 * st.b_off,
-                                                 st.coef.data_ptr(), C_, s), u.name)
+                                                 st.coef.data_ptr(), C_, rawm, s), u.name)
                 else:
                     chk(lib.kodhip_bn_bwd_coeffs_partials(st.bpart.data_ptr(), st.T2, float(st.M), pa + 4 * st.g_off,
                                                           aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off,
-                                                          gp + 4 * st.b_off, st.coef.data_ptr(), C_, s), u.name)
+                                                          gp + 4 * st.b_off, st.coef.data_ptr(), C_, rawm, s), u.name)
                 res = u.residual
                 chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
                                                  aff, aff + 4 * C_, st.coef.data_ptr(),
@@ -471,13 +535,16 @@ class Engine:
                     geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1)
                 else:
                     geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p)
+                    fz = () if st.segs is None else (C.cast(st.segs, C.c_void_p), len(st.segs), st.seg_slots)
                     if u.k == 3 and u.s == 2 and u.p == 1:
-                        chk(lib.kodhip_conv_dgrad_s2(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
-                                                     B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,
-                                                     acc_flag(u.src), s), u.name + ".dgrad")
+                        fn = lib.kodhip_conv_dgrad_s2 if st.segs is None else lib.kodhip_conv_dgrad_s2_bnred
+                        chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
+                               B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,
+                               acc_flag(u.src), *fz, s), u.name + ".dgrad")
                     else:
-                        chk(lib.kodhip_conv_dgrad(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
-                                                  *geo, st.Kdp, C_, 0, acc_flag(u.src), s), u.name + ".dgrad")
+                        fn = lib.kodhip_conv_dgrad if st.segs is None else lib.kodhip_conv_dgrad_bnred
+                        chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
+                               *geo, st.Kdp, C_, 0, acc_flag(u.src), *fz, s), u.name + ".dgrad")
                 chk(lib.kodhip_conv_wgrad(self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
                                           *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0, wgrad_stream()), u.name + ".wgrad")
             # gradient buckets complete from the arena's end toward its start

@@ -245,7 +245,7 @@ def test_bn_silu_fwd_bwd(C, res):
     _lib.check(lib.kodhip_bn_reduce_partials(bpart.data_ptr(), bs.data_ptr(), C, T2, stream()), "bwd sums")
     dg, dbt, coef = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(3 * C, device="cuda")
     _lib.check(lib.kodhip_bn_bwd_coeffs(bs.data_ptr(), bs.data_ptr(), float(M), gm.data_ptr(), a + 8 * C, a + 12 * C,
-                                        dg.data_ptr(), dbt.data_ptr(), coef.data_ptr(), C, stream()), "coeffs")
+                                        dg.data_ptr(), dbt.data_ptr(), coef.data_ptr(), C, 0, stream()), "coeffs")
     _close(dg.cpu(), bn.weight.grad, 5e-3, 5e-3 * bn.weight.grad.abs().max().item(), "dgamma")
     _close(dbt.cpu(), bn.bias.grad, 5e-3, 5e-3 * bn.bias.grad.abs().max().item(), "dbeta")
     di = torch.ones((B, H, W, C), dtype=torch.bfloat16, device="cuda") if res else None
