@@ -289,6 +289,9 @@ class Engine:
             w = units[wname]
             ws = self.ustate[wname]
             s2 = int(w.k == 3 and w.s == 2 and w.p == 1)
+            # (A/B knob: only fuse into launches whose reduction length is at least KODHIP_BNRED_MINK; measured best: all)
+            if w.k * w.k * w.cout < int(os.environ.get("KODHIP_BNRED_MINK", "0")):
+                continue
             slots = lib.kodhip_conv_dgrad_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.k, w.k, w.s, w.s, w.p, w.p, w.cout, s2)
             if slots <= 0:
                 continue
