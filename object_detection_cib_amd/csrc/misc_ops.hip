@@ -114,9 +114,11 @@ __global__ void maxpool5_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_t*
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = (bf16_t)best[e];
   *reinterpret_cast<bf16x8*>(y + p * ldy + ycoff + cc * 8) = o;
-  unsigned char* ip = idx + p * C + cc * 8;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ip[e] = bi[e];
+  // the 8 argmax bytes leave as one 8-byte store (C % 8 == 0 keeps it aligned)
+  uint2 packed;
+  packed.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+  packed.y = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+  *reinterpret_cast<uint2*>(idx + p * C + cc * 8) = packed;
 }
 
 // dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic)
@@ -144,12 +146,14 @@ __global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const 
       int ox = ix - dxx + 2;
       if (ox < 0 || ox >= W) continue;
       long op = (long)(b * H + oy) * W + ox;
-      const unsigned char* ip = idx + op * C + cc * 8;
+      const uint2 ib = *reinterpret_cast<const uint2*>(idx + op * C + cc * 8);     // 8 argmax bytes in one load
       bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + op * ldy + ycoff + cc * 8);
-      unsigned char want = (unsigned char)(dyy * 5 + dxx);
+      const uint32_t want = (uint32_t)(dyy * 5 + dxx);
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (ip[e] == want) acc[e] += (float)g[e];
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t byte = ((e < 4 ? ib.x : ib.y) >> (8 * (e & 3))) & 0xffu;
+        if (byte == want) acc[e] += (float)g[e];
+      }
     }
   }
   bf16x8 o;
