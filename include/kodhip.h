@@ -162,6 +162,12 @@ int kodhip_compose_desc_bytes(void);
 int kodhip_compose_batch(const void* pool, const void* descs, const float* mix, const void* bilinear_tab,
                          float* out_f32, void* out_pairs, int B, int S, kodStream_t stream);
 
+/* ---- validation pre-processing: SampleReader (LongestMaxSize + PadIfNeeded(114), kod/data/sample_reader.py:16-40,
+ *      102-136) + ValidationSampleAugmentor (ToFloat(255) + CHW, kod/data/augmentations/albu.py:91-119) ------------ */
+int kodhip_val_prep_desc_bytes(void);
+int kodhip_val_prep_batch(const void* pool, const void* descs /* device [B] */, float* out_f32, void* out_pairs,
+                          int B, int S, kodStream_t stream);
+
 /* ---- evaluation post-process (kod/lightning/experiments/yv5_baseline/layers.py:55-155, exp.py:70-102;
  *      kod/core/nms.py:9-75 + torchvision.ops.nms) -------------------------------------------------- */
 typedef struct KodDecodeLevel { const float* raw; int h, w, stride; float anchor_w[3], anchor_h[3]; } KodDecodeLevel;

@@ -72,6 +72,8 @@ SIGNATURES = {
     "kodhip_comm_broadcast": (i32, [vp, vp, i64, i32, vp]),
     "kodhip_compose_desc_bytes": (i32, []),
     "kodhip_compose_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "kodhip_val_prep_desc_bytes": (i32, []),
+    "kodhip_val_prep_batch": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_decode": (i32, [C.POINTER(KodDecodeLevel), vp, i32, i32, i32, vp]),
     "kodhip_nms": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, f32, vp]),
     "kodhip_map_match": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(f64), i32, i32, vp]),

@@ -259,3 +259,66 @@ class DeviceTrainPipeline:
 
 def desc_bytes() -> int:
     return _lib.lib().kodhip_compose_desc_bytes()
+
+
+# ------------------------------------------------------------------------------------------- validation batches
+VAL_DESC = np.dtype([("off", "<i8"), ("h", "<i4"), ("w", "<i4"), ("nh", "<i4"), ("nw", "<i4"), ("top", "<i4"),
+                     ("left", "<i4"), ("scale_x", "<f8"), ("scale_y", "<f8")], align=True)
+
+
+def _py3round(v: float) -> int:
+    """albumentations' py3round (geometric/functional.py): exact halves round away from zero."""
+    if abs(round(v) - v) == 0.5:
+        return int(2.0 * round(v / 2.0))
+    return int(round(v))
+
+
+def letterbox_geometry(h: int, w: int, S: int):
+    """(new_h, new_w, pad_top, pad_left) of A.LongestMaxSize(S) followed by A.PadIfNeeded(S, S), centre position
+    (kod/data/sample_reader.py:16-40)."""
+    scale = S / float(max(w, h))
+    nh, nw = (_py3round(h * scale), _py3round(w * scale)) if scale != 1.0 else (h, w)
+    top = int((S - nh) / 2.0) if nh < S else 0
+    left = int((S - nw) / 2.0) if nw < S else 0
+    return nh, nw, top, left
+
+
+class DeviceValPipeline:
+    """Validation batches on the GPU: SampleReader(letter_box=True) + ValidationSampleAugmentor
+    (kod/data/sample_reader.py:102-136, kod/data/augmentations/albu.py:91-119) for a pool of ORIGINAL-size u8
+    images resident in HBM - resize (cv2 INTER_LINEAR fixed point), pad 114, /255, CHW in one launch."""
+
+    def __init__(self, images: Sequence[np.ndarray], boxes: Sequence[np.ndarray], labels: Sequence[np.ndarray],
+                 target_image_size: int, device):
+        _lib.require_gpu()
+        assert _lib.lib().kodhip_val_prep_desc_bytes() == VAL_DESC.itemsize
+        self.S = int(target_image_size)
+        self.device = torch.device(device)
+        self.pool = ImagePool(images, self.device)
+        self.boxes, self.labels = list(boxes), list(labels)
+
+    def make_batch(self, batch_indices: Sequence[int], out_f32: bool = True, out_pairs: bool = False):
+        """Returns (images f32 [B,3,S,S] or None, pairs bf16 [B,S,S/2,8] or None, tuple of DetectionTarget)."""
+        B, S = len(batch_indices), self.S
+        descs = np.zeros(B, dtype=VAL_DESC)
+        targets = []
+        for k, i in enumerate(batch_indices):
+            h, w = self.pool.shapes[i]
+            nh, nw, top, left = letterbox_geometry(h, w, S)
+            d = descs[k]
+            d["off"], d["h"], d["w"], d["nh"], d["nw"], d["top"], d["left"] = self.pool.offsets[i], h, w, nh, nw, top, left
+            d["scale_x"], d["scale_y"] = 1.0 / (nw / float(w)), 1.0 / (nh / float(h))     # OpenCV: 1 / inv_scale
+            bb = np.asarray(self.boxes[i], dtype=np.float64).reshape(-1, 4).copy()
+            if bb.size:          # albumentations keeps boxes normalised through the resize; the pad shifts pixels
+                bb[:, [0, 2]] = bb[:, [0, 2]] / w * nw + left
+                bb[:, [1, 3]] = bb[:, [1, 3]] / h * nh + top
+            targets.append(DetectionTarget(torch.from_numpy(bb), torch.from_numpy(np.asarray(self.labels[i], dtype=np.int64))))
+        d_dev = torch.from_numpy(descs.view(np.uint8).reshape(-1)).to(self.device)
+        img = torch.empty((B, 3, S, S), dtype=torch.float32, device=self.device) if out_f32 else None
+        pairs = torch.empty((B, S, S // 2, 8), dtype=torch.bfloat16, device=self.device) if out_pairs else None
+        _lib.check(_lib.lib().kodhip_val_prep_batch(self.pool.data.data_ptr(), d_dev.data_ptr(),
+                                                    img.data_ptr() if out_f32 else None,
+                                                    pairs.data_ptr() if out_pairs else None, B, S,
+                                                    torch.cuda.current_stream().cuda_stream), "val_prep_batch")
+        self._keep = d_dev
+        return img, pairs, tuple(targets)

@@ -302,3 +302,78 @@ def train_sample(cache, idx, S, rng: np.random.Generator, mixup_prob=0.0, rnd=ra
         img = mixup_blend(torch.from_numpy(img), torch.from_numpy(img2), r).numpy()
         bb, lb = np.concatenate((bb, bb2), 0), np.concatenate((lb, lb2), 0)
     return img, bb, lb
+
+
+# ----------------------------------------------------------------------------- validation pre-processing
+# kod/data/sample_reader.py:16-40,102-136 (albumentations LongestMaxSize(INTER_LINEAR) + PadIfNeeded(114)) followed
+# by ValidationSampleAugmentor (kod/data/augmentations/albu.py:91-119: ToFloat(255) + HWC->CHW).
+# Third-party arithmetic absent from this image (albumentations 1.3.x, opencv-python 4.x): restated from their
+# published algorithms, PARITY UNPINNED like the other OpenCV restatements above.
+def _py3round(v: float) -> int:
+    """albumentations.augmentations.geometric.functional.py3round: round half away from zero on exact .5."""
+    if abs(round(v) - v) == 0.5:
+        return int(2.0 * round(v / 2.0))
+    return int(round(v))
+
+
+def _resize_coeffs(n_src: int, n_dst: int):
+    """OpenCV resize.cpp (INTER_LINEAR, 8-bit): per destination index the left source index and the two
+    11-bit fixed-point weights.  fx = (float)((d + 0.5) * scale - 0.5), s = floor(fx), fx -= s; s < 0 -> (0, fx = 0);
+    s >= n_src - 1 -> (n_src - 1, fx = 0) [HResize uses S[s]*2048 there, VResize clamps both rows]."""
+    scale = 1.0 / (n_dst / float(n_src))                  # scale_x = 1. / inv_scale_x, inv_scale_x = dsize / ssize
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    return s, f
+
+
+def resize_linear_u8(src: np.ndarray, w_out: int, h_out: int) -> np.ndarray:
+    """cv2.resize(src, (w_out, h_out), interpolation=cv2.INTER_LINEAR) for u8 HWC."""
+    h, w = src.shape[:2]
+    sx, fx = _resize_coeffs(w, w_out)
+    lo = sx < 0
+    hi = sx >= w - 1
+    fx = np.where(lo | hi, np.float32(0), fx)
+    sx = np.where(lo, 0, np.where(hi, w - 1, sx))
+    a0 = np.clip(np.rint((np.float32(1) - fx).astype(np.float64) * 2048), -32768, 32767).astype(np.int64)
+    a1 = np.clip(np.rint(fx.astype(np.float64) * 2048), -32768, 32767).astype(np.int64)
+    sx1 = np.minimum(sx + 1, w - 1)
+    sy, fy = _resize_coeffs(h, h_out)
+    b0 = np.clip(np.rint((np.float32(1) - fy).astype(np.float64) * 2048), -32768, 32767).astype(np.int64)
+    b1 = np.clip(np.rint(fy.astype(np.float64) * 2048), -32768, 32767).astype(np.int64)
+    r0 = np.clip(sy, 0, h - 1)
+    r1 = np.clip(sy + 1, 0, h - 1)
+    s = src.astype(np.int64)
+    hrow = s[:, sx, :] * a0[None, :, None] + s[:, sx1, :] * a1[None, :, None]          # [h, w_out, c], 11-bit
+    S0, S1 = hrow[r0], hrow[r1]
+    out = ((((b0[:, None, None] * (S0 >> 4)) >> 16) + ((b1[:, None, None] * (S1 >> 4)) >> 16) + 2) >> 2)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def val_geometry(h: int, w: int, S: int):
+    """(new_h, new_w, pad_top, pad_left) of LongestMaxSize(S) + PadIfNeeded(S, S) (centre position)."""
+    scale = S / float(max(w, h))
+    if scale != 1.0:
+        nh, nw = _py3round(h * scale), _py3round(w * scale)
+    else:
+        nh, nw = h, w
+    top = int((S - nh) / 2.0) if nh < S else 0
+    left = int((S - nw) / 2.0) if nw < S else 0
+    return nh, nw, top, left
+
+
+def val_sample(img: np.ndarray, boxes: np.ndarray, S: int):
+    """SampleReader.__call__(letter_box=True) + ValidationSampleAugmentor: (f32 [3,S,S], boxes xyxy px f64)."""
+    h, w = img.shape[:2]
+    nh, nw, top, left = val_geometry(h, w, S)
+    res = resize_linear_u8(img, nw, nh) if (nh, nw) != (h, w) else img
+    canvas = np.full((S, S, 3), 114, dtype=np.uint8)
+    canvas[top:top + nh, left:left + nw] = res
+    out = (canvas.astype(np.float32) / np.float32(255.0)).transpose(2, 0, 1)
+    b = np.asarray(boxes, dtype=np.float64).reshape(-1, 4).copy()
+    if b.size:
+        # albumentations keeps boxes normalised: x / cols survives the resize, then the pad shifts the pixel value
+        b[:, [0, 2]] = b[:, [0, 2]] / w * nw + left
+        b[:, [1, 3]] = b[:, [1, 3]] / h * nh + top
+    return out, b

@@ -61,3 +61,28 @@ def test_full_size_properties():
     canvas, *_ = datapath.mosaic([cache[i] for i in idx], S, random)
     crop = canvas[S // 2:S // 2 + S, S // 2:S // 2 + S].transpose(2, 0, 1).astype(np.float32) / np.float32(255)
     np.testing.assert_array_equal(a[k].cpu().numpy(), crop)
+
+
+def test_validation_preprocessing_bit_exact():
+    """Device resize + letter-box + /255 (kod/data/sample_reader.py SampleReader(letter_box=True) +
+    ValidationSampleAugmentor) against the oracle's OpenCV / albumentations restatement: pixels bit-exact (integer
+    fixed-point arithmetic), boxes to 1e-12.  Landscape, portrait, square, up- and down-scaling, exact size."""
+    from oracle import datapath as D
+    from object_detection_cib_amd.data.device_pipeline import DeviceValPipeline
+    rng = np.random.default_rng(5)
+    S = 128
+    shapes = [(96, 128), (128, 96), (128, 128), (333, 500), (500, 375), (37, 53), (64, 64), (200, 127), (2, 300), (481, 640)]
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    boxes = [np.array([[1.5, 2.0, w * 0.6, h * 0.7], [w * 0.2, h * 0.1, w - 1.0, h - 1.0]]) for h, w in shapes]
+    labels = [np.array([1, 2]) for _ in shapes]
+    pipe = DeviceValPipeline(imgs, boxes, labels, S, "cuda")
+    img, pairs, tg = pipe.make_batch(list(range(len(shapes))), out_f32=True, out_pairs=True)
+    torch.cuda.synchronize()
+    for k, (im, bb) in enumerate(zip(imgs, boxes)):
+        want, wb = D.val_sample(im, bb, S)
+        got = img[k].cpu().numpy()
+        assert np.array_equal(got, want), (shapes[k], np.abs(got - want).max())
+        np.testing.assert_allclose(tg[k].boxes.numpy(), wb, rtol=0, atol=1e-12)
+        pr = pairs[k].float().cpu().numpy().reshape(S, S, 4)
+        np.testing.assert_array_equal(pr[..., :3], torch.from_numpy(want).permute(1, 2, 0).to(torch.bfloat16).float().numpy())
+        assert (pr[..., 3] == 0).all()

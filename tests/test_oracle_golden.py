@@ -178,3 +178,28 @@ def test_affine_boxes_flip_mixup(golden):
     a = torch.arange(24, dtype=torch.float32).reshape(3, 2, 4) / 24
     b = torch.arange(24, dtype=torch.float32).flip(0).reshape(3, 2, 4) / 24
     np.testing.assert_array_equal(datapath.mixup_blend(a, b, r).numpy(), g["mixup_image"])
+
+
+def test_val_preprocessing_restatement_properties():
+    """The OpenCV-resize / albumentations letter-box restatement (parity unpinned: neither library is in the image):
+    identity at equal size, constants stay constant, agreement with float bilinear (half-pixel centres) to < 1 LSB,
+    geometry of LongestMaxSize + centred PadIfNeeded."""
+    import torch.nn.functional as F
+    from oracle import datapath as D
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(D.resize_linear_u8(img, 53, 37), img)
+    assert (D.resize_linear_u8(np.full((10, 14, 3), 77, np.uint8), 28, 20) == 77).all()
+    t = torch.from_numpy(img).permute(2, 0, 1)[None].float()
+    for hw in ((74, 106), (28, 40), (37, 200), (111, 53)):
+        ref = F.interpolate(t, size=hw, mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        got = D.resize_linear_u8(img, hw[1], hw[0]).astype(np.float64)
+        assert np.abs(got - ref).max() < 1.0, hw
+    assert D.val_geometry(480, 640, 640) == (480, 640, 80, 0)
+    assert D.val_geometry(333, 500, 640) == (426, 640, 107, 0)
+    assert D.val_geometry(1000, 750, 640) == (640, 480, 0, 80)
+    out, b = D.val_sample(img, np.array([[1.0, 2.0, 30.0, 20.0]]), 64)
+    assert out.shape == (3, 64, 64) and out.dtype == np.float32
+    assert out[0, 0, 0] == np.float32(114) / np.float32(255)           # padded border row
+    nh, nw, top, left = D.val_geometry(37, 53, 64)
+    np.testing.assert_allclose(b, [[1.0 / 53 * nw + left, 2.0 / 37 * nh + top, 30.0 / 53 * nw + left, 20.0 / 37 * nh + top]])
