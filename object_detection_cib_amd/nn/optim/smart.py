@@ -12,6 +12,7 @@ class SmartSGD:
             raise NotImplementedError("the fused kernel implements nesterov=True (reference config)")
         self.net = net
         self.world_size = world_size
+        self.steps_taken = 0          # torch keeps no momentum_buffer before the first step (checkpoint layout)
         self.param_groups = [
             dict(name="bias_params", lr=lr, initial_lr=lr, momentum=momentum, weight_decay=0.0, nesterov=True),
             dict(name="decay_params", lr=lr, initial_lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True),
@@ -29,3 +30,13 @@ class SmartSGD:
         g = self.param_groups
         self.net.engine().sgd_step([float(x["lr"]) for x in g], [float(x["momentum"]) for x in g],
                                    [float(x["weight_decay"]) for x in g], 1.0 / self.world_size)
+        self.steps_taken += 1
+
+    def state_dict(self):
+        """torch.optim.SGD.state_dict() layout (lightning/checkpoint.py)."""
+        from ...lightning.checkpoint import optimizer_state_dict
+        return optimizer_state_dict(self.net, self)
+
+    def load_state_dict(self, sd):
+        from ...lightning.checkpoint import load_optimizer_state_dict
+        load_optimizer_state_dict(self.net, self, sd)

@@ -146,3 +146,22 @@ def test_samplers_and_schedule_host_mirrors(golden):
     a = list(iter(rs))
     rs2 = S.RepeatFactorSampler([1.0, 2.0, 1.0, 4.0])
     assert a == list(iter(rs2)) and len(a) == 4
+
+
+def test_checkpoint_optimizer_param_order_matches_smart_optimizer():
+    """lightning/checkpoint.py numbers parameters like torch.optim.SGD built by SmartOptimizer (smart.py:20-60):
+    bias | decay | norm groups, module-walk order - checked against the oracle's grouping of the oracle network,
+    and a torch SGD over those groups accepts a state dict in our layout."""
+    import torch
+    from object_detection_cib_amd.nn.networks.yolov5 import Yolov5Network
+    from object_detection_cib_amd.lightning.checkpoint import optimizer_param_order
+    from oracle.network import OracleYolov5
+    from oracle import optim as O
+    net = Yolov5Network(3, 10, widen_factor=0.25, deepen_factor=0.33)
+    groups = optimizer_param_order(net)
+    assert [len(g) for g in groups] == [66, 66, 57]
+    ora = OracleYolov5(3, 10, 0.25, 0.33)
+    names = {id(p): k for k, p in ora.named_parameters()}
+    for mine, theirs in zip(groups, O.param_groups(ora)):
+        assert mine == [names[id(p)] for p in theirs]
+    assert list(net.state_dict().keys()) == list(ora.state_dict().keys())
