@@ -52,6 +52,7 @@ struct ConvArgs {
   int tiles_m, tiles_n, groups_m, stats_slots;
   float rcp_hwo, rcp_wo;       // reciprocals for the row -> (b, oy, ox) decomposition (m < 2^24: one fix-up step)
   uint32_t x_bytes, w_bytes;   // FAST path: byte extents of the gather source / weight pack (buffer descriptors)
+  int wide_px;                 // FAST path: a tap reads Cin = wide_px * ldx channels = wide_px consecutive pixels (stem)
   // MODE_PLAIN_BN (stats_slots = slot capacity of every seg_part buffer)
   int nseg, slot_base, slot_used;
   int seg_begin[MAX_SEG], seg_end[MAX_SEG], seg_ldr[MAX_SEG], seg_C[MAX_SEG];
@@ -190,9 +191,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         int by = oy * a.mul_h + a.add_h, bx = ox * a.mul_w + a.add_w;
         int chunk = (lane & 3) ^ ((row >> 2) & 3);
         dvoff[i] = (uint32_t)(((long)(b * HWs + by * a.Ws + bx) * a.ldx + a.xcoff + chunk * 8) * 2);
+        // wide pixels (stem: a 32-value K step spans 4 consecutive 8-channel pixel pairs): this lane's 16-byte
+        // chunk belongs to pixel bx + chunk*8/ldx, which has its own left/right padding test
+        const int bxl = a.wide_px > 1 ? bx + (chunk * 8) / a.ldx : bx;
         uint32_t xm = 0, mk = 0;
         for (int kw = 0; kw < a.KW; ++kw)
-          if ((unsigned)(bx + a.tap_sign * kw) < (unsigned)a.Ws) xm |= 1u << kw;
+          if ((unsigned)(bxl + a.tap_sign * kw) < (unsigned)a.Ws) xm |= 1u << kw;
         for (int kh = 0; kh < a.KH; ++kh)
           if ((unsigned)(by + a.tap_sign * kh) < (unsigned)a.Hs) mk |= xm << (kh * a.KW);
         dmask[i] = valid ? mk : 0u;
@@ -633,6 +637,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   ConvArgs args = a;
   const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, wb = (long)a.N * a.Kp * 2;
   const bool fast = fast_eligible(a);
+  KOD_CHECK_ARG(fast || a.wide_px == 1, "conv: wide-pixel taps need the FAST path");
   args.x_bytes = (uint32_t)xb; args.w_bytes = (uint32_t)wb;
   const Plan p = make_plan(a.M, a.N, a.K, fast);
   args.tiles_n = p.tiles_n; args.tiles_m = p.tiles_m; args.groups_m = p.groups_m;
@@ -711,7 +716,10 @@ static int fill_common(ConvArgs& a, const void* x, const void* w, int B, int Hs,
   KOD_CHECK_ARG(x && w, "conv: null pointer");
   KOD_CHECK_ARG(B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0 && N > 0, "conv: bad dims");
   KOD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0, "conv: channels must be multiples of 8 (Cin=%d ldx=%d off=%d)", Cin, ldx, xcoff);
-  KOD_CHECK_ARG(xcoff + Cin <= ldx, "conv: channel slice out of range");
+  // a tap may span several consecutive pixels (Cin = wide * ldx, one column of taps): the stem's pixel-pair window
+  const bool wide = Cin > ldx && xcoff == 0 && Cin % ldx == 0 && KW == 1 && Cin == 32;
+  KOD_CHECK_ARG(xcoff + Cin <= ldx || wide, "conv: channel slice out of range");
+  a.wide_px = wide ? Cin / ldx : 1;
   KOD_CHECK_ARG(Kp % 32 == 0 && Kp >= KH * KW * Cin, "conv: Kp=%d must be a multiple of 32 covering K=%d", Kp, KH * KW * Cin);
   KOD_CHECK_ARG(KH * KW <= 32, "conv: at most 32 taps");
   KOD_CHECK_ARG((long)B * Hs * Ws < (1l << 31) / 1 && (long)B * Ho * Wo < (1l << 31), "conv: pixel count overflows int32");
@@ -730,7 +738,10 @@ int kodhip_conv_fwd_raw(const void* x, const void* w_packed, void* y, float* sta
                         int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
                         int ldy, int ycoff, hipStream_t stream) {
   ConvArgs a = {};
-  int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
+  // wide-pixel form (the stem: Cin = 32 = four 8-channel pixel pairs per tap, KW = 1): the window's last pixel is
+  // K-alignment padding with zero weights, so the true kernel width for the output size is Cin/ldx - 1
+  const int kw_out = (Cin > ldx && KW == 1) ? Cin / ldx - 1 : KW;
+  int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - kw_out) / SW + 1;
   int rc = fill_common(a, x, w_packed, B, H, W, ldx, xcoff, Cin, Ho, Wo, N, KH, KW, Kp);
   if (rc) return rc;
   KOD_CHECK_ARG(y && stats, "conv_fwd_raw: null output");

@@ -27,7 +27,8 @@ struct PackDesc {          // all int64 so the host can fill it as a plain int64
   long N, Cin, KH, KW;     // true weight dims [N][Cin][KH][KW]
   long Kp, Kdp;            // padded row lengths of the two packs
   long Ntot, n_off;        // dgrad pack: channels per tap (padded total) and this weight's first channel
-  long stem;               // 1: 6x6/s2 stem in pixel-pair form, k = (kh, kw', dx, c4); 2: 3x3/s2 parity-class dgrad packs
+  long stem;               // 1: 6x6/s2 stem in pixel-pair form, k = kh*32 + kw'*8 + dx*4 + c (kw' = 0..2 of a 4-pair,
+                           //    32-value window: the 4th pair's weights stay zero); 2: 3x3/s2 parity-class dgrad packs
   long blk_begin;          // first block of this descriptor in the grid
 };
 
@@ -54,7 +55,7 @@ __global__ void pack_weights_kernel(const float* master, bf16_t* fpack, bf16_t* 
   bf16_t v = (bf16_t)master[d.w_off + local];
   if (d.stem == 1) {
     long kh = tap / 6, kw = tap - kh * 6;
-    long k = (kh * 3 + (kw >> 1)) * 8 + (kw & 1) * 4 + ci;
+    long k = kh * 32 + (kw >> 1) * 8 + (kw & 1) * 4 + ci;
     fpack[d.f_off + n * d.Kp + k] = v;
   } else {
     fpack[d.f_off + n * d.Kp + tap * d.Cin + ci] = v;

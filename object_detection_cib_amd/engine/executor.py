@@ -32,7 +32,7 @@ def _pad(n: int, a: int = 64) -> int:
 class _UnitState:
     __slots__ = ("u", "w_off", "g_off", "b_off", "f_off", "d_off", "Kp", "Kdp", "rs_off", "stats", "T",
                  "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho", "Wo",
-                 "fused_red", "segs", "seg_slots")
+                 "fused_red", "segs", "seg_slots", "Kp_f")
 
 
 class Engine:
@@ -138,10 +138,13 @@ class Engine:
             st = _UnitState()
             st.u = u
             K = u.k * u.k * u.cin if not u.stem else 144
-            st.Kp = _pad(K, 32)
+            st.Kp = _pad(K, 32)                       # K of the weight-gradient slabs (stem: 6x3 taps x 8 = 144 -> 160)
+            # forward operand rows: the stem packs each kernel row as one 32-value K step (4 pixel pairs, the 4th
+            # zero) so that it runs on the LDS-DMA path like every other layer
+            st.Kp_f = 6 * 32 if u.stem else st.Kp
             st.Kdp = _pad(u.k * u.k * u.cout, 32)
             st.f_off, st.d_off = foff, (-1 if u.stem else doff)
-            foff += u.cout * st.Kp
+            foff += u.cout * st.Kp_f
             s2 = (not u.stem) and u.k == 3 and u.s == 2 and u.p == 1
             if s2:
                 doff += u.cin * sum(_pad(nt * u.cout, 32) for nt in (1, 2, 2, 4))
@@ -152,7 +155,7 @@ class Engine:
             st.b_off = layout[u.name + ".1.bias"][0]
             st.rs_off = self.rs_layout[u.name]
             if u.stem:
-                add_desc(u.name + ".0.weight", st.f_off, -1, u.cout, 3, 6, 6, st.Kp, 0, 0, 0, 1)
+                add_desc(u.name + ".0.weight", st.f_off, -1, u.cout, 3, 6, 6, st.Kp_f, 0, 0, 0, 1)
             else:
                 add_desc(u.name + ".0.weight", st.f_off, st.d_off, u.cout, u.cin, u.k, u.k, st.Kp, st.Kdp,
                          u.cout, 0, 2 if s2 else 0)
@@ -353,7 +356,7 @@ class Engine:
                 st = self.ustate[u.name]
                 C_ = u.cout
                 if u.stem:
-                    geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1, st.Kp)
+                    geo = (B, st.H, st.W, 8, 0, 32, C_, 6, 1, 2, 1, 2, 1, st.Kp_f)      # wide-pixel form, see Kp_f
                 else:
                     geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p, st.Kp)
                 if self.profile is not None:

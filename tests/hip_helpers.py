@@ -34,7 +34,7 @@ def pack(weights, stem=False, ntot=None, s2=False):
     lib = _lib.lib()
     N = sum(w.shape[0] for w in weights)
     Cin, KH, KW = weights[0].shape[1:]
-    K = 144 if stem else KH * KW * Cin
+    K = 192 if stem else KH * KW * Cin          # stem: 6 kernel rows x (4 pixel pairs x 8), the 4th pair zero
     Kp = pad(K, 32)
     Ntot = ntot or N
     Kdp = pad(KH * KW * Ntot, 32)

@@ -119,9 +119,10 @@ def test_conv_channel_slices():
 
 
 def test_stem_conv():
-    """6x6/s2/p2 stem on a 3-channel image through the pixel-pair layout."""
+    """6x6/s2/p2 stem on a 3-channel image through the pixel-pair layout (forward: wide-pixel FAST form, one 32-value
+    K step = four 8-channel pixel pairs per kernel row)."""
     g = torch.Generator().manual_seed(9)
-    B, H, W, Cout = 2, 32, 64, 32
+    B, H, W, Cout = 2, 32, 72, 32            # 36 pixel pairs per row: ragged tiles, both horizontal borders
     x = bf(torch.rand(B, 3, H, W, generator=g))
     w = bf(torch.randn(Cout, 3, 6, 6, generator=g) / 10)
     xr, wr = x.clone(), w.clone().requires_grad_(True)
@@ -136,15 +137,16 @@ def test_stem_conv():
     T = lib.kodhip_conv_stats_slots(B * (H // 2) * (W // 2), Cout)
     stats = torch.zeros(2 * Cout * T, dtype=torch.float32, device="cuda")
     _lib.check(lib.kodhip_conv_fwd_raw(img.data_ptr(), pk["f"].data_ptr(), out.data_ptr(), stats.data_ptr(),
-                                       B, H, W // 2, 8, 0, 8, Cout, 6, 3, 2, 1, 2, 1, pk["Kp"], Cout, 0, stream()), "stem")
+                                       B, H, W // 2, 8, 0, 32, Cout, 6, 1, 2, 1, 2, 1, pk["Kp"], Cout, 0, stream()), "stem")
     _close(nchw(out), y.detach(), 1e-2, 2e-2, "stem fwd")
     dyb = nhwc(dy)
     M = B * (H // 2) * (W // 2)
-    splits = lib.kodhip_conv_wgrad_splits(M, Cout, pk["Kp"])
-    part = torch.zeros(splits * Cout * pk["Kp"], dtype=torch.float32, device="cuda")
+    Kw = 160                                   # weight-gradient slabs keep the 6x3-tap x 8-channel K (144 -> 160)
+    splits = lib.kodhip_conv_wgrad_splits(M, Cout, Kw)
+    part = torch.zeros(splits * Cout * Kw, dtype=torch.float32, device="cuda")
     gw = torch.zeros_like(w, device="cuda")
     _lib.check(lib.kodhip_conv_wgrad(img.data_ptr(), dyb.data_ptr(), part.data_ptr(), gw.data_ptr(), B, H, W // 2, 8, 0,
-                                     8, Cout, 6, 3, 2, 1, 2, 1, pk["Kp"], Cout, 0, Cout, 1, 1.0, stream()), "stem wgrad")
+                                     8, Cout, 6, 3, 2, 1, 2, 1, Kw, Cout, 0, Cout, 1, 1.0, stream()), "stem wgrad")
     _close(gw.cpu(), wr.grad, 2e-3, 2e-3 * wr.grad.abs().max().item(), "stem wgrad")
 
 
