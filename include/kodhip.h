@@ -101,17 +101,17 @@ int kodhip_bn_bwd_coeffs_partials(const float* partials, int T, double count, co
                                   const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
                                   int raw_moment /* 1: partials[1] = sum dz*y (kodhip_conv_dgrad_bnred) */,
                                   kodStream_t stream);
-int kodhip_bn_silu_apply(const void* y, const float* scale, const float* shift,
+int kodhip_bn_silu_apply(const void* y, int ldy /* row stride of y (>= C: y may be a channel slice) */, const float* scale, const float* shift,
                          const void* residual, int ldr, int rcoff,
                          void* out, int ldo, int ocoff, long M, int C, kodStream_t stream);
 int kodhip_bn_bwd_slots(long M, int C);
-int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, const float* scale,
+int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, int ldy, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* partials,
                               long M, int C, kodStream_t stream);
 int kodhip_bn_bwd_coeffs(const double* sums_local, const double* sums_global, double count, const float* gamma,
                          const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
                          int raw_moment, kodStream_t stream);
-int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, const float* scale,
+int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, int ldy, const float* scale,
                              const float* shift, const float* coef, void* dI, int ldi, int dicoff, int di_accum,
                              long M, int C, kodStream_t stream);
 

@@ -123,7 +123,7 @@ __device__ __forceinline__ float fast_sigmoid(float z) {
 
 // ---------------------------------------------------------------- forward apply
 // out[m][ocoff + c] = silu(y[m][c]*scale[c] + shift[c]) (+ res[m][rcoff + c])
-__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, const float* scale, const float* shift,
+__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, int ldy, const float* scale, const float* shift,
                                      const bf16_t* res, int ldr, int rcoff,
                                      bf16_t* out, int ldo, int ocoff, long M, int C, int rows_per_block_iter) {
   const int CC = C >> 3;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, con
     for (int u = 0; u < U; ++u) {
       const long m = m0 + u * stride;
       if (m < M) {
-        v[u] = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+        v[u] = *reinterpret_cast<const bf16x8*>(y + m * ldy + cc * 8);
         if (res) r[u] = *reinterpret_cast<const bf16x8*>(res + m * ldr + rcoff + cc * 8);
       }
     }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, con
 // ---------------------------------------------------------------- backward reduce
 // dz = dA * silu'(z), z = y*scale + shift ; xhat = (y - mean)*rstd
 // part[0][c][blk] = sum dz ; part[1][c][blk] = sum dz*xhat
-__global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const bf16_t* dA, int lda, int dacoff, const bf16_t* y,
+__global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const bf16_t* dA, int lda, int dacoff, const bf16_t* y, int ldy,
                                           const float* scale, const float* shift, const float* mean,
                                           const float* rstd, float* part, long M, int C, int rpb) {
   extern __shared__ float sm[];   // [rpb][CC][16]
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const bf16_t* d
         const long m = m0 + u * stride;
         if (m < M) {
           g[u] = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
-          v[u] = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+          v[u] = *reinterpret_cast<const bf16x8*>(y + m * ldy + cc * 8);
         }
       }
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ void bn_bwd_coeffs_kernel(const double* sums_local, const double* sum
 }
 
 // dY (bf16, written in place over y) ; optional identity gradient: dI[m][c] (+)= dA[m][c]
-__global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, bf16_t* y,
+__global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, bf16_t* y, int ldy,
                                          const float* scale, const float* shift, const float* coef,
                                          bf16_t* dI, int ldi, int dicoff, int di_accum,
                                          long M, int C, int rpb) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA
       const long m = m0 + u * stride;
       if (m < M) {
         g[u] = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
-        v[u] = *reinterpret_cast<const bf16x8*>(y + m * C + cc * 8);
+        v[u] = *reinterpret_cast<const bf16x8*>(y + m * ldy + cc * 8);
         if (acc) old[u] = *reinterpret_cast<const bf16x8*>(dI + m * ldi + dicoff + cc * 8);
       }
     }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA
         float dz = (float)g[u][e] * sg * (1.f + z * (1.f - sg));
         o[e] = (bf16_t)(k1[e] * dz + k2[e] * yv + k3[e]);
       }
-      *reinterpret_cast<bf16x8*>(y + m * C + cc * 8) = o;
+      *reinterpret_cast<bf16x8*>(y + m * ldy + cc * 8) = o;
       if (dI) {
         bf16x8 gi = g[u];
         if (acc) {
@@ -363,14 +363,15 @@ int kodhip_bn_bwd_coeffs_partials(const float* partials, int T, double count, co
   return KOD_OK;
 }
 
-int kodhip_bn_silu_apply(const void* y, const float* scale, const float* shift,
+int kodhip_bn_silu_apply(const void* y, int ldy, const float* scale, const float* shift,
                          const void* residual, int ldr, int rcoff,
                          void* out, int ldo, int ocoff, long M, int C, hipStream_t stream) {
   KOD_CHECK_ARG(y && scale && shift && out && M > 0, "bn_silu_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldo % 8 == 0 && ocoff % 8 == 0 && ocoff + C <= ldo, "bn_silu_apply: bad channel geometry");
   KOD_CHECK_ARG(!residual || (ldr % 8 == 0 && rcoff % 8 == 0 && rcoff + C <= ldr), "bn_silu_apply: bad residual slice");
   Geo g = geo(M, C, 4096);
-  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, scale, shift,
+  KOD_CHECK_ARG(ldy % 8 == 0 && ldy >= C, "bn_silu_apply: bad row stride of y");
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, ldy, scale, shift,
                      (const bf16_t*)residual, ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb);
   KOD_LAUNCH_CHECK("bn_silu_apply");
   return KOD_OK;
@@ -386,15 +387,16 @@ static int bwd_reduce_blocks(long M, int C) {
 
 int kodhip_bn_bwd_slots(long M, int C) { return geo(M, C, bwd_reduce_blocks(M, C)).grid; }
 
-int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, const float* scale,
+int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, int ldy, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* partials,
                               long M, int C, hipStream_t stream) {
   KOD_CHECK_ARG(dA && y && scale && shift && mean && rstd && partials && M > 0, "bn_silu_bwd_reduce: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda, "bn_silu_bwd_reduce: bad geometry");
   Geo g = geo(M, C, bwd_reduce_blocks(M, C));
   size_t shm = (size_t)g.rpb * (C / 8) * 16 * sizeof(float);
+  KOD_CHECK_ARG(ldy % 8 == 0 && ldy >= C, "bn_silu_bwd_reduce: bad row stride of y");
   hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(g.grid), dim3(g.threads), shm, stream, (const bf16_t*)dA, lda,
-                     dacoff, (const bf16_t*)y, scale, shift, mean, rstd, partials, M, C, g.rpb);
+                     dacoff, (const bf16_t*)y, ldy, scale, shift, mean, rstd, partials, M, C, g.rpb);
   KOD_LAUNCH_CHECK("bn_silu_bwd_reduce");
   return KOD_OK;
 }
@@ -410,15 +412,16 @@ int kodhip_bn_bwd_coeffs(const double* sums_local, const double* sums_global, do
   return KOD_OK;
 }
 
-int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, const float* scale,
+int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, int ldy, const float* scale,
                              const float* shift, const float* coef, void* dI, int ldi, int dicoff, int di_accum,
                              long M, int C, hipStream_t stream) {
   KOD_CHECK_ARG(dA && y_inout && scale && shift && coef && M > 0, "bn_silu_bwd_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda, "bn_silu_bwd_apply: bad geometry");
   KOD_CHECK_ARG(!dI || (ldi % 8 == 0 && dicoff % 8 == 0 && dicoff + C <= ldi), "bn_silu_bwd_apply: bad identity slice");
   Geo g = geo(M, C, 4096);
+  KOD_CHECK_ARG(ldy % 8 == 0 && ldy >= C, "bn_silu_bwd_apply: bad row stride of y");
   hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)dA, lda, dacoff,
-                     (bf16_t*)y_inout, scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb);
+                     (bf16_t*)y_inout, ldy, scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb);
   KOD_LAUNCH_CHECK("bn_silu_bwd_apply");
   return KOD_OK;
 }

@@ -32,7 +32,7 @@ def _pad(n: int, a: int = 64) -> int:
 class _UnitState:
     __slots__ = ("u", "w_off", "g_off", "b_off", "f_off", "d_off", "Kp", "Kdp", "rs_off", "stats", "T",
                  "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho", "Wo",
-                 "fused_red", "segs", "seg_slots", "Kp_f")
+                 "fused_red", "segs", "seg_slots", "Kp_f", "raw_ld")
 
 
 class Engine:
@@ -222,6 +222,7 @@ class Engine:
                 st.Ho, st.Wo = st.H // u.s, st.W // u.s
             st.M = B * st.Ho * st.Wo
             st.raw = torch.empty((B, st.Ho, st.Wo, u.cout), dtype=torch.bfloat16, device=dev)
+            st.raw_ld = u.cout                         # row stride of raw (pre-BN output / dY)
             st.T = lib.kodhip_conv_stats_slots(st.M, u.cout)
             st.stats = torch.empty(2 * u.cout * st.T, dtype=torch.float32, device=dev)
             st.sums = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
@@ -386,7 +387,7 @@ class Engine:
                 else:
                     self._eval_affine(st)
                 res = u.residual
-                chk(lib.kodhip_bn_silu_apply(st.raw.data_ptr(), aff, aff + 4 * C_,
+                chk(lib.kodhip_bn_silu_apply(st.raw.data_ptr(), st.raw_ld, aff, aff + 4 * C_,
                                              self._ptr(res) if res else None, res.buf.C if res else 0,
                                              res.coff if res else 0,
                                              self._ptr(u.dst), u.dst.buf.C, u.dst.coff, st.M, C_, s), u.name)
@@ -515,7 +516,7 @@ class Engine:
                 dA = u.dst
                 rawm = 1 if st.fused_red else 0        # partials came from the last dgrad into this tensor
                 if not st.fused_red:
-                    chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
+                    chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
                                                       aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
                                                       st.bpart.data_ptr(), st.M, C_, s), u.name)
                 if self.sync_bn and self.collectives:
@@ -531,7 +532,7 @@ class Engine:
                                                           aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off,
                                                           gp + 4 * st.b_off, st.coef.data_ptr(), C_, rawm, s), u.name)
                 res = u.residual
-                chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(),
+                chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
                                                  aff, aff + 4 * C_, st.coef.data_ptr(),
                                                  self._ptr(res, True) if res else None,
                                                  res.buf.C if res else 0, res.coff if res else 0,

@@ -53,7 +53,7 @@ def test_library_loads_and_reports(built):
     assert h.kodhip_pack_desc_bytes() == 13 * 8
     assert h.kodhip_device_count() >= 0
     # argument validation happens before any launch, so it is testable without a GPU
-    rc = h.kodhip_bn_silu_apply(None, None, None, None, 0, 0, None, 0, 0, 0, 0, None)
+    rc = h.kodhip_bn_silu_apply(None, 0, None, None, None, 0, 0, None, 0, 0, 0, 0, None)
     assert rc < 0 and b"bn_silu_apply" in h.kodhip_last_error()
     rc = h.kodhip_conv_fwd_raw(1, 1, 1, 1, 1, 8, 8, 12, 0, 12, 8, 1, 1, 1, 1, 0, 0, 32, 8, 0, None)
     assert rc < 0 and b"multiples of 8" in h.kodhip_last_error()

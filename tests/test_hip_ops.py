@@ -233,7 +233,7 @@ def test_bn_silu_fwd_bwd(C, res):
     ldo = C + 16
     ob = torch.zeros((B, H, W, ldo), dtype=torch.bfloat16, device="cuda")
     ib = nhwc(ident) if res else None
-    _lib.check(lib.kodhip_bn_silu_apply(yb.data_ptr(), a, a + 4 * C, ib.data_ptr() if res else None, C, 0,
+    _lib.check(lib.kodhip_bn_silu_apply(yb.data_ptr(), C, a, a + 4 * C, ib.data_ptr() if res else None, C, 0,
                                         ob.data_ptr(), ldo, 8, M, C, stream()), "apply")
     _close(nchw(ob)[:, 8:8 + C], out.detach(), 1e-2, 1e-2, "bn+silu fwd")
     # backward
@@ -241,7 +241,7 @@ def test_bn_silu_fwd_bwd(C, res):
     dob[..., 8:8 + C] = nhwc(dout)
     T2 = lib.kodhip_bn_bwd_slots(M, C)
     bpart = torch.zeros(2 * C * T2, device="cuda")
-    _lib.check(lib.kodhip_bn_silu_bwd_reduce(dob.data_ptr(), ldo, 8, yb.data_ptr(), a, a + 4 * C, a + 8 * C, a + 12 * C,
+    _lib.check(lib.kodhip_bn_silu_bwd_reduce(dob.data_ptr(), ldo, 8, yb.data_ptr(), C, a, a + 4 * C, a + 8 * C, a + 12 * C,
                                              bpart.data_ptr(), M, C, stream()), "bwd reduce")
     bs = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
     _lib.check(lib.kodhip_bn_reduce_partials(bpart.data_ptr(), bs.data_ptr(), C, T2, stream()), "bwd sums")
@@ -251,7 +251,7 @@ def test_bn_silu_fwd_bwd(C, res):
     _close(dg.cpu(), bn.weight.grad, 5e-3, 5e-3 * bn.weight.grad.abs().max().item(), "dgamma")
     _close(dbt.cpu(), bn.bias.grad, 5e-3, 5e-3 * bn.bias.grad.abs().max().item(), "dbeta")
     di = torch.ones((B, H, W, C), dtype=torch.bfloat16, device="cuda") if res else None
-    _lib.check(lib.kodhip_bn_silu_bwd_apply(dob.data_ptr(), ldo, 8, yb.data_ptr(), a, a + 4 * C, coef.data_ptr(),
+    _lib.check(lib.kodhip_bn_silu_bwd_apply(dob.data_ptr(), ldo, 8, yb.data_ptr(), C, a, a + 4 * C, coef.data_ptr(),
                                             di.data_ptr() if res else None, C, 0, 1, M, C, stream()), "bwd apply")
     _close(nchw(yb), yr.grad, 2e-2, 2e-2 * yr.grad.abs().max().item(), "dY")
     if res:
