@@ -40,20 +40,26 @@ class _Joined:
 
 
 def launch_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, stream=None, comm=None, also_after=None):
-    """Sum all-reduce of a contiguous arena slice, overlapped with the caller's stream.
+    """Sum all-reduce of a contiguous arena slice.
 
-    On the GPU the collective goes on a side stream that first waits for the caller's stream - the dependency
-    lives in stream order only, so the same code is hipGraph-capturable - through the native RCCL communicator
-    `comm` (engine/comm.py), or synchronously through torch.distributed when there is none (gloo-backed GPU
-    tests).  CPU tensors (host-logic tests): a plain async_op Work."""
-    if flat.is_cuda and stream is not None:
-        stream.wait_stream(torch.cuda.current_stream())
+    GPU tensors: through the native RCCL communicator `comm` (engine/comm.py), or through torch.distributed when
+    there is none (gloo-backed GPU tests).  With `stream` (a side stream) the collective overlaps the caller's
+    stream: the side stream first waits for the caller's stream and for `also_after` (the weight-gradient stream
+    that fills this bucket) - dependencies live in stream order only, so the code is hipGraph-capturable.  Without
+    `stream` the collective is enqueued on the caller's stream itself: every collective of the step is then in ONE
+    stream order, identical on all ranks - the conservative default (Engine.comm_overlap).
+    CPU tensors (host-logic tests): a plain async_op Work."""
+    if flat.is_cuda:
+        cur = torch.cuda.current_stream()
+        target = stream if stream is not None else cur
+        if stream is not None:
+            stream.wait_stream(cur)
         if also_after is not None:           # e.g. the weight-gradient stream that fills this bucket
-            stream.wait_stream(also_after)
+            target.wait_stream(also_after)
         if comm is not None:
-            comm.all_reduce(flat[lo:hi], stream.cuda_stream)
+            comm.all_reduce(flat[lo:hi], target.cuda_stream)
         else:
-            with torch.cuda.stream(stream):
+            with torch.cuda.stream(target):
                 torch.distributed.all_reduce(flat[lo:hi], group=group)
         return _Joined(stream)
     return torch.distributed.all_reduce(flat[lo:hi], group=group, async_op=True)

@@ -54,6 +54,7 @@ class Engine:
         self.wgrad_overlap = os.environ.get("KODHIP_WGRAD_OVERLAP", "1") != "0"
         self.comm = None               # RcclComm when the process group is RCCL-backed (the product path)
         self.comm_stream = None        # side stream of the gradient-bucket all-reduces
+        self.comm_overlap = os.environ.get("KODHIP_COMM_OVERLAP", "0") == "1"
         self.collectives = False       # True when gradients / BN sums go through the process group (world > 1)
         self.bucket_bytes = 8 << 20
         self._pending = []
@@ -566,6 +567,12 @@ class Engine:
         self._publish_grads()
 
     def _comm_stream(self):
+        """Side stream of the gradient-bucket all-reduces, or None: by default every collective of the step (SyncBN
+        sums and gradient buckets) is enqueued on the main stream, i.e. in one order that is the same on all ranks
+        by construction.  KODHIP_COMM_OVERLAP=1 moves the buckets to a side stream (overlapped with the rest of
+        backward; collectives of one communicator then come from two streams)."""
+        if not self.comm_overlap:
+            return None
         if self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=self.device)
         return self.comm_stream
