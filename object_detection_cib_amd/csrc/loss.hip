@@ -321,9 +321,15 @@ __global__ __launch_bounds__(256) void loss_cells_kernel(LossArgs a) {
   const float u_obj = a.upstream ? a.upstream[1] : 1.f;
   const float kobj = a.lam_obj * u_obj * L.balance / (float)ncells;
   float acc = 0.f;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    long cell = e / a.P;
-    int slot = (int)(e - cell * a.P);
+  // (cell, slot) of the grid-stride index is carried, not divided out: one 64-bit division per thread, not per element
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long stride_cells = stride / a.P;
+  const int stride_slot = (int)(stride - stride_cells * a.P);
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long cell = e / a.P;
+  int slot = (int)(e - cell * a.P);
+  for (; e < total; e += stride, cell += stride_cells, slot += stride_slot) {
+    if (slot >= a.P) { slot -= a.P; ++cell; }
     float g = 0.f;
     if (slot == 4) {
       float x = L.logits[e];
