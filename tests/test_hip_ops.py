@@ -321,3 +321,76 @@ def test_sgd_nesterov():
             pk = refp[sl]
             refb[k] = O.sgd_nesterov_step(pk, gr[sl] * 0.5, refb[k], lr[gi], mom[gi], wd[gi])
     _close(pc.cpu(), refp, 1e-6, 1e-6, "sgd")
+
+
+@pytest.mark.parametrize("case", [
+    # B, Cin (dX channels), H, W, Cout (dY channels), k, s, p, producer channel split of dX
+    (2, 64, 24, 20, 64, 3, 1, 1, (64,)),            # one producer owns the whole output
+    (2, 128, 16, 12, 32, 1, 1, 0, (64, 64)),        # concat buffer: two producers, short reduction
+    (3, 96, 10, 14, 64, 1, 1, 0, (32, 64)),         # ragged split, segment boundary inside a 128-wide tile
+    (2, 64, 16, 24, 128, 3, 2, 1, (32, 32)),        # stride-2 form (four parity classes share the slot range)
+    (4, 128, 72, 64, 128, 3, 1, 1, (128,)),         # M = 18432 rows, K = 1152: 256-pixel tiles
+])
+def test_conv_dgrad_with_fused_bn_backward_reduction(case):
+    """kodhip_conv_dgrad_bnred / _s2_bnred: the data gradient is unchanged, and the per-segment partials (sum dz,
+    sum dz*y), turned into coefficients with raw_moment=1, equal the separate reduce pass over the same tensors."""
+    from object_detection_cib_amd._lib import KodBnRedSeg
+    import ctypes as C
+    B, Cin, H, W, Cout, k, s, p, split = case
+    g = torch.Generator().manual_seed(sum(case[:8]))
+    x = bf(torch.randn(B, Cin, H, W, generator=g)).requires_grad_(True)
+    w = bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    y = F.conv2d(x, w, None, s, p)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    lib = _lib.lib()
+    s2 = (k, s, p) == (3, 2, 1)
+    pk = pack([w], s2=s2)
+    dyb = nhwc(dy)
+    M = B * H * W
+    slots = lib.kodhip_conv_dgrad_bnred_slots(B, H, W, Cin, Cout, k, k, s, s, p, p, Cout, int(s2))
+    assert slots > 0
+    # producers of dX's channel ranges: pre-BN tensors + BN constants
+    prods, ch0 = [], 0
+    for c in split:
+        raw = bf(torch.randn(B, c, H, W, generator=g))
+        aff = torch.cat([torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3,      # scale, shift
+                         torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5]).cuda()   # mean, rstd
+        prods.append(dict(c=c, ch0=ch0, raw=nhwc(raw), aff=aff,
+                          part=torch.full((2 * c * slots,), float("nan"), device="cuda"),
+                          gamma=(torch.rand(c, generator=g) + 0.5).cuda()))
+        ch0 += c
+    segs = (KodBnRedSeg * len(prods))()
+    for i, pr in enumerate(prods):
+        segs[i].ch_begin, segs[i].ch_count = pr["ch0"], pr["c"]
+        segs[i].raw, segs[i].ldr = pr["raw"].data_ptr(), pr["c"]
+        segs[i].aff, segs[i].partials = pr["aff"].data_ptr(), pr["part"].data_ptr()
+    dxb = torch.zeros((B, H, W, Cin), dtype=torch.bfloat16, device="cuda")
+    sp = C.cast(segs, C.c_void_p)
+    if s2:
+        _lib.check(lib.kodhip_conv_dgrad_s2_bnred(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
+                                                  Cout, Cout, 0, 0, sp, len(prods), slots, stream()), "dgrad_s2_bnred")
+    else:
+        _lib.check(lib.kodhip_conv_dgrad_bnred(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
+                                               Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 0, sp, len(prods), slots,
+                                               stream()), "dgrad_bnred")
+    _close(nchw(dxb), x.grad, 1e-2, 3e-2, "dX of the fused launch")
+    for pr in prods:
+        c = pr["c"]
+        a = pr["aff"].data_ptr()
+        out_f = [torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(3 * c, device="cuda")]
+        _lib.check(lib.kodhip_bn_bwd_coeffs_partials(pr["part"].data_ptr(), slots, float(M), pr["gamma"].data_ptr(),
+                                                     a + 8 * c, a + 12 * c, out_f[0].data_ptr(), out_f[1].data_ptr(),
+                                                     out_f[2].data_ptr(), c, 1, stream()), "coeffs fused")
+        # the separate pass over the very same (dX slice, raw) tensors
+        T2 = lib.kodhip_bn_bwd_slots(M, c)
+        bpart = torch.zeros(2 * c * T2, device="cuda")
+        _lib.check(lib.kodhip_bn_silu_bwd_reduce(dxb.data_ptr(), Cin, pr["ch0"], pr["raw"].data_ptr(), c, a, a + 4 * c,
+                                                 a + 8 * c, a + 12 * c, bpart.data_ptr(), M, c, stream()), "reduce")
+        out_s = [torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(3 * c, device="cuda")]
+        _lib.check(lib.kodhip_bn_bwd_coeffs_partials(bpart.data_ptr(), T2, float(M), pr["gamma"].data_ptr(),
+                                                     a + 8 * c, a + 12 * c, out_s[0].data_ptr(), out_s[1].data_ptr(),
+                                                     out_s[2].data_ptr(), c, 0, stream()), "coeffs separate")
+        for got, want, what in zip(out_f, out_s, ("dgamma", "dbeta", "coef")):
+            assert torch.isfinite(got).all(), what
+            _close(got.cpu(), want.cpu(), 2e-4, 2e-4 * want.abs().max().item(), what)
