@@ -607,12 +607,12 @@ Plan make_plan(long M, int N, int K, bool fast) {
   if (force_bn < 0) { const char* e = getenv("KODHIP_FORCE_BN"); force_bn = e ? atoi(e) : 0; }
   if (force_bm < 0) { const char* e = getenv("KODHIP_FORCE_BM"); force_bm = e ? atoi(e) : 0; }
   const int widest = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
-  const bool can256 = fast && widest == 128 && M >= 256 * 64;
+  const bool can256 = fast && widest >= 64 && M >= 256 * 64;       // 256 x 128 and 256 x 64 tiles
   const int bm = can256 && (force_bm ? force_bm == 256 : K >= 512) ? 256 : 128;
   Plan best = {};
   double best_cost = 1e30;
   for (int bn = widest; bn >= 32 && bn >= widest / 2; bn >>= 1) {
-    if (bm == 256 && bn != 128) continue;
+    if (bm == 256 && bn != widest) continue;
     if (force_bn && force_bn <= widest && bn != force_bn) continue;
     long tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
     int slots = slots_for(bm, bn, fast);
@@ -650,7 +650,8 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   }
   dim3 g(p.grid);
   if (fast) {
-    if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
+    if (p.bm == 256 && p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
+    else if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
     else if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE, true>), g, dim3(256), 0, stream, args);
     else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE, true>), g, dim3(256), 0, stream, args);
     else hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, args);
@@ -683,7 +684,8 @@ int launch_x4(ConvArgs c[4], hipStream_t stream) {
     }
   }
   dim3 g(pl.grid * 4);
-  if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
+  if (pl.bm == 256 && pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
+  else if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
   else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true>), g, dim3(256), 0, stream, p);
   else if (pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 2, MODE, true>), g, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, p);
