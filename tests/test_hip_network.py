@@ -92,7 +92,7 @@ def test_train_step_vs_oracle(case):
     assert all(int(sd_h[k]) == int(sd_r[k]) == 1 for k in sd_r if k.endswith("num_batches_tracked"))
 
 
-@pytest.mark.parametrize("case", ["yv5s_160", "yv5s_640", "yv5m_96"])
+@pytest.mark.parametrize("case", ["yv5s_160", "yv5s_640", "yv5m_96", "yv5s_rect160x224", "yv5n_rect192x96"])
 def test_layers_teacher_forced(case):
     """Every conv+BN+SiLU unit, in situ: feed the HIP path's own bf16 input activation / output gradient to
     plain torch fp32 and compare that unit's output, dY, dgamma, dbeta, dW and the accumulated dX of every
@@ -100,16 +100,24 @@ def test_layers_teacher_forced(case):
     import torch.nn.functional as F
     cases = dict(synth.network_cases())
     cases["yv5m_96"] = (0.75, 0.67, 10, 3, 96, 5)
+    cases["yv5s_rect160x224"] = (0.5, 0.33, 10, 2, (160, 224), 6)      # H != W: nothing may assume square maps
+    cases["yv5n_rect192x96"] = (0.25, 0.33, 10, 3, (192, 96), 8)
     widen, deepen, nc, B, size, seed = cases[case]
     torch.manual_seed(seed)
     net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen).cuda().train()
-    x, tg = synth.batch(B, size, nc, seed)
+    if isinstance(size, tuple):
+        img_h, img_w = size
+        x = torch.rand(B, 3, img_h, img_w, generator=torch.Generator().manual_seed(seed))
+        tg = synth.targets(B, min(size), nc, seed)
+    else:
+        img_h = img_w = size
+        x, tg = synth.batch(B, size, nc, seed)
     eng = net.engine()
     raws = net.forward_raw(x.cuda())
     for r in raws:
         r.retain_grad()
     fwd_raw = {u.name: eng.ustate[u.name].raw.float().cpu() for u in eng.exec_units}
-    lr = _loss()(FeatureShape(width=size, height=size),
+    lr = _loss()(FeatureShape(width=img_w, height=img_h),
                  tuple((r[..., :4], r[..., 4:5], r[..., 5:]) for r in raws), tuple(DetectionTarget(b, l) for b, l in tg))
     (B * (lr.localization + lr.classification + lr.objectness)).backward()
     grads = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
