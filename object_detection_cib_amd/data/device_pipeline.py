@@ -150,6 +150,33 @@ SAMPLE_DESC = np.dtype([("tile", _TILE, (4,)), ("im", "<f8", (6,)), ("lut_h", "u
                         ("lut_v", "u1", (256,)), ("hsv_on", "<i4"), ("flip", "<i4"), ("canvas", "<i4")], align=True)
 
 
+class _Stager:
+    """Host -> device upload of small per-batch tables without stalling the host on the stream: a ring of pinned
+    buffers + non-blocking copies (a pageable-memory copy waits for everything queued on the stream before it, which
+    serialises the data pipeline behind the previous training step); a slot is reused only after its copy ran."""
+
+    def __init__(self, device, depth: int = 8):
+        self.device, self.depth = device, depth
+        self.slots, self.events, self.i = [None] * depth, [None] * depth, 0
+
+    def upload(self, arr: np.ndarray) -> torch.Tensor:
+        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        k = self.i
+        self.i = (self.i + 1) % self.depth
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        if self.slots[k] is None or self.slots[k].numel() < raw.size:
+            self.slots[k] = torch.empty(max(raw.size, 1024), dtype=torch.uint8).pin_memory()
+        host = self.slots[k][:raw.size]
+        host.numpy()[:] = raw
+        dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
+        dev.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return dev
+
+
 class ImagePool:
     """RAM-cache analogue resident in HBM: all resized source images (u8 HWC, longest side <= S) in one buffer."""
 
@@ -179,6 +206,7 @@ class DeviceTrainPipeline:
         self.weights = image_repeat_factors
         self.sampler_indices = sampler_indices if sampler_indices is not None else range(len(images))
         self.tab = torch.from_numpy(bilinear_table()).to(self.device)
+        self._stager = _Stager(self.device)
 
     # -- one composite (mosaic + augment): fills a descriptor, returns boxes / labels --------------------
     def _composite(self, indices: List[int], desc):
@@ -245,8 +273,8 @@ class DeviceTrainPipeline:
                 mix[k] = (np.float32(r), np.float32(1 - r))
                 bb, lb = np.concatenate((bb, bb2), 0), np.concatenate((lb, lb2), 0)
             targets.append(DetectionTarget(torch.from_numpy(np.ascontiguousarray(bb)), torch.from_numpy(np.ascontiguousarray(lb))))
-        d_dev = torch.from_numpy(descs.view(np.uint8).reshape(-1)).to(self.device)
-        m_dev = torch.from_numpy(mix).to(self.device)
+        d_dev = self._stager.upload(descs)
+        m_dev = self._stager.upload(mix).view(torch.float32)
         img = torch.empty((B, 3, S, S), dtype=torch.float32, device=self.device) if out_f32 else None
         pairs = torch.empty((B, S, S // 2, 8), dtype=torch.bfloat16, device=self.device) if out_pairs else None
         _lib.check(_lib.lib().kodhip_compose_batch(self.pool.data.data_ptr(), d_dev.data_ptr(), m_dev.data_ptr(),
@@ -296,6 +324,7 @@ class DeviceValPipeline:
         self.device = torch.device(device)
         self.pool = ImagePool(images, self.device)
         self.boxes, self.labels = list(boxes), list(labels)
+        self._stager = _Stager(self.device)
 
     def make_batch(self, batch_indices: Sequence[int], out_f32: bool = True, out_pairs: bool = False):
         """Returns (images f32 [B,3,S,S] or None, pairs bf16 [B,S,S/2,8] or None, tuple of DetectionTarget)."""
@@ -313,7 +342,7 @@ class DeviceValPipeline:
                 bb[:, [0, 2]] = bb[:, [0, 2]] / w * nw + left
                 bb[:, [1, 3]] = bb[:, [1, 3]] / h * nh + top
             targets.append(DetectionTarget(torch.from_numpy(bb), torch.from_numpy(np.asarray(self.labels[i], dtype=np.int64))))
-        d_dev = torch.from_numpy(descs.view(np.uint8).reshape(-1)).to(self.device)
+        d_dev = self._stager.upload(descs)
         img = torch.empty((B, 3, S, S), dtype=torch.float32, device=self.device) if out_f32 else None
         pairs = torch.empty((B, S, S // 2, 8), dtype=torch.bfloat16, device=self.device) if out_pairs else None
         _lib.check(_lib.lib().kodhip_val_prep_batch(self.pool.data.data_ptr(), d_dev.data_ptr(),

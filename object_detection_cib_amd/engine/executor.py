@@ -185,7 +185,9 @@ class Engine:
         self.exec_units = exec_units
         self.device = device
         self.hyper = torch.zeros(10, dtype=torch.float32, device=device)
-        self._hyper_host = torch.zeros(10, dtype=torch.float32).pin_memory()
+        # pinned staging ring: the H2D copy is asynchronous, so a slot is not rewritten for the next 15 uploads
+        self._hyper_host = [torch.zeros(10, dtype=torch.float32).pin_memory() for _ in range(16)]
+        self._hyper_slot = 0
         self._hyper_vals = None
 
     def _grad_view(self, name, arena=None):
@@ -604,14 +606,21 @@ class Engine:
         return self.g_arena[self.g_cur ^ 1]
 
     # ------------------------------------------------------------------ optimizer
+    def set_hyper(self, lr, momentum, weight_decay, grad_scale: float = 1.0):
+        """Upload the optimizer hyper-parameters (3-tuples for bias_params, decay_params, norm_params) to the device
+        buffer the fused SGD kernel reads - outside any captured graph, so schedules keep working under replay."""
+        vals = (*lr, *momentum, *weight_decay, grad_scale)
+        if vals != self._hyper_vals:                       # only touch the device copy when the schedule moved
+            host = self._hyper_host[self._hyper_slot]
+            self._hyper_slot = (self._hyper_slot + 1) % len(self._hyper_host)
+            host.copy_(torch.tensor(vals, dtype=torch.float32))
+            self.hyper.copy_(host, non_blocking=True)
+            self._hyper_vals = vals
+
     def sgd_step(self, lr, momentum, weight_decay, grad_scale: float = 1.0):
         """lr / momentum / weight_decay: 3-tuples for (bias_params, decay_params, norm_params)."""
         self.wait_grads()
-        vals = (*lr, *momentum, *weight_decay, grad_scale)
-        if vals != self._hyper_vals:                       # only touch the device copy when the schedule moved
-            self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
-            self.hyper.copy_(self._hyper_host, non_blocking=True)
-            self._hyper_vals = vals
+        self.set_hyper(lr, momentum, weight_decay, grad_scale)
         self.sgd_step_device()
 
     def sgd_step_device(self):

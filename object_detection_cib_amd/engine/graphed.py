@@ -1,0 +1,133 @@
+"""GraphedTrainStep - one training step (forward, assigner + loss, backward, gradient all-reduce, fused SGD) captured
+once as a hipGraph and replayed on new data.
+
+The reference leaves launch scheduling to PyTorch / Lightning (one aten kernel at a time from Python).  Here the
+step is ~520 launches of 5-100 us; issued from Python it is host-bound, so the capture is what makes a training LOOP
+run at device speed (bench.py measures exactly this replay).  What makes the step capturable:
+
+* inputs live in static device buffers that new batches are copied into: the image batch, and the boxes / labels /
+  image indices of all targets padded to a fixed capacity with zero-size boxes, which the assigner never matches
+  (kod/core/label_assignment/yv5.py:262-296: the anchor-ratio test rejects w = h = 0);
+* optimizer hyper-parameters are read from device memory (Engine.set_hyper), so warm-up / LR schedules keep working;
+* no host synchronisation anywhere in the step (assigner counts stay on the device).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from ..core.label_assignment.yv5 import BatchedTargets
+from ..core.types import FeatureShape
+
+
+class GraphedTrainStep:
+    def __init__(self, net, loss, batch_size: int, height: int, width: int, max_targets: int = 4096,
+                 loss_scale: Optional[float] = None):
+        self.net, self.loss = net, loss
+        self.eng = net.engine()
+        dev = self.eng.device
+        self.B, self.H, self.W = batch_size, height, width
+        self.cap = int(max_targets)
+        self.scale = float(batch_size if loss_scale is None else loss_scale)     # exp.py:104-138: total = B * sum
+        self.x = torch.zeros((batch_size, 3, height, width), dtype=torch.float32, device=dev)
+        self.boxes = torch.zeros((self.cap, 4), dtype=torch.float64, device=dev)
+        self.labels = torch.zeros(self.cap, dtype=torch.int64, device=dev)
+        self.samples = torch.zeros(self.cap, dtype=torch.int32, device=dev)
+        self.targets = BatchedTargets(self.boxes, self.labels, self.samples, self.cap)
+        self.shape = FeatureShape(width=width, height=height)
+        self.params = list(net.parameters())
+        self.graph = None
+        self.total = None
+        self.parts = None
+        self._host = [(torch.zeros((self.cap, 4), dtype=torch.float64).pin_memory(), torch.zeros(self.cap, dtype=torch.int64).pin_memory(),
+                       torch.zeros(self.cap, dtype=torch.int32).pin_memory()) for _ in range(4)]
+        self._events, self._slot = [None] * 4, 0
+
+    # -- the step itself (what gets captured)
+    def _step(self):
+        for p in self.params:
+            p.grad = None
+        lr = self.loss(self.shape, self.net(self.x), self.targets)
+        total = self.scale * (lr.localization + lr.classification + lr.objectness)
+        total.backward()
+        self.eng.wait_grads()
+        self.eng.sgd_step_device()
+        return total, (lr.localization.detach(), lr.objectness.detach(), lr.classification.detach())
+
+    def _load(self, images: torch.Tensor, targets):
+        assert tuple(images.shape) == tuple(self.x.shape), (images.shape, self.x.shape)
+        self.x.copy_(images, non_blocking=True)
+        if isinstance(targets, BatchedTargets):
+            n = targets.n
+            if n > self.cap:
+                raise ValueError(f"{n} target boxes in the batch exceed the graph's capacity {self.cap}")
+            self.boxes.zero_(); self.labels.zero_(); self.samples.zero_()      # padding = zero-size boxes: never assigned
+            if n:
+                self.boxes[:n].copy_(targets.boxes)
+                self.labels[:n].copy_(targets.labels)
+                self.samples[:n].copy_(targets.samples)
+            return
+        # host-side targets (tuple of DetectionTarget on the CPU): pack them into one pinned block and upload it
+        # without stalling the host behind the previous step (a pageable copy would)
+        lens = [int(t.boxes.shape[0]) for t in targets]
+        n = sum(lens)
+        if n > self.cap:
+            raise ValueError(f"{n} target boxes in the batch exceed the graph's capacity {self.cap}")
+        k = self._slot
+        self._slot = (self._slot + 1) % len(self._host)
+        if self._events[k] is not None:
+            self._events[k].synchronize()
+        hb, hl, hs = self._host[k]
+        hb.zero_(); hl.zero_(); hs.zero_()
+        o = 0
+        for i, t in enumerate(targets):
+            m = lens[i]
+            if m:
+                hb[o:o + m] = t.boxes.reshape(-1, 4).to(torch.float64)
+                hl[o:o + m] = t.labels.reshape(-1).to(torch.int64)
+                hs[o:o + m] = i
+                o += m
+        self.boxes.copy_(hb, non_blocking=True)
+        self.labels.copy_(hl, non_blocking=True)
+        self.samples.copy_(hs, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[k] = ev
+
+    def capture(self, images: torch.Tensor, targets, warmup: int = 2, preserve_state: bool = True):
+        """Runs `warmup` eager steps on this batch (allocations, lazy initialisation), then captures the step.
+        preserve_state: parameters, momentum and BatchNorm buffers are restored afterwards, so that capturing
+        does not move the training trajectory."""
+        eng = self.eng
+        self._load(images, targets)
+        keep = [t.clone() for t in (eng.p_arena, eng.m_arena, eng.rm_arena, eng.rv_arena, eng.nbt_arena)] if preserve_state else None
+        side = torch.cuda.Stream(device=eng.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 2)):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.total, self.parts = self._step()
+        if keep is not None:
+            for t, k in zip((eng.p_arena, eng.m_arena, eng.rm_arena, eng.rv_arena, eng.nbt_arena), keep):
+                t.copy_(k)
+            eng.mark_params_changed()
+        return self
+
+    def __call__(self, images: torch.Tensor, targets, lr: Optional[Sequence[float]] = None,
+                 momentum: Optional[Sequence[float]] = None, weight_decay: Optional[Sequence[float]] = None,
+                 grad_scale: float = 1.0):
+        """One replayed step on a new batch.  Returns (total, (box, obj, cls)) - static tensors that the next call
+        overwrites (clone to keep)."""
+        if self.graph is None:
+            raise RuntimeError("call capture() first")
+        if lr is not None:
+            self.eng.set_hyper(lr, momentum, weight_decay, grad_scale)
+        self._load(images, targets)
+        self.graph.replay()
+        self.eng.param_version += 1           # the replayed SGD changed the parameters
+        return self.total, self.parts

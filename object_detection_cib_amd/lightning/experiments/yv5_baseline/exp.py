@@ -24,7 +24,8 @@ from .warmup import OptimizerWarmupUpdater
 class DefaultYolov5Experiment:
     def __init__(self, net, loss, anchor_info: LayerwiseAnchorInfo, optimizer: Optional[SmartSGD] = None,
                  sch_fn: Callable = None, optimizer_warmup_updater: Optional[OptimizerWarmupUpdater] = None,
-                 val_nms_conf_threshold: float = 0.001, val_nms_iou_threshold: float = 0.6, max_epochs: int = 300):
+                 val_nms_conf_threshold: float = 0.001, val_nms_iou_threshold: float = 0.6, max_epochs: int = 300,
+                 graphed: bool = False, max_targets: int = 4096):
         self.net, self.loss, self.anchor_info = net, loss, anchor_info
         self.optimizer = optimizer or SmartSGD(net)
         self.max_epochs = max_epochs
@@ -35,6 +36,9 @@ class DefaultYolov5Experiment:
         self.global_step = 0
         self.current_epoch = 0
         self.logged = {}
+        # graphed=True: the optimisation step is captured once as a hipGraph (engine/graphed.py) and replayed - same
+        # arithmetic, no per-launch Python; batches must keep one shape and at most max_targets boxes
+        self.graphed, self.max_targets, self._gstep = graphed, max_targets, None
 
     def get_metrics_to_display(self):
         return ["box", "cls", "obj"]
@@ -64,17 +68,37 @@ class DefaultYolov5Experiment:
 
     # exp.py:164-185 + Lightning automatic optimisation
     def optimize(self, batch, num_training_batches: int):
+        if self.graphed:
+            return self._optimize_graphed(batch, num_training_batches)
         self.optimizer.zero_grad(set_to_none=True)
         total = self.training_step(batch)
         total.backward()
+        self._warmup(num_training_batches)
+        self.optimizer.step()
+        self.global_step += 1
+        return total
+
+    def _warmup(self, num_training_batches: int):
         if self.optimizer_warmup_updater is not None:
             nw = max(round(num_training_batches * self.optimizer_warmup_updater.warmup_epochs), 100)
             if self.global_step <= nw:
                 self.optimizer_warmup_updater(current_step=self.global_step, current_epoch=self.current_epoch,
                                               max_warmup_steps=nw, sch_fn=self.sch_fn, optimizer=self.optimizer)
-        self.optimizer.step()
+
+    def _optimize_graphed(self, batch, num_training_batches: int):
+        from ....engine.graphed import GraphedTrainStep
+        images, targets, _ = batch
+        if self._gstep is None:
+            B, _, H, W = images.shape
+            self._gstep = GraphedTrainStep(self.net, self.loss, B, H, W, self.max_targets).capture(images, targets)
+        self._warmup(num_training_batches)
+        g = self.optimizer.param_groups
+        total, (box, obj, cls) = self._gstep(images, targets, [float(x["lr"]) for x in g], [float(x["momentum"]) for x in g],
+                                             [float(x["weight_decay"]) for x in g], 1.0 / self.optimizer.world_size)
+        self.optimizer.steps_taken += 1
+        self.logged = {"obj": obj, "cls": cls, "box": box}
         self.global_step += 1
-        return total
+        return total.clone()
 
     def end_epoch(self):
         """LambdaLR.step(): lr = initial_lr * sch_fn(epoch) for the next epoch."""

@@ -102,3 +102,29 @@ def test_training_learns_synthetic_set():
     assert set(rep) >= {"map", "map30", "map50", "map75", "map90"} and np.isfinite(rep["map"])
     assert rep["map30"] > 0.01, rep          # learned something real in 320 steps (100 of them warm-up)
     print("synthetic-set report:", {k: round(v, 4) for k, v in rep.items() if not k.startswith("map50_")}, first, last)
+
+
+def test_graphed_training_loop_equals_eager_loop():
+    """DefaultYolov5Experiment(graphed=True) replays one captured hipGraph per step (engine/graphed.py): same batches,
+    same warm-up schedule => the same losses and parameters as the eager loop, bit for bit (targets are padded to
+    a fixed capacity with zero-size boxes, which the assigner never matches; capture restores the state it touched)."""
+    S, nc, B, steps, seed = 160, 10, 8, 8, 4          # (as above: every level gets matches, no NaN level)
+    cache = synth.coco_zipf_like(64, S, seed, nc)
+    runs = {}
+    for graphed in (False, True):
+        pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda")
+        random.seed(seed); np.random.seed(seed)
+        exp = _experiment(0.25, 0.33, nc, seed)
+        exp.graphed, exp.max_targets = graphed, 512
+        losses = []
+        for step in range(steps):
+            idx = [(step * B + k) % len(cache) for k in range(B)]
+            img, _, targets = pipe.make_batch(idx)
+            losses.append(exp.optimize((img, targets, None), 8).item())
+        torch.cuda.synchronize()
+        runs[graphed] = (losses, torch.cat([p.detach().flatten() for p in exp.net.parameters()]).cpu(),
+                         exp.net.engine().rm_arena.cpu().clone())
+    assert np.isfinite(runs[False][0]).all()
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
+    assert torch.equal(runs[True][1], runs[False][1])
+    assert torch.equal(runs[True][2], runs[False][2])
