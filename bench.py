@@ -29,13 +29,30 @@ HBM_PEAK = 8.0e12                        # B/s, MI355X_MICROARCH.md chip table
 
 
 def synth_batch(B, size, nc, seed, device):
-    from oracle import synth          # input generator only (no oracle compute in the timed path)
-    x, tg = synth.batch(B, size, nc, seed)
-    tg = synth.targets(B, size, nc, seed, nmin=4, nmax=30)     # mosaic-like box counts (4 source images)
+    """Seeded synthetic batch of BASELINE configs[1]: U[0,1) fp32 images [B,3,size,size] and coco-zipf-like targets -
+    4..30 boxes per image (mosaic of 4 sources), class ~ Zipf(1.01) (kod/data/builder.py:110-116), log-uniform box
+    sizes.  (Own generator: the timed path must not touch oracle/.)"""
+    import numpy as np
     from object_detection_cib_amd.data.detection import DetectionTarget
     from object_detection_cib_amd.core.label_assignment.yv5 import BatchedTargets
-    tg = tuple(DetectionTarget(b, l) for b, l in tg)
-    return x.to(device), BatchedTargets.from_targets(tg, device)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, size, size, generator=g)
+    rng = np.random.default_rng(seed)
+    k = np.arange(1, nc + 1, dtype=np.float64)
+    pmf = k ** (-1.01)
+    pmf /= pmf.sum()
+    tg = []
+    for _ in range(B):
+        n = int(rng.integers(4, 31))
+        c = rng.uniform(0, size, (n, 2))
+        wh = np.exp(rng.uniform(np.log(8 * size / 640), np.log(400 * size / 640), (n, 2)))
+        b = np.concatenate((c - wh / 2, c + wh / 2), 1).clip(0, size - 1)
+        b = b[((b[:, 2] - b[:, 0]) > 2) & ((b[:, 3] - b[:, 1]) > 2)]
+        if b.shape[0] == 0:
+            b = np.array([[size * 0.25, size * 0.25, size * 0.75, size * 0.75]])
+        lab = rng.choice(nc, size=b.shape[0], p=pmf)
+        tg.append(DetectionTarget(torch.from_numpy(b.astype(np.float64)), torch.from_numpy(lab.astype(np.int64))))
+    return x.to(device), BatchedTargets.from_targets(tuple(tg), device)
 
 
 def build(nc, device, seed=2023):

@@ -57,3 +57,23 @@ def test_bench_uses_oracle_only_for_inputs_and_cpu_baseline():
                 users.setdefault(fn.name, set()).update(a.name for a in node.names)
     assert set(users) <= {"cpu_baseline", "synth_batch"}, users
     assert users.get("synth_batch", set()) <= {"synth"}, users
+
+
+def test_bench_touches_oracle_only_in_its_cpu_baseline_leg():
+    """bench.py may time the oracle as the CPU baseline, nothing else: every `oracle` import sits inside
+    cpu_baseline(); __graft_entry__ only inside build() (compiling / importing the checker) and smoke()."""
+    for fname, ok_funcs in (("bench.py", {"cpu_baseline"}), ("__graft_entry__.py", {"build", "smoke"})):
+        tree = ast.parse(open(os.path.join(ROOT, fname)).read(), fname)
+        inside = set()
+        for fn in ast.walk(tree):
+            if isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef)) and fn.name in ok_funcs:
+                for node in ast.walk(fn):
+                    inside.add(id(node))
+        for node in ast.walk(tree):
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom) and node.module:
+                mods = [node.module]
+            if any(m.split(".")[0] == "oracle" for m in mods):
+                assert id(node) in inside, (fname, getattr(node, "lineno", None))
