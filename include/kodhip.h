@@ -190,6 +190,7 @@ int kodhip_comm_unique_id(void* id128 /* host, 128 bytes out */);
 int kodhip_comm_init(void** comm, const void* id128, int rank, int world);
 int kodhip_comm_destroy(void* comm);
 int kodhip_comm_allreduce_sum(void* comm, void* buf, long count, int elem_bytes /* 4: fp32, 8: fp64 */, kodStream_t stream);
+int kodhip_comm_allreduce_sum_to(void* comm, const void* send, void* recv, long count, int elem_bytes, kodStream_t stream);
 int kodhip_comm_broadcast(void* comm, void* buf, long bytes, int root, kodStream_t stream);
 
 #ifdef __cplusplus

@@ -69,6 +69,7 @@ SIGNATURES = {
     "kodhip_comm_init": (i32, [C.POINTER(vp), vp, i32, i32]),
     "kodhip_comm_destroy": (i32, [vp]),
     "kodhip_comm_allreduce_sum": (i32, [vp, vp, i64, i32, vp]),
+    "kodhip_comm_allreduce_sum_to": (i32, [vp, vp, vp, i64, i32, vp]),
     "kodhip_comm_broadcast": (i32, [vp, vp, i64, i32, vp]),
     "kodhip_compose_desc_bytes": (i32, []),
     "kodhip_compose_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),

@@ -111,6 +111,14 @@ int kodhip_comm_allreduce_sum(void* comm, void* buf, long count, int elem_bytes,
   return KOD_OK;
 }
 
+// out-of-place form: recv = sum over ranks of send (send is left untouched; SyncBN backward keeps the local sums)
+int kodhip_comm_allreduce_sum_to(void* comm, const void* send, void* recv, long count, int elem_bytes, hipStream_t stream) {
+  KOD_CHECK_ARG(comm && send && recv && count > 0 && (elem_bytes == 4 || elem_bytes == 8), "comm_allreduce_sum_to: bad args");
+  KOD_RCCL(g_api.AllReduce(send, recv, (size_t)count, elem_bytes == 4 ? kFloat32 : kFloat64, kSum, comm, stream),
+           "comm_allreduce_sum_to");
+  return KOD_OK;
+}
+
 // in-place broadcast of `bytes` bytes from `root` (initial parameters and BatchNorm buffers)
 int kodhip_comm_broadcast(void* comm, void* buf, long bytes, int root, hipStream_t stream) {
   KOD_CHECK_ARG(comm && buf && bytes > 0 && root >= 0, "comm_broadcast: bad args");

@@ -42,6 +42,14 @@ class RcclComm:
         _lib.check(self.lib.kodhip_comm_allreduce_sum(self._handle, t.data_ptr(), t.numel(), t.element_size(), s),
                    "comm_allreduce")
 
+    def all_reduce_to(self, src: torch.Tensor, dst: torch.Tensor, stream: int | None = None):
+        """dst = sum over ranks of src (src untouched)."""
+        assert src.is_cuda and dst.is_cuda and src.dtype == dst.dtype and src.dtype in (torch.float32, torch.float64)
+        assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel() and self._handle
+        s = torch.cuda.current_stream(src.device).cuda_stream if stream is None else stream
+        _lib.check(self.lib.kodhip_comm_allreduce_sum_to(self._handle, src.data_ptr(), dst.data_ptr(), src.numel(),
+                                                         src.element_size(), s), "comm_allreduce_to")
+
     def broadcast(self, t: torch.Tensor, root: int = 0, stream: int | None = None):
         assert t.is_cuda and t.is_contiguous() and self._handle
         s = torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream

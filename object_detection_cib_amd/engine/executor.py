@@ -524,8 +524,11 @@ class Engine:
                                                       st.bpart.data_ptr(), st.M, C_, s), u.name)
                 if self.sync_bn and self.collectives:
                     chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), C_, st.T2, s), u.name)
-                    st.bsums_g.copy_(st.bsums)
-                    self._allreduce(st.bsums_g)
+                    if self.comm is not None:             # out of place: the local sums stay for dgamma / dbeta
+                        self.comm.all_reduce_to(st.bsums, st.bsums_g)
+                    else:
+                        st.bsums_g.copy_(st.bsums)
+                        self._allreduce(st.bsums_g)
                     chk(lib.kodhip_bn_bwd_coeffs(st.bsums.data_ptr(), st.bsums_g.data_ptr(),
                                                  float(st.M) * self.world_size, pa + 4 * st.g_off,
                                                  aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off, gp + 4 * st.b_off,
