@@ -33,6 +33,10 @@ CONV_CASES = [
     (1, 512, 4, 4, 512, 1, 1, 0),
     (5, 64, 60, 56, 160, 3, 1, 1),       # M = 16800, K = 576: the 256-pixel-tile / 3-stage-ring configuration, ragged M and N
     (4, 128, 64, 64, 128, 3, 2, 1),      # same configuration through the stride-2 forward and its parity-class dgrad
+    (2, 48, 12, 10, 48, 1, 1, 0),        # Cin % 16 == 0 only: half-step FAST form with a K tail (48 -> 64), both directions
+    (2, 16, 8, 8, 48, 3, 1, 1),          # 16 input channels: every half step is a new tap
+    (2, 96, 10, 10, 48, 3, 2, 1),        # stride-2 dgrad gathers 48-channel dY: half-step form in the merged launch
+    (3, 80, 7, 9, 80, 3, 1, 1),          # yv5x-like 80 channels
 ]
 
 
