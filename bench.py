@@ -181,20 +181,33 @@ def main():
     if use_graph:
         # the whole step (~650 launches, and for N>1 the RCCL all-reduces between them) becomes one hipGraph
         barrier()
+        err = None
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 last = step()
-            graph.replay()
-            launch_note = "hipGraph replay"
-        except Exception as e:      # capture refused (e.g. a collective that cannot be captured): run eagerly, say so
+        except Exception as e:      # capture refused (e.g. a collective that cannot be captured)
+            err, graph = e, None
             if not use_dist:
                 raise
+        # replay or eager must be ONE decision for the whole job: a rank replaying a graph while another runs eagerly
+        # would issue different RCCL call sequences and hang.  Agree on it over the gloo control plane.
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32)
+        if dist is not None:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            graph.replay()
+            launch_note = "hipGraph replay"
+        else:
+            if err is None:
+                print(f"[bench rank {rank}] another rank failed to capture the step: running eagerly everywhere",
+                      file=sys.stderr, flush=True)
+            else:
+                print(f"[bench rank {rank}] hipGraph capture failed, running eagerly: {err}", file=sys.stderr, flush=True)
             graph = None
             torch.cuda.synchronize()
             eng._pending = []
-            launch_note = f"eager (graph capture failed: {type(e).__name__})"
-            print(f"[bench rank {rank}] hipGraph capture failed, running eagerly: {e}", file=sys.stderr, flush=True)
+            launch_note = "eager (graph capture failed" + (f": {type(err).__name__})" if err is not None else " on another rank)")
             for _ in range(2):
                 last = step()
     barrier()

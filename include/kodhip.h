@@ -156,6 +156,14 @@ int kodhip_yolo_loss(const KodLossLevel* levels /* host[3] */, int B, int A, int
                      const float* upstream, float* partials, int nslots, float* out, int compute_grad,
                      kodStream_t stream);
 
+/* Aligned IoU family behind kod.core.bbox.iou.IoUCalculator.__call__ (kod/core/bbox/iou.py:77-95,142-268):
+ * boxes [m][4] xyxy fp32 -> out [m]; kind 0 iou | 1 giou | 2 diou | 3 ciou (IoUType order, iou.py:9-14).
+ * The backward follows autograd's conventions (max/min ties split evenly, clamp(0) passes at 0, CIoU alpha constant). */
+int kodhip_iou_fwd(const float* boxes1, const float* boxes2, float* out, long m, int kind, float eps,
+                   kodStream_t stream);
+int kodhip_iou_bwd(const float* boxes1, const float* boxes2, const float* grad_out, float* grad_boxes1 /* or NULL */,
+                   float* grad_boxes2 /* or NULL */, long m, int kind, float eps, kodStream_t stream);
+
 /* ---- device data path: mosaic + warpAffine + HSV + flip + /255 (+ mixup) in one gather kernel
  *      (kod/data/mosaic.py:58-132, kod/data/augmentations/default.py:279-320,354-408,433-438) ------- */
 int kodhip_compose_desc_bytes(void);
@@ -177,7 +185,8 @@ int kodhip_nms(const float* det, void* keys, int key_cap, int* ncand, float* out
                kodStream_t stream);
 
 /* detection <-> ground-truth matching of COCO-style mAP (kod/lightning/callbacks/pycoco_map_eval.py:50-125 ->
- * vision_evaluation -> pycocotools COCOeval.evaluateImg); tp [B][max_det][T] u8, counted [B][max_det] u8 */
+ * vision_evaluation -> pycocotools COCOeval.evaluateImg); tp [B][max_det][T] u8, counted [B][max_det] u8.
+ * At most 256 ground truths per image take part in the matching (later ones are never matched). */
 int kodhip_map_match(const float* det, const int* ndet, const double* gt_boxes, const long* gt_labels,
                      const int* gt_start, void* tp, void* counted, int B, int max_det, int nc,
                      const double* iou_thresholds /* host */, int T, int max_per_class, kodStream_t stream);

@@ -79,6 +79,8 @@ SIGNATURES = {
     "kodhip_nms": (i32, [vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, i32, i32, f32, vp]),
     "kodhip_map_match": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(f64), i32, i32, vp]),
     "kodhip_assign_targets": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, C.POINTER(KodAssignLevel), vp]),
+    "kodhip_iou_fwd": (i32, [vp, vp, vp, i64, i32, f32, vp]),
+    "kodhip_iou_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, f32, vp]),
     "kodhip_yolo_loss": (i32, [C.POINTER(KodLossLevel), i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp,
                                i32, vp]),
 }

@@ -15,12 +15,17 @@ from .. import _lib
 
 def non_max_suppression(detections: torch.Tensor, conf_thres: float = 0.25, nms_thres: float = 0.45,
                         classes=None) -> Sequence[torch.Tensor]:
-    if classes is not None:
-        raise NotImplementedError("class filtering is not on the HIP path (the reference never passes it)")
     _lib.require_gpu()
     det = detections.contiguous().float()
     B, rows, P = det.shape
     nc = P - 5
+    if classes is not None:
+        # nms.py:52-54 drops candidates whose class is not listed, before the top-30000 cut: a zeroed class
+        # probability never passes `cls * obj > conf_thres`, so masking the columns is the same filter
+        keep = torch.zeros(nc, dtype=torch.bool, device=det.device)
+        keep[torch.as_tensor(list(classes), dtype=torch.long, device=det.device)] = True
+        det = det.clone()
+        det[..., 5:] *= keep.to(det.dtype)
     max_wh, max_det, max_nms = 4096.0, 300, 30000                  # nms.py:22-26
     need = rows * nc
     key_cap = 64

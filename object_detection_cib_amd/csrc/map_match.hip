@@ -46,7 +46,8 @@ __global__ void map_match_kernel(MapArgs a) {
         for (int g = g0; g < g1; ++g) {
           if (a.gt_label[g] != c) continue;
           int k = g - g0;
-          if (k < 256 && ((used[k >> 6] >> (k & 63)) & 1ull)) continue;
+          if (k >= 256) break;       // beyond the bitmap: never matched (the host wrapper rejects such images)
+          if ((used[k >> 6] >> (k & 63)) & 1ull) continue;
           const double* G = a.gt + (size_t)g * 4;
           double w = fmin(x2, G[2]) - fmax(x1, G[0]);
           double h = fmin(y2, G[3]) - fmax(y1, G[1]);
@@ -56,7 +57,7 @@ __global__ void map_match_kernel(MapArgs a) {
           if (iou < best) continue;
           best = iou; m = k;
         }
-        if (m >= 0) { if (m < 256) used[m >> 6] |= 1ull << (m & 63); hit = 1; }
+        if (m >= 0) { used[m >> 6] |= 1ull << (m & 63); hit = 1; }
       }
       a.tp[((size_t)b * a.max_det + d) * a.T + t] = hit;
     }

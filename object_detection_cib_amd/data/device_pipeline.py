@@ -177,6 +177,64 @@ class _Stager:
         return dev
 
 
+def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas: int, border, always_warp: bool = False):
+    """TrainSampleAugmentor.__call__ (default.py:440-488) for one sample: consumes the augmentor's generator in the
+    reference's order (8 affine draws, 3 HSV draws, 1 flip draw), writes the pixel-side parameters (inverse affine
+    matrix, HSV LUTs, flip flag) into the compositing descriptor and returns the transformed boxes / labels and the
+    output image side."""
+    ap = aug.affine_params
+    if ap.perspective != 0.0:
+        raise NotImplementedError("perspective warps are not on the HIP path (reference default is 0)")
+    if not always_warp and ap.degrees == 0.0 and ap.translate == 0.0 and ap.scale == 0.0 and ap.shear == 0.0:
+        # AffineParams.should_aug() is False (default.py:38-48,445-457): no draws, no warp, the image keeps its size
+        wo = ho = canvas
+        desc["im"] = np.array([1.0, 0.0, 0.0, 0.0, 1.0, 0.0])
+    else:
+        draws = (rng.uniform(-ap.perspective, ap.perspective), rng.uniform(-ap.perspective, ap.perspective),
+                 rng.uniform(-ap.degrees, ap.degrees), rng.uniform(1 - ap.scale, 1 + ap.scale),
+                 rng.uniform(-ap.shear, ap.shear), rng.uniform(-ap.shear, ap.shear),
+                 rng.uniform(0.5 - ap.translate, 0.5 + ap.translate), rng.uniform(0.5 - ap.translate, 0.5 + ap.translate))
+        M, wo, ho = affine_matrix(draws, canvas, canvas, border)
+        desc["im"] = invert_affine(M).reshape(-1)
+        if len(lb):
+            nb, keep = affine_boxes(bb, M, wo, ho, draws[3])
+            bb, lb = nb[keep], lb[keep]
+    hp = aug.hsv_params
+    if hp.hue == 0.0 and hp.saturation == 0.0 and hp.value == 0.0:
+        desc["hsv_on"] = 0
+    else:
+        r = rng.uniform(-1, 1, 3) * [hp.hue, hp.saturation, hp.value] + 1               # default.py:365-369
+        x = np.arange(0, 256, dtype=np.int16)
+        desc["lut_h"] = ((x * r[0]) % 180).astype(np.uint8)
+        desc["lut_s"] = np.clip(x * r[1], 0, 255).astype(np.uint8)
+        desc["lut_v"] = np.clip(x * r[2], 0, 255).astype(np.uint8)
+        desc["hsv_on"] = 1
+    flip = aug.flip_lr_prob > 0.0 and rng.random() < aug.flip_lr_prob
+    desc["flip"] = int(flip)
+    if flip and len(bb):
+        f = bb.copy()
+        f[:, 2] = wo - 1 - bb[:, 0]
+        f[:, 0] = wo - 1 - bb[:, 2]
+        bb = f
+    desc["canvas"] = canvas
+    return bb, lb, wo
+
+
+def compose(pool: torch.Tensor, descs: np.ndarray, mix: np.ndarray, tab: torch.Tensor, S: int, stager: "_Stager",
+            out_f32: bool = True, out_pairs: bool = False):
+    """One launch of compose_kernel for descs [B][2] / mix [B][2]; returns (f32 [B,3,S,S] | None, pairs | None)."""
+    B = descs.shape[0]
+    d_dev = stager.upload(descs)
+    m_dev = stager.upload(mix).view(torch.float32)
+    img = torch.empty((B, 3, S, S), dtype=torch.float32, device=pool.device) if out_f32 else None
+    pairs = torch.empty((B, S, S // 2, 8), dtype=torch.bfloat16, device=pool.device) if out_pairs else None
+    _lib.check(_lib.lib().kodhip_compose_batch(pool.data_ptr(), d_dev.data_ptr(), m_dev.data_ptr(), tab.data_ptr(),
+                                               img.data_ptr() if out_f32 else None,
+                                               pairs.data_ptr() if out_pairs else None, B, S,
+                                               torch.cuda.current_stream().cuda_stream), "compose_batch")
+    return img, pairs, (d_dev, m_dev)
+
+
 class ImagePool:
     """RAM-cache analogue resident in HBM: all resized source images (u8 HWC, longest side <= S) in one buffer."""
 
@@ -222,37 +280,9 @@ class DeviceTrainPipeline:
             d["off"], d["h"], d["w"] = self.pool.offsets[i], shapes[t][0], shapes[t][1]
             d["x1a"], d["y1a"], d["x2a"], d["y2a"] = a
             d["x1b"], d["y1b"] = b
-        ap = self.aug.affine_params
-        rng = self.rng
-        draws = (rng.uniform(-ap.perspective, ap.perspective), rng.uniform(-ap.perspective, ap.perspective),
-                 rng.uniform(-ap.degrees, ap.degrees), rng.uniform(1 - ap.scale, 1 + ap.scale),
-                 rng.uniform(-ap.shear, ap.shear), rng.uniform(-ap.shear, ap.shear),
-                 rng.uniform(0.5 - ap.translate, 0.5 + ap.translate), rng.uniform(0.5 - ap.translate, 0.5 + ap.translate))
-        if ap.perspective != 0.0:
-            raise NotImplementedError("perspective warps are not on the HIP path (reference default is 0)")
-        M, wo, ho = affine_matrix(draws, 2 * S, 2 * S, border)
-        desc["im"] = invert_affine(M).reshape(-1)
-        if len(lb):
-            nb, keep = affine_boxes(bb, M, wo, ho, draws[3])
-            bb, lb = nb[keep], lb[keep]
-        hp = self.aug.hsv_params
-        if hp.hue == 0.0 and hp.saturation == 0.0 and hp.value == 0.0:
-            desc["hsv_on"] = 0
-        else:
-            r = rng.uniform(-1, 1, 3) * [hp.hue, hp.saturation, hp.value] + 1               # default.py:365-369
-            x = np.arange(0, 256, dtype=np.int16)
-            desc["lut_h"] = ((x * r[0]) % 180).astype(np.uint8)
-            desc["lut_s"] = np.clip(x * r[1], 0, 255).astype(np.uint8)
-            desc["lut_v"] = np.clip(x * r[2], 0, 255).astype(np.uint8)
-            desc["hsv_on"] = 1
-        flip = self.aug.flip_lr_prob > 0.0 and rng.random() < self.aug.flip_lr_prob
-        desc["flip"] = int(flip)
-        if flip and len(bb):
-            f = bb.copy()
-            f[:, 2] = wo - 1 - bb[:, 0]
-            f[:, 0] = wo - 1 - bb[:, 2]
-            bb = f
-        desc["canvas"] = 2 * S
+        # always_warp: a batch is S x S, so the affine stage (which crops the 2S canvas to S) runs even when no jitter
+        # is configured (the reference would hand 2S x 2S images to the collate function in that case)
+        bb, lb, _ = augment_into(desc, self.aug, self.rng, bb, lb, 2 * S, border, always_warp=True)
         return bb, lb
 
     def make_batch(self, batch_indices: Sequence[int], out_f32: bool = True, out_pairs: bool = False):
@@ -273,15 +303,7 @@ class DeviceTrainPipeline:
                 mix[k] = (np.float32(r), np.float32(1 - r))
                 bb, lb = np.concatenate((bb, bb2), 0), np.concatenate((lb, lb2), 0)
             targets.append(DetectionTarget(torch.from_numpy(np.ascontiguousarray(bb)), torch.from_numpy(np.ascontiguousarray(lb))))
-        d_dev = self._stager.upload(descs)
-        m_dev = self._stager.upload(mix).view(torch.float32)
-        img = torch.empty((B, 3, S, S), dtype=torch.float32, device=self.device) if out_f32 else None
-        pairs = torch.empty((B, S, S // 2, 8), dtype=torch.bfloat16, device=self.device) if out_pairs else None
-        _lib.check(_lib.lib().kodhip_compose_batch(self.pool.data.data_ptr(), d_dev.data_ptr(), m_dev.data_ptr(),
-                                                   self.tab.data_ptr(), img.data_ptr() if out_f32 else None,
-                                                   pairs.data_ptr() if out_pairs else None, B, S,
-                                                   torch.cuda.current_stream().cuda_stream), "compose_batch")
-        self._keep = (d_dev, m_dev)
+        img, pairs, self._keep = compose(self.pool.data, descs, mix, self.tab, S, self._stager, out_f32, out_pairs)
         return img, pairs, tuple(targets)
 
 

@@ -1,6 +1,8 @@
-"""Index samplers (host logic; mirror kod/data/samplers.py:17-138).  Pure index generation with torch RNG streams
-identical to the reference: RandomCycleSampler / ClassAwareSampler use the global torch generator,
-RepeatFactorSampler a torch.Generator seeded with 2023."""
+"""Index samplers - drop-ins for kod.data.samplers (kod/data/samplers.py:17-138; `_target_`s of
+kod/configs/data/class_aware.yaml and repeat_factor.yaml).  Same constructors (a DatasetInfo-shaped object), same
+torch RNG streams: RandomCycleSampler / ClassAwareSampler draw from the global torch generator in the reference's
+construction order, RepeatFactorSampler from a torch.Generator seeded with 2023.  Pure host index logic; pinned to
+the reference's own outputs by tests/golden/samplers.npz."""
 from __future__ import annotations
 
 import math
@@ -9,79 +11,85 @@ from typing import Iterator, Optional, Sequence
 import torch
 from torch.utils.data import Sampler, WeightedRandomSampler
 
+from .filter import filter_dataset
 
-class RandomCycleSampler(Sampler):
+
+class RandomCycleSampler:
     """samplers.py:17-38: endless shuffled cycle over a list."""
 
     def __init__(self, data: Sequence[int], generator: Optional[torch.Generator] = None):
-        self.data = list(data)
-        self.length = len(self.data)
-        self.generator = generator
+        self.data = data
+        self.length = len(data)
         self.indices = torch.randperm(self.length, generator=generator)
         self.current_index = 0
+        self.generator = generator
 
     def __iter__(self):
         return self
 
-    def __len__(self):
+    def __len__(self) -> int:
         return self.length
 
-    def __next__(self):
+    def __next__(self) -> int:
         if self.current_index == self.length:
             self.indices = torch.randperm(self.length, generator=self.generator)
             self.current_index = 0
-        idx = self.data[int(self.indices[self.current_index])]
+        index = self.data[int(self.indices[self.current_index].item())]
         self.current_index += 1
-        return idx
+        return index
 
 
 class ClassAwareSampler(Sampler):
-    """samplers.py:41-77: uniform class -> next image of that class (cyclic reshuffle)."""
+    """samplers.py:41-77: uniform class -> next image of that class (cyclic reshuffle); one epoch = len(samples)
+    draws; `sampler_indices` is the side channel DetectionDataset's mosaic reads (kod/data/detection.py:114-122)."""
 
-    def __init__(self, class_to_images: Sequence[Sequence[int]], num_samples: int):
-        """class_to_images[c] = dataset indices of the images that contain class c (the reference derives it
-        with filter_dataset); construction order = reference's RNG order (label cycle first, then classes)."""
-        self.num_samples = num_samples
-        self.label_iter_list = RandomCycleSampler(list(range(len(class_to_images))))
-        self.data_iter_dict = {c: RandomCycleSampler(list(ix)) for c, ix in enumerate(class_to_images)}
+    def __init__(self, dataset_info):
+        self.dataset_info = dataset_info
+        position = {s.id: i for i, s in enumerate(dataset_info.samples)}
+        self.label_to_index = {name: i for i, name in enumerate(dataset_info.classes)}
+        self.label_iter_list = RandomCycleSampler(list(self.label_to_index.values()))
+        self.data_iter_dict = {}
+        for name, i in self.label_to_index.items():
+            members = filter_dataset(ds_info=dataset_info, new_name=name, classes_to_include=[name]).samples
+            self.data_iter_dict[i] = RandomCycleSampler([position[s.id] for s in members])
 
     def __iter__(self) -> Iterator[int]:
         indices = []
-        while len(indices) < self.num_samples:
-            label_index = next(self.label_iter_list)
-            indices.append(next(self.data_iter_dict[label_index]))
+        while len(indices) < len(self.dataset_info.samples):
+            indices.append(next(self.data_iter_dict[next(self.label_iter_list)]))
         self.sampler_indices = indices
         return iter(indices)
 
-    def __len__(self):
-        return self.num_samples
+    def __len__(self) -> int:
+        return len(self.dataset_info.samples)
 
 
-def image_repeat_factors(image_target_classes: Sequence[Sequence[int]], class_instance_count: Sequence[int],
-                         threshold: float = 1.0, reduction: Optional[str] = None, use_sqrt: bool = True):
-    """samplers.py:88-128: f_c = instances_c / total; r_c = max(1, t / f_c) (sqrt if use_sqrt); per image the
-    mean over its TARGETS (sum / (n + 1e-6)) or, with reduction == "max", the maximum."""
-    total = float(sum(class_instance_count))
-    rc = []
-    for n in class_instance_count:
-        v = max(1.0, threshold / (n / total))
-        rc.append(math.sqrt(v) if use_sqrt else v)
-    out = []
-    for cls in image_target_classes:
-        s, mx = 0.0, 0.0
-        for c in cls:
-            s += rc[c]
-            mx = max(mx, rc[c])
-        out.append(mx if reduction == "max" else s / (len(cls) + 1e-6))
+def class_repeat_factors(dataset_info, threshold: float = 1.0, use_sqrt: bool = True) -> dict:
+    """samplers.py:88-109: f_c = instances_c / total; r_c = max(1, t / f_c), square-rooted if use_sqrt."""
+    count = dataset_info.get_instance_count()
+    total = sum(count.values())
+    out = {}
+    for k in dataset_info.classes:
+        r = max(1.0, threshold / (count[k] / total))
+        out[k] = math.sqrt(r) if use_sqrt else r
     return out
 
 
 class RepeatFactorSampler(WeightedRandomSampler):
-    """samplers.py:80-138: weighted sampling with replacement, generator seed 2023."""
+    """samplers.py:80-138: weighted sampling with replacement; image weight = mean (sum / (n + 1e-6)) or, with
+    reduction == "max", maximum of its targets' class repeat factors; generator seed 2023."""
 
-    def __init__(self, repeat_factors: Sequence[float], seed: int = 2023):
-        self.image_repeat_factors = list(repeat_factors)
+    def __init__(self, dataset_info, reduction: Optional[str] = None, threshold: float = 1.0, use_sqrt: bool = True):
+        self.dataset_info = dataset_info
+        rc = class_repeat_factors(dataset_info, threshold, use_sqrt)
+        self.image_repeat_factors = []
+        for sample in dataset_info.samples:
+            total, biggest = 0.0, 0.0
+            for t in sample.targets:
+                total += rc[t.class_name]
+                biggest = max(biggest, rc[t.class_name])
+            self.image_repeat_factors.append(biggest if reduction == "max" else total / (len(sample.targets) + 1e-6))
         self.generator = torch.Generator()
-        self.generator.manual_seed(seed)
-        super().__init__(torch.tensor(self.image_repeat_factors), num_samples=len(self.image_repeat_factors),
+        self.generator.manual_seed(2023)
+        super().__init__(torch.tensor(self.image_repeat_factors), num_samples=len(dataset_info.samples),
                          replacement=True, generator=self.generator)

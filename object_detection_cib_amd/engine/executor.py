@@ -46,6 +46,11 @@ class Engine:
         self.buffers = buffers        # running_mean / running_var / num_batches_tracked
         self.device = None
         self.shape = None             # (B, H, W) of the current allocation
+        # one complete buffer set per (B, H, W): a captured hipGraph bakes buffer addresses in, so a forward at another
+        # shape (validation batch, partial last batch) must never free what a graph replays into
+        self._sets: Dict[tuple, dict] = {}
+        self._pinned = set()          # shapes a captured graph depends on: never evicted
+        self.max_shape_sets = int(os.environ.get("KODHIP_MAX_SHAPE_SETS", "4"))
         self.training_ready = False
         self.sync_bn = False
         self.process_group = None
@@ -187,6 +192,7 @@ class Engine:
         self.hyper = torch.zeros(10, dtype=torch.float32, device=device)
         # pinned staging ring: the H2D copy is asynchronous, so a slot is not rewritten for the next 15 uploads
         self._hyper_host = [torch.zeros(10, dtype=torch.float32).pin_memory() for _ in range(16)]
+        self._hyper_events = [None] * len(self._hyper_host)
         self._hyper_slot = 0
         self._hyper_vals = None
 
@@ -196,13 +202,52 @@ class Engine:
         return a[o:o + k].view(self.params[name].shape)
 
     # ------------------------------------------------------------------ activations
+    _UNIT_FIELDS = ("stats", "T", "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho",
+                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld")
+    _HEAD_FIELDS = ("H", "W", "M", "dy", "ws")
+
+    def _export_set(self) -> dict:
+        return dict(act=self.act, gact=self.gact, wg_part=self.wg_part, pool_idx=self.pool_idx,
+                    units={n: {f: getattr(st, f) for f in self._UNIT_FIELDS} for n, st in self.ustate.items()},
+                    heads={n: {f: hs[f] for f in self._HEAD_FIELDS} for n, hs in self.hstate.items()})
+
+    def _import_set(self, d: dict):
+        self.act, self.gact, self.wg_part, self.pool_idx = d["act"], d["gact"], d["wg_part"], d["pool_idx"]
+        for n, fields in d["units"].items():
+            st = self.ustate[n]
+            for f, v in fields.items():
+                setattr(st, f, v)
+        for n, fields in d["heads"].items():
+            self.hstate[n].update(fields)
+
+    def pin_shape(self, B: int, H: int, W: int):
+        """A captured graph replays into the buffer set of this shape: keep it for the engine's lifetime."""
+        self._pinned.add((B, H, W))
+
     def allocate(self, B: int, H: int, W: int):
-        if self.shape == (B, H, W):
+        """Make the buffer set of (B, H, W) current.  Sets are kept (a dict keyed by shape), never reallocated: a
+        forward at another shape swaps pointers and leaves the previous set - and any hipGraph captured over it -
+        intact.  Unpinned sets beyond KODHIP_MAX_SHAPE_SETS are dropped least-recently-used first."""
+        key = (B, H, W)
+        if self.shape == key:
             return
         assert H % 32 == 0 and W % 32 == 0, "image size must be a multiple of 32"
+        if self.shape is not None:
+            self._sets.pop(self.shape, None)
+            self._sets[self.shape] = self._export_set()          # (re-inserted last = most recently used)
+        self.training_ready = False                              # a pending backward belongs to the previous set
+        if key in self._sets:
+            d = self._sets.pop(key)
+            self._sets[key] = d
+            self._import_set(d)
+            self.shape = key
+            return
+        for old in [k for k in self._sets if k not in self._pinned][:max(0, len(self._sets) + 1 - self.max_shape_sets)]:
+            del self._sets[old]
         dev = self.device
         lib = self.lib
-        self.shape = (B, H, W)
+        self.shape = key
+        self._check_equal_local_batch(key)
         self.act: Dict[str, torch.Tensor] = {}
         self.gact: Dict[str, torch.Tensor] = {}
         for b in self.g.bufs:
@@ -253,6 +298,19 @@ class Engine:
             if op.kind == "pool":
                 h, w = H // op.src.stride, W // op.src.stride
                 self.pool_idx.append(torch.empty((B, h, w, op.src.C), dtype=torch.uint8, device=dev))
+
+    def _check_equal_local_batch(self, key):
+        """SyncBN here divides the all-reduced sums by M_local * world_size (torch's SyncBatchNorm all-gathers the
+        per-rank counts instead): that is only right when every rank holds the same number of pixels, so the first
+        allocation of a shape checks it across the group and refuses uneven local batches loudly."""
+        if not (self.collectives and self.sync_bn and self.world_size > 1):
+            return
+        import torch.distributed as dist
+        shapes = [None] * self.world_size
+        dist.all_gather_object(shapes, tuple(key), group=self.process_group)
+        if any(tuple(s) != tuple(key) for s in shapes):
+            raise RuntimeError(f"SyncBN needs the same local batch shape on every rank, got {shapes}: pad or drop the "
+                               "last uneven batch (DistributedSampler drop_last / padding)")
 
     def _plan_bn_fusion(self, B: int):
         """Static analysis of the backward program: for every conv unit U find the LAST launch that writes U's
@@ -414,7 +472,7 @@ class Engine:
                 outs.append(out)
         if training:
             self.nbt_arena += 1
-            self.training_ready = True
+        self.training_ready = training          # an eval forward overwrites the saved pre-BN tensors / BN constants
         return outs
 
     def _eval_affine(self, st):
@@ -614,10 +672,16 @@ class Engine:
         buffer the fused SGD kernel reads - outside any captured graph, so schedules keep working under replay."""
         vals = (*lr, *momentum, *weight_decay, grad_scale)
         if vals != self._hyper_vals:                       # only touch the device copy when the schedule moved
-            host = self._hyper_host[self._hyper_slot]
-            self._hyper_slot = (self._hyper_slot + 1) % len(self._hyper_host)
+            k = self._hyper_slot
+            self._hyper_slot = (k + 1) % len(self._hyper_host)
+            if self._hyper_events[k] is not None:          # the DMA that last read this pinned slot must have run
+                self._hyper_events[k].synchronize()
+            host = self._hyper_host[k]
             host.copy_(torch.tensor(vals, dtype=torch.float32))
             self.hyper.copy_(host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hyper_events[k] = ev
             self._hyper_vals = vals
 
     def sgd_step(self, lr, momentum, weight_decay, grad_scale: float = 1.0):

@@ -100,6 +100,7 @@ class GraphedTrainStep:
         preserve_state: parameters, momentum and BatchNorm buffers are restored afterwards, so that capturing
         does not move the training trajectory."""
         eng = self.eng
+        eng.pin_shape(self.B, self.H, self.W)      # the graph bakes this shape's buffer addresses in (Engine.allocate)
         self._load(images, targets)
         keep = [t.clone() for t in (eng.p_arena, eng.m_arena, eng.rm_arena, eng.rv_arena, eng.nbt_arena)] if preserve_state else None
         side = torch.cuda.Stream(device=eng.device)

@@ -24,6 +24,7 @@ from ...core.label_assignment.yv5 import BatchedTargets
 
 IOUS = (0.3, 0.5, 0.75, 0.9)            # pycoco_map_eval.py:45-48
 MAX_DETS = 100
+MAX_GT_PER_IMAGE = 256          # size of the per-lane 'matched' bitmap in map_match_kernel
 REC_THRS = np.linspace(0.0, 1.0, 101)
 
 
@@ -51,6 +52,9 @@ class DeviceMAPEvaluator:
                 det[b, :d.shape[0]] = d
         bt = targets if isinstance(targets, BatchedTargets) else BatchedTargets.from_targets(targets, dev)
         counts = torch.bincount(bt.samples.long(), minlength=B) if bt.n else torch.zeros(B, dtype=torch.long, device=dev)
+        if bt.n and int(counts.max()) > MAX_GT_PER_IMAGE:
+            raise ValueError(f"an image carries {int(counts.max())} ground-truth boxes; the device matcher tracks at most "
+                             f"{MAX_GT_PER_IMAGE} per image (csrc/map_match.hip)")
         start = torch.zeros(B + 1, dtype=torch.int32, device=dev)
         start[1:] = torch.cumsum(counts, 0).int()
         T = len(IOUS)

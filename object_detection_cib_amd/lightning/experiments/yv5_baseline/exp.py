@@ -13,8 +13,8 @@ import torch
 
 from ....core.types import FeatureShape
 from ....core.nms import non_max_suppression
-from ....nn.optim.smart import SmartSGD
-from ....nn.optim.schedulers import sch_linear
+from ....nn.optim.smart import SmartOptimizer, FusedSGD
+from ....nn.optim.schedulers import LinearScheduler
 from ...callbacks.map_eval import DeviceMAPEvaluator
 from .layers import get_detections
 from .type_defs import LayerwiseAnchorInfo
@@ -22,23 +22,46 @@ from .warmup import OptimizerWarmupUpdater
 
 
 class DefaultYolov5Experiment:
-    def __init__(self, net, loss, anchor_info: LayerwiseAnchorInfo, optimizer: Optional[SmartSGD] = None,
-                 sch_fn: Callable = None, optimizer_warmup_updater: Optional[OptimizerWarmupUpdater] = None,
-                 val_nms_conf_threshold: float = 0.001, val_nms_iou_threshold: float = 0.6, max_epochs: int = 300,
-                 graphed: bool = False, max_targets: int = 4096):
+    """Constructor = the reference's (exp.py:37-58: net, loss, anchor_info, smart_optimizer, lr_scheduler,
+    optimizer_warmup_updater, val_nms_conf_threshold, val_nms_iou_threshold); the keyword-only extras stand in for
+    what Lightning's Trainer supplies (`trainer.max_epochs`) or are build-side switches.  smart_optimizer /
+    lr_scheduler default to the reference's configs (configs/nn/optimizers/smart_sgd.yaml, schedulers/linear.yaml)."""
+
+    def __init__(self, net, loss, anchor_info: LayerwiseAnchorInfo, smart_optimizer: Optional[SmartOptimizer] = None,
+                 lr_scheduler: Optional[Callable] = None,
+                 optimizer_warmup_updater: Optional[OptimizerWarmupUpdater] = None,
+                 val_nms_conf_threshold: float = 0.001, val_nms_iou_threshold: float = 0.6, *, max_epochs: int = 300,
+                 graphed: bool = False, max_targets: int = 4096, world_size: int = 1):
         self.net, self.loss, self.anchor_info = net, loss, anchor_info
-        self.optimizer = optimizer or SmartSGD(net)
+        self.smart_optimizer = smart_optimizer or SmartOptimizer(
+            partial(torch.optim.SGD, lr=0.01, momentum=0.937, nesterov=True), weight_decay=0.0005)
+        self.lr_scheduler = lr_scheduler or partial(LinearScheduler, lrf=0.01)
         self.max_epochs = max_epochs
-        self.sch_fn = sch_fn or partial(sch_linear, max_epochs=max_epochs, lrf=0.01)   # configs/nn/schedulers/linear.yaml
         self.optimizer_warmup_updater = optimizer_warmup_updater
         self.val_nms_conf_threshold = val_nms_conf_threshold
         self.val_nms_iou_threshold = val_nms_iou_threshold
         self.global_step = 0
         self.current_epoch = 0
         self.logged = {}
+        self.world_size = world_size
+        self.optimizer = self.scheduler = None
         # graphed=True: the optimisation step is captured once as a hipGraph (engine/graphed.py) and replayed - same
         # arithmetic, no per-launch Python; batches must keep one shape and at most max_targets boxes
         self.graphed, self.max_targets, self._gstep = graphed, max_targets, None
+
+    # exp.py:156-162
+    def configure_optimizers(self):
+        if self.optimizer is None:
+            self.optimizer = self.smart_optimizer(self.net)
+            if isinstance(self.optimizer, FusedSGD):
+                self.optimizer.world_size = self.world_size
+            self.scheduler = self.lr_scheduler(optimizer=self.optimizer, max_epochs=self.max_epochs)
+        return [self.optimizer], [self.scheduler]
+
+    @property
+    def sch_fn(self):
+        self.configure_optimizers()
+        return self.scheduler.sch_fn
 
     def get_metrics_to_display(self):
         return ["box", "cls", "obj"]
@@ -68,6 +91,7 @@ class DefaultYolov5Experiment:
 
     # exp.py:164-185 + Lightning automatic optimisation
     def optimize(self, batch, num_training_batches: int):
+        self.configure_optimizers()
         if self.graphed:
             return self._optimize_graphed(batch, num_training_batches)
         self.optimizer.zero_grad(set_to_none=True)
@@ -92,19 +116,18 @@ class DefaultYolov5Experiment:
             B, _, H, W = images.shape
             self._gstep = GraphedTrainStep(self.net, self.loss, B, H, W, self.max_targets).capture(images, targets)
         self._warmup(num_training_batches)
-        g = self.optimizer.param_groups
-        total, (box, obj, cls) = self._gstep(images, targets, [float(x["lr"]) for x in g], [float(x["momentum"]) for x in g],
-                                             [float(x["weight_decay"]) for x in g], 1.0 / self.optimizer.world_size)
+        lr, mom, wd = self.optimizer.hyper()
+        total, (box, obj, cls) = self._gstep(images, targets, lr, mom, wd, 1.0 / self.optimizer.world_size)
         self.optimizer.steps_taken += 1
         self.logged = {"obj": obj, "cls": cls, "box": box}
         self.global_step += 1
         return total.clone()
 
     def end_epoch(self):
-        """LambdaLR.step(): lr = initial_lr * sch_fn(epoch) for the next epoch."""
+        """Lightning steps the epoch-interval scheduler: LambdaLR sets lr = initial_lr * lr_lambda(epoch)."""
+        self.configure_optimizers()
         self.current_epoch += 1
-        for pg in self.optimizer.param_groups:
-            pg["lr"] = pg["initial_lr"] * self.sch_fn(self.current_epoch)
+        self.scheduler.step()
 
     def fit_epoch(self, batches: Sequence, num_training_batches: Optional[int] = None):
         n = num_training_batches or len(batches)

@@ -97,6 +97,10 @@ class Yolov5Loss(nn.Module):
         self.assigner = assigner
         self.hparams = hparams
         self.iou_calculator = iou_calculator
+        kind = getattr(getattr(iou_calculator, "iou_type", None), "value", getattr(iou_calculator, "iou_type", None))
+        if kind != "ciou" or abs(float(getattr(iou_calculator, "eps", 1e-7)) - 1e-7) > 1e-12:
+            raise NotImplementedError("the fused HIP loss kernel implements iou_type=ciou, eps=1e-7 "
+                                      "(kod/configs/nn/losses/yv5.yaml:13-16)")
         # reference: plain attribute moved to CUDA when available (loss.py:58-61)
         self.weights = torch.tensor(weights, dtype=torch.float32) if weights is not None else None
 

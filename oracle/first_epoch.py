@@ -1,0 +1,124 @@
+"""Oracle: the reference CPU trainer's FIRST EPOCH on a synthetic coco-zipf-like set, and the mAP it reaches.
+
+TEST INFRASTRUCTURE - see oracle/__init__.py.  Restates, with the oracle's pinned pieces, what
+`python kod/cli/hydra_train.py experiment=yv5s trainer=cpu ...` does for one epoch:
+
+* per-sample protocol (mosaic + affine + HSV + flip)     kod/data/detection.py:102-156 -> oracle/datapath.py
+* training_step / automatic optimisation                  kod/lightning/experiments/yv5_baseline/exp.py:104-138
+* warm-up hook + SGD-nesterov groups                      exp.py:164-185, warmup.py:39-58, nn/optim/smart.py:36-58
+* validation_step (letter-box, decode, NMS .001 / .6)     exp.py:140-154, kod/core/nms.py:9-75
+* mAP report                                              kod/lightning/callbacks/pycoco_map_eval.py:106-125
+
+    python -m oracle.first_epoch            # writes tests/golden/first_epoch.npz (a few minutes of CPU)
+
+The HIP run of the same protocol (tests/test_hip_training.py::test_first_epoch_map_vs_cpu_trainer) feeds identical
+batches (the device compositing kernel is bit-exact against oracle/datapath.py) from identical seeds and initial
+weights; the two trainers then differ only by bf16 storage vs fp32, which decorrelates the trajectories after a
+few hundred steps, so the test compares epoch-level quantities (mean loss per phase, mAP) with the tolerances
+stated there.  A second CPU run with bf16-rounded weights/activations (oracle/bf16_emul.py) is recorded as the
+reference's own sensitivity to that perturbation.
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import datapath, detection as D, map_eval, optim as O, synth
+from .network import OracleYolov5
+
+# one config for both trainers; small enough that the CPU side takes minutes, long enough that mAP leaves zero
+CONFIG = dict(widen=0.5, deepen=0.33, nc=10, S=160, B=16, n_train=8000, n_val=256, seed=2023, data_seed=77,
+              conf_thres=0.001, nms_thres=0.6)
+
+
+def epoch_order(cfg) -> np.ndarray:
+    return np.random.default_rng(cfg["seed"]).permutation(cfg["n_train"])
+
+
+def validation_batches(cfg, val):
+    S, B = cfg["S"], cfg["B"]
+    out = []
+    for k in range(0, len(val), B):
+        imgs, tg = [], []
+        for im, bb, lb in val[k:k + B]:
+            x, b = datapath.val_sample(im, bb, S)
+            imgs.append(torch.from_numpy(np.ascontiguousarray(x)))
+            tg.append((b, lb))
+        out.append((torch.stack(imgs), tg))
+    return out
+
+
+def evaluate(cfg, net, val):
+    net.eval()
+    per_image = []
+    with torch.no_grad():
+        for x, tg in validation_batches(cfg, val):
+            det = D.decode(net(x), cfg["S"], cfg["S"])
+            for d, (b, l) in zip(D.nms(det, cfg["conf_thres"], cfg["nms_thres"]), tg):
+                per_image.append(map_eval.match_image(d.numpy(), b, l, cfg["nc"]))
+    net.train()
+    return map_eval.report(map_eval.accumulate(per_image, cfg["nc"]))
+
+
+def run_cpu(cfg=CONFIG, emulate_bf16: bool = False, log=None):
+    S, B, nc, seed = cfg["S"], cfg["B"], cfg["nc"], cfg["seed"]
+    train = synth.coco_zipf_like(cfg["n_train"], S, cfg["data_seed"], nc)
+    val = synth.coco_zipf_like(cfg["n_val"], S, cfg["data_seed"] + 1, nc)
+    torch.manual_seed(seed)
+    net = OracleYolov5(3, nc, cfg["widen"], cfg["deepen"]).train()
+    if emulate_bf16:
+        from . import bf16_emul
+        net = bf16_emul.emulate(net)
+    bias, decay, norm = O.param_groups(net)
+    opt = torch.optim.SGD([dict(params=bias, weight_decay=0.0), dict(params=decay, weight_decay=O.WEIGHT_DECAY),
+                           dict(params=norm, weight_decay=0.0)], lr=O.LR0, momentum=O.MOMENTUM, nesterov=True)
+    order = epoch_order(cfg)
+    n_batches = len(order) // B
+    nw = O.warmup_steps(n_batches)
+    random.seed(seed); np.random.seed(seed)
+    rng = np.random.default_rng(51)
+    losses = np.zeros((n_batches, 4))
+    t0 = time.time()
+    for step in range(n_batches):
+        samples = [datapath.train_sample(train, int(i), S, rng) for i in order[step * B:(step + 1) * B]]
+        x = torch.from_numpy(np.stack([s[0] for s in samples]))
+        tg = [D.Target(torch.from_numpy(s[1]), torch.from_numpy(s[2])) for s in samples]
+        w = O.warmup_values(step, 0, nw)
+        for pg, name in zip(opt.param_groups, O.GROUP_NAMES):
+            pg["lr"], pg["momentum"] = w[name]
+        opt.zero_grad(set_to_none=True)
+        lr = D.yolo_loss(S, S, net(x), tg)
+        tot = D.train_step_total(lr, B)
+        tot.backward()
+        opt.step()
+        losses[step] = (lr.localization.item(), lr.objectness.item(), lr.classification.item(), tot.item())
+        if log and (step % 50 == 0 or step == n_batches - 1):
+            log(f"step {step}/{n_batches} total {tot.item():.4f}  ({time.time() - t0:.0f}s)")
+    rep = evaluate(cfg, net, val)
+    return dict(losses=losses, report=rep)
+
+
+def main():
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "first_epoch.npz")
+    torch.set_num_threads(os.cpu_count() or 1)
+    log = lambda s: print(s, file=sys.stderr, flush=True)
+    fp32 = run_cpu(CONFIG, False, log)
+    log(f"fp32 CPU trainer: {fp32['report']}")
+    emu = run_cpu(CONFIG, True, log)
+    log(f"bf16-storage emulation: {emu['report']}")
+    keys = ("map", "map30", "map50", "map75", "map90")
+    np.savez_compressed(out, config=np.array([repr(sorted(CONFIG.items()))]),
+                        losses_fp32=fp32["losses"], losses_bf16emu=emu["losses"],
+                        map_fp32=np.array([fp32["report"][k] for k in keys]),
+                        map_bf16emu=np.array([emu["report"][k] for k in keys]),
+                        map_keys=np.array(keys))
+    print(f"wrote {out}")
+
+
+if __name__ == "__main__":
+    main()

@@ -59,7 +59,49 @@ def gen_iou():
     b1g = b1.clone().requires_grad_(True)
     iou.compute_ciou(b1g, b2).sum().backward()
     out["ciou_grad_b1"] = _np(b1g.grad)
+    # backward of every kind w.r.t. both box tensors under a seeded (non-uniform) upstream gradient
+    gout = torch.randn(64, generator=torch.Generator().manual_seed(8))
+    out["gout"] = _np(gout)
+    for kind in ("iou", "giou", "diou", "ciou"):
+        a, b = b1.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+        (iou.IoUCalculator(iou.IoUType(kind), 1e-7)(a, b) * gout).sum().backward()
+        out[f"{kind}_gw_b1"], out[f"{kind}_gw_b2"] = _np(a.grad), _np(b.grad)      # d sum(out * gout) / d boxes
     np.savez(os.path.join(OUT, "iou.npz"), **out)
+
+
+def gen_samplers():
+    """kod/data/samplers.py:41-138 on a synthetic DatasetInfo (oracle.synth.dataset_info): the ClassAware index
+    stream under torch.manual_seed(2023), repeat factors (mean / max / no sqrt / threshold) and RepeatFactor draws."""
+    import datetime
+    S = R.ref("kod.data.samplers")
+    C = R.ref("kod.data.cache")
+    B = R.ref("kod.core.bbox.boxes")
+    spec = synth.dataset_info_spec(48, 6, seed=5)
+    meta = C.ImageMetadata(width=64, height=48, num_channels=3, mime_type="image/jpeg", size_bytes=1)
+    samples = [C.SampleInfo(id=sid, image_path=f"/nowhere/{sid}.jpg", image_metadata=meta,
+                            targets=[C.TargetInfo(bounding_box=B.XYXYBoundingBox(*bb), class_name=cn) for bb, cn in tg])
+               for sid, tg in spec["samples"]]
+    ds = C.DatasetInfo(name="synthetic", date=datetime.datetime(2023, 1, 1), classes=list(spec["classes"]), samples=samples)
+    out = {}
+    torch.manual_seed(2023)
+    cas = S.ClassAwareSampler(ds)
+    out["class_aware_epoch0"] = np.array(list(iter(cas)), dtype=np.int64)
+    out["class_aware_epoch1"] = np.array(list(iter(cas)), dtype=np.int64)
+    import contextlib, io
+    for tag, kw in (("mean", dict()), ("max", dict(reduction="max")), ("nosqrt", dict(use_sqrt=False)),
+                    ("thr05", dict(threshold=0.5))):
+        with contextlib.redirect_stdout(io.StringIO()):
+            rfs = S.RepeatFactorSampler(ds, **kw)
+        out[f"repeat_factors_{tag}"] = np.array(rfs.image_repeat_factors, dtype=np.float64)
+        out[f"repeat_draws_{tag}"] = np.array(list(iter(rfs)), dtype=np.int64)
+    torch.manual_seed(7)
+    rc = S.RandomCycleSampler([10, 11, 12, 13, 14])
+    out["random_cycle"] = np.array([next(rc) for _ in range(13)], dtype=np.int64)
+    out["instance_count"] = np.array(list(ds.get_instance_count().values()), dtype=np.int64)
+    flt = R.ref("kod.data.filter").filter_dataset(ds, "sub", [spec["classes"][1], spec["classes"][3]])
+    out["filter_ids"] = np.array([int(s.id) for s in flt.samples], dtype=np.int64)
+    out["filter_ntargets"] = np.array([len(s.targets) for s in flt.samples], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "samplers.npz"), **out)
 
 
 def gen_assigner():
@@ -277,10 +319,14 @@ def gen_affine_boxes():
 
 
 def main():
+    import sys
     assert R.available(), "reference checkout not found"
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])                      # e.g. `python -m oracle.gen_golden gen_iou gen_samplers`
     for fn in (gen_iou, gen_assigner, gen_loss, gen_network, gen_decode_nms, gen_optim, gen_mosaic,
-               gen_affine_boxes):
+               gen_affine_boxes, gen_samplers):
+        if only and fn.__name__ not in only:
+            continue
         try:
             fn()
             print("ok  ", fn.__name__)

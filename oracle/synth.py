@@ -166,3 +166,23 @@ def coco_zipf_like(n: int, S: int, seed: int, nc: int = 10):
             boxes.append([x1, y1, x2, y2]); labels.append(c)
         out.append((img, np.array(boxes, dtype=np.float64), np.array(labels, dtype=np.int64)))
     return out
+
+
+def dataset_info_spec(n: int, n_classes: int, seed: int):
+    """Plain-data description of a DatasetInfo (kod/data/cache.py:21-50): class names + per sample (id, [(xyxy, class)]).
+    Zipf-like class frequencies; every class occurs; sample ids are decimal strings."""
+    rng = np.random.default_rng(seed)
+    classes = [f"class_{chr(97 + i)}" for i in range(n_classes)]
+    pmf = zipf_pmf(n_classes)
+    samples = []
+    for i in range(n):
+        k = int(rng.integers(1, 5))
+        cls = [int(c) for c in rng.choice(n_classes, size=k, p=pmf)]
+        if i < n_classes:
+            cls[0] = i                                     # every class has at least one image
+        tg = []
+        for c in cls:
+            x1, y1 = rng.uniform(0, 40), rng.uniform(0, 30)
+            tg.append(((float(x1), float(y1), float(x1 + rng.uniform(3, 20)), float(y1 + rng.uniform(3, 15))), classes[c]))
+        samples.append((str(1000 + i), tg))
+    return {"classes": classes, "samples": samples}

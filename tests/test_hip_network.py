@@ -3,8 +3,13 @@ pinned to the reference by tests/test_oracle_golden.py.
 
 Tolerances (north star: "to a stated fp tolerance"): the HIP path stores activations / activation
 gradients in bf16 and accumulates in fp32; SURVEY.md B.7 measured the reference's own fp32-vs-bf16-autocast
-sensitivity at loss 1.4e-3 and grad-norm 2.4e-2 relative.  We require: losses <= 1e-2 rel, global
-gradient norm <= 5e-2 rel, per-tensor gradient cosine >= 0.98 for tensors carrying >= 0.1 % of the norm.
+sensitivity at loss 1.4e-3 and grad-norm 2.4e-2 relative.  Bars:
+* B=2 cases (BASELINE configs[0] shape): losses <= 1e-2 rel at 640 px (2e-2 / 3e-2 at 160 / 64 px), global gradient
+  norm <= 1e-1 rel - train-mode BatchNorm over 2 images amplifies bf16 rounding ~2x per layer (DESIGN 5);
+* B=16 at 640 px, where every BatchNorm sees >= 6400 samples per channel (test_train_step_well_conditioned_batch):
+  losses <= 1e-2 rel, global gradient norm <= 5e-2 rel, per-tensor gradient cosine >= 0.98 for every tensor
+  carrying >= 0.1 % of the gradient norm;
+* every layer in situ (teacher-forced, no amplification): <= 4e-3 .. 2e-2 relL2, also at B=64 / 640 px.
 """
 import numpy as np
 import pytest
@@ -90,6 +95,144 @@ def test_train_step_vs_oracle(case):
         if size >= 160:
             assert _rel(a, b) <= tol, (suffix, _rel(a, b))
     assert all(int(sd_h[k]) == int(sd_r[k]) == 1 for k in sd_r if k.endswith("num_batches_tracked"))
+
+
+def test_train_step_well_conditioned_batch():
+    """B=16 at 640 px: BatchNorm statistics are well conditioned (>= 6400 samples per channel in the deepest layers), so
+    a real bug and bf16 chaos separate: losses <= 1e-2, global gradient norm <= 5e-2, and every parameter tensor that
+    carries >= 0.1 % of the gradient norm has cosine >= 0.98 with the fp32 oracle's gradient."""
+    widen, deepen, nc, B, size, seed = 0.5, 0.33, 10, 16, 640, 2023
+    torch.manual_seed(seed)
+    ref = OracleYolov5(3, nc, widen, deepen).train()
+    torch.manual_seed(seed)
+    net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen).cuda().train()
+    x, tg = synth.batch(B, size, nc, seed)
+    lr = D.yolo_loss(size, size, ref(x), [D.Target(b, l) for b, l in tg])
+    tot = D.train_step_total(lr, B)
+    tot.backward()
+    _, lr_h, tot_h = _step(net, x.cuda(), tg, size, B)
+    got = np.array([lr_h.localization.item(), lr_h.objectness.item(), lr_h.classification.item(), tot_h.item()])
+    want = np.array([lr.localization.item(), lr.objectness.item(), lr.classification.item(), tot.item()])
+    np.testing.assert_allclose(got, want, rtol=1e-2)
+    gr = {k: p.grad.double() for k, p in ref.named_parameters()}
+    gh = {k: p.grad.detach().cpu().double() for k, p in net.named_parameters()}
+    gn_r = torch.sqrt(sum((g ** 2).sum() for g in gr.values())).item()
+    gn_h = torch.sqrt(sum((g ** 2).sum() for g in gh.values())).item()
+    assert abs(gn_h - gn_r) <= 5e-2 * gn_r, (gn_h, gn_r)
+    worst, checked = (1.0, None), 0
+    for k, g in gr.items():
+        if g.norm().item() < 1e-3 * gn_r:
+            continue
+        cos = (g.flatten() @ gh[k].flatten() / (g.norm() * gh[k].norm() + 1e-300)).item()
+        worst = min(worst, (cos, k))
+        checked += 1
+    print(f"well-conditioned batch: grad norm HIP {gn_h:.4f} vs oracle {gn_r:.4f}; {checked} tensors, worst cosine {worst}")
+    assert checked >= 100 and worst[0] >= 0.98, worst
+    # BN running statistics, network-wide
+    sd_r, sd_h = ref.state_dict(), net.state_dict()
+    for suffix, tol in (("running_mean", 2e-2), ("running_var", 5e-3)):
+        a = torch.cat([sd_h[k].cpu().flatten() for k in sd_r if k.endswith(suffix)])
+        b = torch.cat([sd_r[k].flatten() for k in sd_r if k.endswith(suffix)])
+        assert _rel(a, b) <= tol, (suffix, _rel(a, b))
+
+
+def test_bench_geometry_b64_640_deterministic_and_teacher_forced():
+    """BASELINE configs[1] at its real batch: B=64, 640 px (M up to 6.55 M pixels: 256-pixel tiles, full split-K /
+    statistic-slot geometry, exactly what bench.py times).  (1) two steps on the same batch give bit-identical
+    gradients for every parameter; (2) the six largest-M units plus the first stride-2 stage conv are checked
+    teacher-forced (fp32 torch on the HIP path's own bf16 inputs): raw conv output, BatchNorm batch statistics, dW."""
+    import torch.nn.functional as F
+    widen, deepen, nc, B, size, seed = 0.5, 0.33, 10, 64, 640, 2023
+    torch.manual_seed(seed)
+    net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen).cuda().train()
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(seed))
+    tg = synth.targets(B, size, nc, seed, nmin=4, nmax=30)
+    xg = x.cuda()
+    runs = []
+    for _ in range(2):
+        for p in net.parameters():
+            p.grad = None
+        _, lr, tot = _step(net, xg, tg, size, B)
+        runs.append((tot.item(), torch.cat([p.grad.flatten() for p in net.parameters()]).clone()))
+    assert np.isfinite(runs[0][0]) and runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]), "gradients differ between two runs of the same step"
+    eng = net.engine()
+    grads = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    params = {k: p.detach().cpu() for k, p in net.named_parameters()}
+    bf = lambda t: t.to(torch.bfloat16).float()
+    units = sorted(eng.exec_units, key=lambda u: -eng.ustate[u.name].M)[:6]
+    units += [u for u in eng.exec_units if u.name == "backbone.stages.stage2.blocks.0"]
+    worst, ref_y = {}, {}
+    for u in units:
+        st = eng.ustate[u.name]
+        # NOTE st.raw holds dY after backward; the forward's pre-BN tensor is recomputed by one more forward below
+        X = bf(x) if u.stem else eng.act[u.src.buf.name][..., u.src.coff:u.src.coff + u.src.C].float().permute(0, 3, 1, 2).cpu()
+        W = bf(params[u.name + ".0.weight"]).requires_grad_(True)
+        y = F.conv2d(X, W, None, u.s, u.p)
+        dY = st.raw.float().permute(0, 3, 1, 2).cpu()
+        y.backward(dY)
+        worst.setdefault("dW", 0.0)
+        e = _rel(grads[u.name + ".0.weight"], W.grad)
+        worst["dW"] = max(worst["dW"], e)
+        assert e <= 5e-3, ("dW", u.name, e)
+        ref_y[u.name] = y.detach()
+    with torch.no_grad():
+        net.forward_raw(xg)             # train-mode forward again: st.raw = pre-BN output, st.aff = batch statistics
+    for u in units:
+        st = eng.ustate[u.name]
+        raw = st.raw.float().permute(0, 3, 1, 2).cpu()
+        e = _rel(raw, ref_y.pop(u.name))
+        worst["conv_raw"] = max(worst.get("conv_raw", 0.0), e)
+        assert e <= 4e-3, ("conv_raw", u.name, e)
+        C_ = u.cout
+        aff = st.aff.cpu().double()
+        r64 = raw.double()
+        mean = r64.mean((0, 2, 3))
+        var = r64.var((0, 2, 3), unbiased=False)
+        e_m = ((aff[2 * C_:3 * C_] - mean).abs().max() / (var.sqrt().max() + 1e-30)).item()
+        e_r = _rel(aff[3 * C_:4 * C_], 1.0 / torch.sqrt(var + 1e-3))
+        worst["bn_mean"], worst["bn_rstd"] = max(worst.get("bn_mean", 0.0), e_m), max(worst.get("bn_rstd", 0.0), e_r)
+        assert e_m <= 1e-4 and e_r <= 1e-4, ("bn stats", u.name, e_m, e_r)
+    print("B=64/640 teacher-forced worst:", {k: round(v, 6) for k, v in worst.items()}, [u.name for u in units])
+
+
+def test_eval_mode_forward_vs_oracle_through_decode():
+    """Validation path net.eval() -> decode: after a few HIP training steps (non-trivial running statistics) the same
+    state_dict is loaded into the fp32 oracle; eval-mode head outputs and the decoded [B, 25200-like, 5+nc] tensor
+    must agree (no train-mode BN amplification in eval => a tight bar for bf16 storage)."""
+    from object_detection_cib_amd.core.anchors.info import voc_anchor_info as vai
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.layers import get_detections
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.type_defs import LayerwiseAnchorInfo
+    widen, deepen, nc, B, size, seed = 0.5, 0.33, 10, 4, 320, 17
+    torch.manual_seed(seed)
+    net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen).cuda().train()
+    for step in range(4):
+        x, tg = synth.batch(B, size, nc, seed + step)
+        for p in net.parameters():
+            p.grad = None
+        _step(net, x.cuda(), tg, size, B)
+        net.engine().sgd_step((0.05, 0.01, 0.01), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0))
+    ref = OracleYolov5(3, nc, widen, deepen)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    ref.eval(); net.eval()
+    x, _ = synth.batch(B, size, nc, seed + 100)
+    with torch.no_grad():
+        out_r = ref(x)
+        out_h = net(x.cuda())
+        det_r = D.decode(out_r, size, size)
+        det_h = get_detections(FeatureShape(width=size, height=size), out_h, LayerwiseAnchorInfo(vai(8), vai(16), vai(32))).cpu()
+    worst = 0.0
+    for hr, hh in zip(out_r, out_h):
+        for tr, th in zip(hr, hh):
+            worst = max(worst, _rel(th.cpu(), tr))
+    print("eval-mode head logits worst relL2:", worst, "decoded max|dprob|", (det_h[..., 4:] - det_r[..., 4:]).abs().max().item())
+    assert worst <= 2e-2, worst
+    assert det_h.shape == det_r.shape
+    assert (det_h[..., 4:] - det_r[..., 4:]).abs().max() <= 2e-2
+    assert _rel(det_h[..., :4], det_r[..., :4]) <= 1e-2
+    # an eval forward must not touch the BatchNorm buffers
+    sd = net.state_dict()
+    assert all(torch.equal(sd[k].cpu(), v) for k, v in ref.state_dict().items() if "running" in k or "num_batches" in k)
 
 
 @pytest.mark.parametrize("case", ["yv5s_160", "yv5s_640", "yv5m_96", "yv5s_rect160x224", "yv5n_rect192x96"])

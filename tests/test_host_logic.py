@@ -74,9 +74,16 @@ def test_batched_targets_cpu():
 
 def test_iou_calculator_contract():
     from object_detection_cib_amd.core.bbox.iou import IoUCalculator, IoUType
+    from object_detection_cib_amd.core.bbox import iou as I
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.loss import Yolov5Loss, Yolov5LossParams
     assert IoUCalculator("ciou", 1e-7).iou_type is IoUType.ciou
-    with pytest.raises(NotImplementedError):
-        IoUCalculator("giou")
+    assert [t.value for t in IoUType] == ["iou", "giou", "diou", "ciou"]            # iou.py:9-14
+    for kind, fn in (("iou", I.compute_iou), ("giou", I.compute_giou), ("diou", I.compute_diou), ("ciou", I.compute_ciou)):
+        assert IoUCalculator(IoUType(kind), 1e-6).fn is fn                          # iou.py:254-261
+    with pytest.raises(RuntimeError):          # no CPU fallback: the op is HIP only
+        IoUCalculator(IoUType.giou)(torch.zeros(2, 4), torch.zeros(2, 4))
+    with pytest.raises(NotImplementedError):   # the fused loss kernel is CIoU / 1e-7 only
+        Yolov5Loss(None, Yolov5LossParams.get_default(), IoUCalculator("giou"), None)
 
 
 def test_device_pipeline_host_math_matches_golden(golden):
@@ -117,11 +124,8 @@ def test_samplers_and_schedule_host_mirrors(golden):
     from object_detection_cib_amd.lightning.experiments.yv5_baseline.warmup import OptimizerWarmupUpdater
     from functools import partial
     g = golden("optim")
-    # warm-up + schedule against the reference vectors (driving a SmartSGD-shaped group list)
-    class _Net:
-        def parameters(self):
-            return []
-    opt = SmartSGD(_Net())
+    # warm-up + schedule against the reference vectors, driving the optimizer SmartOptimizer builds (three named groups)
+    opt = SmartSGD(torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4)))
     assert [pg["name"] for pg in opt.param_groups] == g["group_names"].tolist()
     assert [pg["weight_decay"] for pg in opt.param_groups] == g["group_wd"].tolist()
     upd = OptimizerWarmupUpdater(3, 0.1, 0.8, 0.937)
@@ -131,21 +135,46 @@ def test_samplers_and_schedule_host_mirrors(golden):
         upd(current_step=int(st), current_epoch=int(st) // 220, max_warmup_steps=660, sch_fn=fn, optimizer=opt)
         np.testing.assert_array_equal([pg["lr"] for pg in opt.param_groups], lr)
         np.testing.assert_array_equal([pg["momentum"] for pg in opt.param_groups], mom)
-    # samplers: class-aware covers classes uniformly; repeat factors follow the reference formula
-    torch.manual_seed(0)
-    cas = S.ClassAwareSampler([[0, 1, 2], [3], [4, 5]], 600)
-    idx = list(iter(cas))
-    assert len(idx) == 600 and cas.sampler_indices == idx
-    counts = np.bincount(idx, minlength=6)
-    assert abs(counts[3] - 200) <= 1 and abs(counts[:3].sum() - 200) <= 1
-    rf = S.image_repeat_factors([[0, 0, 1], [1], []], [30, 10], threshold=1.0, reduction=None)
-    r0, r1 = max(1.0, 1 / 0.75) ** 0.5, max(1.0, 1 / 0.25) ** 0.5
-    np.testing.assert_allclose(rf, [(2 * r0 + r1) / (3 + 1e-6), r1 / (1 + 1e-6), 0.0])
-    assert S.image_repeat_factors([[0, 1]], [30, 10], reduction="max") == [r1]
-    rs = S.RepeatFactorSampler([1.0, 2.0, 1.0, 4.0])
-    a = list(iter(rs))
-    rs2 = S.RepeatFactorSampler([1.0, 2.0, 1.0, 4.0])
-    assert a == list(iter(rs2)) and len(a) == 4
+
+
+def _dataset_info():
+    import datetime
+    from oracle import synth
+    from object_detection_cib_amd.data.cache import DatasetInfo, SampleInfo, TargetInfo, ImageMetadata
+    spec = synth.dataset_info_spec(48, 6, seed=5)
+    meta = ImageMetadata(width=64, height=48, num_channels=3, mime_type="image/jpeg", size_bytes=1)
+    samples = [SampleInfo(id=sid, image_path=f"/nowhere/{sid}.jpg", image_metadata=meta,
+                          targets=[TargetInfo(bounding_box=bb, class_name=cn) for bb, cn in tg]) for sid, tg in spec["samples"]]
+    return DatasetInfo(name="synthetic", date=datetime.datetime(2023, 1, 1), classes=list(spec["classes"]), samples=samples), spec
+
+
+def test_samplers_match_reference_outputs(golden):
+    """kod/data/samplers.py run on the same synthetic DatasetInfo (oracle/gen_golden.py::gen_samplers): the host
+    mirrors reproduce the reference's index streams, repeat factors, instance counts and filter bit for bit."""
+    from object_detection_cib_amd.data import samplers as S
+    from object_detection_cib_amd.data.filter import filter_dataset
+    g = golden("samplers")
+    ds, spec = _dataset_info()
+    np.testing.assert_array_equal(list(ds.get_instance_count().values()), g["instance_count"])
+    torch.manual_seed(2023)
+    cas = S.ClassAwareSampler(ds)
+    e0 = list(iter(cas))
+    assert cas.sampler_indices == e0 and len(cas) == len(ds.samples)
+    np.testing.assert_array_equal(e0, g["class_aware_epoch0"])
+    np.testing.assert_array_equal(list(iter(cas)), g["class_aware_epoch1"])
+    for tag, kw in (("mean", dict()), ("max", dict(reduction="max")), ("nosqrt", dict(use_sqrt=False)),
+                    ("thr05", dict(threshold=0.5))):
+        rfs = S.RepeatFactorSampler(ds, **kw)
+        np.testing.assert_array_equal(np.array(rfs.image_repeat_factors), g[f"repeat_factors_{tag}"])
+        np.testing.assert_array_equal(list(iter(rfs)), g[f"repeat_draws_{tag}"])
+    torch.manual_seed(7)
+    rc = S.RandomCycleSampler([10, 11, 12, 13, 14])
+    np.testing.assert_array_equal([next(rc) for _ in range(13)], g["random_cycle"])
+    flt = filter_dataset(ds, "sub", [spec["classes"][1], spec["classes"][3]])
+    np.testing.assert_array_equal([int(s.id) for s in flt.samples], g["filter_ids"])
+    np.testing.assert_array_equal([len(s.targets) for s in flt.samples], g["filter_ntargets"])
+    with pytest.raises(ValueError):
+        filter_dataset(ds, "bad", ["no_such_class"])
 
 
 def test_checkpoint_optimizer_param_order_matches_smart_optimizer():
