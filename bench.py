@@ -26,6 +26,16 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_IMG_BF16 = 371.5e6        # 3 * (sum conv inputs + sum conv outputs) * 2 B
 ALGO_FLOP_PER_IMG = 46.785e9             # fwd + dgrad + wgrad, 2*MAC
 HBM_PEAK = 8.0e12                        # B/s, MI355X_MICROARCH.md chip table
+FAMILY_KERNELS = {
+    "conv_fwd": "conv_igemm_kernel<MODE_RAW> (forward conv + BN statistics, 57 layers)",
+    "dgrad": "conv_igemm[_x4]_kernel<MODE_PLAIN> (data gradient)",
+    "dgrad+bn_reduce": "conv_igemm[_x4]_kernel<MODE_PLAIN_BN> (data gradient + fused BatchNorm-backward reduction)",
+    "wgrad": "conv_wgrad_dma_kernel + wgrad_reduce_kernel (weight gradient)",
+    "bn_silu_apply": "bn_silu_apply_kernel (BatchNorm + SiLU forward, residual add)",
+    "bn_silu_bwd_apply": "bn_silu_bwd_apply_kernel (BatchNorm + SiLU backward)",
+    "bn_finalize": "bn_finalize_fused_kernel", "bn_bwd_coeffs": "bn_bwd_coeffs_fused_kernel",
+    "bn_bwd_reduce": "bn_silu_bwd_reduce_kernel",
+}
 
 
 def synth_batch(B, size, nc, seed, device):
@@ -96,21 +106,50 @@ def cpu_baseline(seconds=15.0):
             "sample": f"{n} train steps of yv5s B=2 640px fp32 (oracle/ CPU restatement) in {dt:.1f}s"}
 
 
-def pmc_traffic(B, S):
-    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes (counters cannot
-    be read from inside this process; tools/pmc_traffic.py documents the collection and the gfx950 corrections)."""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(p) or (B, S) != (64, 640):
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+
+def pmc_traffic(family, B, S):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (counters cannot be read from
+    inside this process; tools/pmc_traffic.py documents the collection and the gfx950 corrections).  The passes are
+    only valid for the kernels they were collected on: if any csrc/ file is newer than the JSON's recorded source
+    digest, the number is stale and the bench refuses to quote it."""
+    if not os.path.exists(PMC_JSON) or (B, S) != (64, 640):
         return None
-    with open(p) as f:
-        return round(json.load(f)["traffic_bytes_per_launch"])
+    with open(PMC_JSON) as f:
+        d = json.load(f)
+    from object_detection_cib_amd import build as kb
+    import glob
+    dig = kb._digest(sorted(glob.glob(os.path.join(kb.CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(kb.CSRC, "*.h"))))
+    if d.get("csrc_digest") != dig:
+        raise SystemExit(f"{PMC_JSON} was collected on other kernel sources (digest {d.get('csrc_digest')!r} != {dig!r}): "
+                         "re-run tools/pmc_traffic.py on the GPU box or remove the file")
+    fam = d.get("families", {}).get(family)
+    return round(fam["traffic_bytes_per_launch"]) if fam else None
+
+
+def family_table(prof, steps_ms):
+    """Per kernel family of one eager step: launches, summed event time, algorithmic bytes (SURVEY 8d byte model for
+    the convolutions; bytes actually touched for the BatchNorm / SiLU passes), achieved GB/s and fraction of 8 TB/s."""
+    fam = {}
+    for name, e0, e1, nb in prof:
+        f = fam.setdefault(name, [0, 0.0, 0.0])
+        f[0] += 1
+        f[1] += e0.elapsed_time(e1)
+        f[2] += nb
+    rows = []
+    for name, (n, ms, nb) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        gbs = nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        rows.append({"family": name, "launches": n, "ms": round(ms, 3), "share_of_step": round(ms / steps_ms, 3),
+                     "algorithmic_MB": round(nb / 1e6, 1), "GB/s": round(gbs, 1), "frac": round(gbs * 1e9 / HBM_PEAK, 4)})
+    return rows
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,8 +250,6 @@ def main():
             for _ in range(2):
                 last = step()
     barrier()
-    if graph is None:
-        eng.profile = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if graph is not None:
@@ -221,17 +258,17 @@ def main():
             last = step()
     barrier()
     dt = time.perf_counter() - t0
-    if graph is None:
-        prof = eng.profile
-        eng.profile = None
-    else:
-        # per-kernel durations of the dominant family: one extra eager step on the launch stream, outside the
-        # timed region (events cannot be read back from inside a replayed graph)
-        eng.profile = []
-        step()
-        torch.cuda.synchronize()
-        prof = eng.profile
-        eng.profile = None
+    # per-kernel durations of every family: one extra eager step with HIP events around each launch on its launch
+    # stream, outside the timed region (events cannot be read back from inside a replayed graph); weight gradients
+    # on the main stream for this step so that the families do not overlap each other
+    eng.profile = None
+    ov, eng.wgrad_overlap = eng.wgrad_overlap, False
+    step(); step()
+    eng.profile = []
+    step()
+    torch.cuda.synchronize()
+    prof = eng.profile
+    eng.profile, eng.wgrad_overlap = None, ov
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -240,11 +277,10 @@ def main():
 
     if rank == 0:
         ips = world * B * args.steps / dt
-        # roofline of the dominant kernel family: algorithmic bytes = read input once + write output once
-        k_ms = sum(a.elapsed_time(b) for a, b, _ in prof)
-        k_bytes = sum(nb for _, _, nb in prof)
-        n_launch = max(len(prof), 1)
-        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # roofline: the kernel family with the largest share of the step (event-timed, see above)
+        table = family_table(prof, 1e3 * dt / args.steps)
+        top = table[0]
+        n_launch = max(top["launches"], 1)
         out = {
             "metric": "images/sec YOLOv5s 640px train", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -259,11 +295,13 @@ def main():
                               "achieved": round(ips / world * ALGO_BYTES_PER_IMG_BF16 / 1e9, 1), "peak": HBM_PEAK / 1e9,
                               "unit": "GB/s", "frac": round(ips / world * ALGO_BYTES_PER_IMG_BF16 / HBM_PEAK, 4),
                               "tflops": round(ips / world * ALGO_FLOP_PER_IMG / 1e12, 1)},
-            "roofline": {"kernel": "conv_igemm_kernel<MODE_RAW> (forward conv, all 57 layers)", "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": pmc_traffic(B, S),
-                         "avg_launch_us": round(1e3 * k_ms / n_launch, 2), "launches": len(prof),
-                         "algorithmic_bytes_per_launch_avg": round(k_bytes / n_launch)},
+            "roofline": {"kernel": FAMILY_KERNELS.get(top["family"], top["family"]), "family": top["family"], "bound": "hbm",
+                         "achieved": top["GB/s"], "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": top["frac"],
+                         "traffic": pmc_traffic(top["family"], B, S),
+                         "avg_launch_us": round(1e3 * top["ms"] / n_launch, 2), "launches": top["launches"],
+                         "algorithmic_bytes_per_launch_avg": round(1e6 * top["algorithmic_MB"] / n_launch),
+                         "share_of_step": top["share_of_step"]},
+            "families": table,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

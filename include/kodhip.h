@@ -14,7 +14,11 @@
  *     the message (thread local);
  *   - activations are channels-last bf16 [B][H][W][ld]; a tensor may be a channel slice (ld, coff) of a
  *     wider concat buffer - that is how torch.cat (csp.py:109, sppf.py:76, yolov5_pafpn.py:186,199)
- *     disappears; all channel counts / offsets are multiples of 8 (16-byte accesses).
+ *     disappears; all channel counts / offsets are multiples of 8 (16-byte accesses);
+ *   - packed MFMA weight operands (kodhip_pack_weights) have a tap-major K axis with every tap padded to a
+ *     multiple of 32 channels: w_packed [N][Kp], k = tap * round_up(Cin, 32) + ci, Kp = KH*KW*round_up(Cin, 32);
+ *     w_dgrad [Cin][Kdp], k = tap * round_up(N, 32) + n.  (kodhip_conv_wgrad's Kp is the K extent of its fp32
+ *     gradient slabs, k = tap * Cin + ci, Kp = round_up(KH*KW*Cin, 32).)
  */
 #ifndef KODHIP_H
 #define KODHIP_H

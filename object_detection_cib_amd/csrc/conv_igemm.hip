@@ -12,10 +12,12 @@
 // wider concat buffer: ld / channel offset), weights pre-packed [N][Kp] with k = (kh, kw, ci),
 // k-contiguous, so both MFMA operands are 16-byte k-runs.
 //
-// Tiling: block = 256 threads (4 waves), tile 128(M pixels) x BN(out channels) x 32(K); operands are
-// staged global -> registers -> LDS (double buffered, 80-byte padded rows => conflict-free
-// ds_read_b128); the MFMA is issued "transposed" (A operand = weights, B operand = pixels) so each lane
-// ends up with 4 consecutive output channels per accumulator quad and the epilogue can stage the tile
+// Tiling: tile {128,256}(M pixels) x {32,64,128}(out channels) x 32(K), 4 or 8 waves.  FAST path (every layer whose
+// per-tap channel count is a multiple of 32 after padding, i.e. all of yv5n/s/m): operands go HBM -> LDS by LDS-DMA
+// (buffer_load ... lds) through a 2- or 3-stage ring, rows unpadded with a source-side XOR swizzle, counted vmcnt +
+// raw s_barrier; generic path (KODHIP_NO_FAST, operands beyond a 32-bit buffer range): global -> registers -> LDS,
+// double buffered, 80-byte padded rows.  The MFMA is issued "transposed" (A operand = weights, B operand = pixels)
+// so each lane ends up with 4 consecutive output channels per accumulator quad and the epilogue can stage the tile
 // through LDS with ds_write_b64 and leave the chip as full 16-byte channel-contiguous stores.
 // Blocks are persistent over M tiles (fixed N tile) so BatchNorm partial statistics are reduced in
 // registers and written once per block; block ids are laid out so the N tiles that share an M tile
@@ -41,6 +43,9 @@ struct ConvArgs {
   const float* bias;
   float* head_out;
   int B, Hs, Ws, ldx, xcoff, Cin;
+  int cin_step;                // channels per tap on the packed K axis = round_up(Cin, 32): k = tap * cin_step + ci, weights of
+                               // ci >= Cin are zero (Cin = 48: the last K step of a tap reads 16 channels past the slice - finite
+                               // activations of the neighbouring pixel / slice, or zeros past the buffer - times zero weights)
   int Ho, Wo, M;
   int N, K, Kp;
   int KH, KW;
@@ -231,7 +236,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       (void)soff; (void)As; (void)Bs; (void)kt;
 #endif
       f_ci += BK;
-      if (f_ci >= a.Cin) {
+      if (f_ci >= a.cin_step) {
         f_ci = 0; ++f_tap;
         if (++f_kw == a.KW) { f_kw = 0; ++f_kh; }
       }
@@ -248,10 +253,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #endif
       const int k = kt * BK + a_chunk * 8;
       const uint32_t tap = __umulhi((uint32_t)k, a.magic_cin);
-      const int ci = k - (int)tap * a.Cin;
+      const int ci = k - (int)tap * a.cin_step;
       const uint32_t kh = (a.KW == 1) ? tap : __umulhi(tap, a.magic_kw);
       const int kw = (int)tap - (int)kh * a.KW;
-      const bool kvalid = k < a.K;
+      const bool kvalid = k < a.K && ci < a.Cin;
       if (linear_taps) {
         const long toff = (long)(a.tap_sign * ((int)kh * a.Ws + kw)) * a.ldx + ci;
 #pragma unroll
@@ -695,7 +700,7 @@ int launch_x4(ConvArgs c[4], hipStream_t stream) {
 
 bool fast_eligible(const ConvArgs& a) {
   const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, wb = (long)a.N * a.Kp * 2;
-  return (a.Cin % 32 == 0) && (a.sh_shift | a.sw_shift) == 0 && a.K == a.Kp && xb < (1l << 32) - 64 &&
+  return (a.cin_step % 32 == 0) && (a.sh_shift | a.sw_shift) == 0 && a.K == a.Kp && xb < (1l << 32) - 64 &&
          wb < (1l << 32) - 64 && !getenv("KODHIP_NO_FAST");
 }
 
@@ -722,13 +727,14 @@ static int fill_common(ConvArgs& a, const void* x, const void* w, int B, int Hs,
   const bool wide = Cin > ldx && xcoff == 0 && Cin % ldx == 0 && KW == 1 && Cin == 32;
   KOD_CHECK_ARG(xcoff + Cin <= ldx || wide, "conv: channel slice out of range");
   a.wide_px = wide ? Cin / ldx : 1;
-  KOD_CHECK_ARG(Kp % 32 == 0 && Kp >= KH * KW * Cin, "conv: Kp=%d must be a multiple of 32 covering K=%d", Kp, KH * KW * Cin);
+  const int cin_step = (Cin + 31) / 32 * 32;
+  KOD_CHECK_ARG(Kp == KH * KW * cin_step, "conv: Kp=%d must be taps x round_up(Cin, 32) = %d (packed K axis: k = tap * round_up(Cin, 32) + ci)", Kp, KH * KW * cin_step);
   KOD_CHECK_ARG(KH * KW <= 32, "conv: at most 32 taps");
   KOD_CHECK_ARG((long)B * Hs * Ws < (1l << 31) / 1 && (long)B * Ho * Wo < (1l << 31), "conv: pixel count overflows int32");
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w;
-  a.B = B; a.Hs = Hs; a.Ws = Ws; a.ldx = ldx; a.xcoff = xcoff; a.Cin = Cin;
-  a.Ho = Ho; a.Wo = Wo; a.M = B * Ho * Wo; a.N = N; a.K = KH * KW * Cin; a.Kp = Kp; a.KH = KH; a.KW = KW;
-  a.magic_cin = magic_u32((uint32_t)Cin); a.magic_kw = magic_u32((uint32_t)KW);
+  a.B = B; a.Hs = Hs; a.Ws = Ws; a.ldx = ldx; a.xcoff = xcoff; a.Cin = Cin; a.cin_step = cin_step;
+  a.Ho = Ho; a.Wo = Wo; a.M = B * Ho * Wo; a.N = N; a.K = KH * KW * cin_step; a.Kp = Kp; a.KH = KH; a.KW = KW;
+  a.magic_cin = magic_u32((uint32_t)cin_step); a.magic_kw = magic_u32((uint32_t)KW);
   a.out_mul = 1;
   a.rcp_hwo = 1.0f / (float)(Ho * Wo); a.rcp_wo = 1.0f / (float)Wo;
   return KOD_OK;
@@ -815,7 +821,7 @@ int prep_dgrad_s2(ConvArgs cls[4], bool& all_fast, const void* dy, const void* w
   for (int c = 0; c < 4; ++c) {
     const int py = c >> 1, px = c & 1;
     const int KH = 1 + py, KW = 1 + px;
-    const int Kp = (KH * KW * N + 31) / 32 * 32;
+    const int Kp = KH * KW * ((N + 31) / 32 * 32);
     ConvArgs& a = cls[c];
     a = ConvArgs{};
     // gather source dy [B,Ho,Wo,N]; class outputs form a Ho x Wo grid scattered into dx with stride 2
@@ -849,7 +855,7 @@ int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
 // Data gradient of a 3x3 / stride 2 / pad 1 convolution, decomposed by output-pixel parity: class (py,px)
 // only meets taps kh = 1 (py=0) or kh in {0,2} (py=1) (same for kw), so the four classes are stride-1 gathers
 // with 1, 2, 2 and 4 taps - 9 taps of MFMA work instead of 36.  w_dgrad_s2 holds the four class packs
-// back to back: class c = 2*py+px is [Cin][Kdp_c], Kdp_c = round_up(ntaps_c * N, 32), k = (kh', kw', n).
+// back to back: class c = 2*py+px is [Cin][Kdp_c], Kdp_c = ntaps_c * round_up(N, 32), k = (kh', kw', n) tap-major.
 int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
                          int B, int H, int W, int ldx, int xcoff, int Cin, int N,
                          int ldy, int ycoff, int accumulate, hipStream_t stream) {
@@ -881,7 +887,7 @@ int kodhip_conv_dgrad_bnred_slots(int B, int H, int W, int Cin, int N, int KH, i
     return 4 * make_plan(cls[0].M, cls[0].N, kmax, true).groups_m;
   }
   ConvArgs a;
-  const int Kp = (KH * KW * N + 31) / 32 * 32;
+  const int Kp = KH * KW * ((N + 31) / 32 * 32);
   if (prep_dgrad(a, fake, fake, (void*)fake, B, H, W, Cin, 0, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, 0, 0) || !fast_eligible(a)) return 0;
   return make_plan(a.M, a.N, a.K, true).groups_m;
 }

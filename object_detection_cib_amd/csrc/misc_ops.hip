@@ -58,7 +58,11 @@ __global__ void pack_weights_kernel(const float* master, bf16_t* fpack, bf16_t* 
     long k = kh * 32 + (kw >> 1) * 8 + (kw & 1) * 4 + ci;
     fpack[d.f_off + n * d.Kp + k] = v;
   } else {
-    fpack[d.f_off + n * d.Kp + tap * d.Cin + ci] = v;
+    // packed K axes are tap-major with each tap padded to a multiple of 32 channels (zeros): k = tap * round_up(C, 32) + c,
+    // so that a 32-wide MFMA K step never straddles two taps whatever the channel count (yv5m: 48)
+    const long cs = (d.Cin + 31) / 32 * 32;
+    const long ns = (d.Ntot + 31) / 32 * 32;
+    fpack[d.f_off + n * d.Kp + tap * cs + ci] = v;
     if (d.d_off >= 0) {
       if (d.stem == 2) {
         // 3x3 stride-2 layer: four parity-class packs (see kodhip_conv_dgrad_s2)
@@ -68,13 +72,13 @@ __global__ void pack_weights_kernel(const float* master, bf16_t* fpack, bf16_t* 
         long base = d.d_off;
         for (long c = 0; c < 2 * py + px; ++c) {
           long nt = (1 + (c >> 1)) * (1 + (c & 1));
-          base += d.Cin * ((nt * d.N + 31) / 32 * 32);
+          base += d.Cin * (nt * ns);
         }
         long KW = 1 + px;
-        long Kc = ((1 + py) * KW * d.N + 31) / 32 * 32;
-        dpack[base + ci * Kc + (khp * KW + kwp) * d.N + n] = v;
+        long Kc = (1 + py) * KW * ns;
+        dpack[base + ci * Kc + (khp * KW + kwp) * ns + n] = v;
       } else {
-        dpack[d.d_off + ci * d.Kdp + tap * d.Ntot + d.n_off + n] = v;
+        dpack[d.d_off + ci * d.Kdp + tap * ns + d.n_off + n] = v;
       }
     }
   }

@@ -7,9 +7,8 @@
 //            nonzero (row, class) order, top-30000 by score, boxes offset by class*4096 (in fp32, as the
 //            reference does - the offset rounding is part of the result), greedy IoU > thr, first 300.
 //
-// One block per image: candidate compaction by ballot prefix sums, bitonic sort of (score desc, candidate
-// index asc) 64-bit keys in global memory, then a wave-batched greedy pass that keeps the <=300 survivors in
-// LDS.  Everything is integer / comparison logic on fp32 values => results are bit-identical to the reference.
+// Candidate compaction by ballot prefix sums (one block per image), a chip-wide bitonic sort of (score desc,
+// candidate index asc) 64-bit keys, then a wave-batched greedy pass that keeps the <=300 survivors in LDS.  Everything is integer / comparison logic on fp32 values => results are bit-identical to the reference.
 #include "kodhip_common.h"
 
 namespace {
@@ -109,27 +108,84 @@ __global__ __launch_bounds__(1024) void nms_candidates_kernel(NmsArgs a) {
   if (tid == 0) a.ncand[b] = base_s < a.kcap ? base_s : a.kcap;
 }
 
-__global__ __launch_bounds__(1024) void nms_sort_kernel(NmsArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  unsigned long long* K = a.keys + (size_t)b * a.kcap;
-  const int n = a.ncand[b];
+// ---- sort of the candidate keys (ascending = best score first, ties by candidate index) ------------------------
+// Bitonic network over npad_b = next power of two >= ncand[b] keys per image, spread over the whole chip instead of
+// one block per image: the passes with partner distance < SORT_CHUNK run inside LDS (one block per 4096-key chunk),
+// the few passes with a longer distance are one launch each.  An image whose candidate count is small leaves every
+// block beyond its padded length (and every pass beyond its size) immediately, so a trained network (hundreds of
+// candidates) costs one LDS sort per image, while the random-init worst case (252 000 candidates) uses all CUs.
+constexpr int SORT_CHUNK = 4096;          // keys per block (32 KB of LDS), 512 threads x 8 keys
+
+__device__ __forceinline__ int npad_of(int n) {
   int npad = 64;
   while (npad < n) npad <<= 1;
-  for (int i = n + tid; i < npad; i += 1024) K[i] = ~0ull;
+  return npad;
+}
+
+// pad [n, npad) with +inf keys, then sort every SORT_CHUNK-sized chunk completely (k = 2 .. SORT_CHUNK), directions
+// taken from the GLOBAL element index so that the chunks form the bitonic sequences the later merge passes expect
+__global__ __launch_bounds__(512) void nms_sort_local_kernel(NmsArgs a) {
+  __shared__ unsigned long long sk[SORT_CHUNK];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int n = a.ncand[b];
+  const int npad = npad_of(n);
+  const int base = chunk * SORT_CHUNK;
+  if (base >= npad) return;
+  unsigned long long* K = a.keys + (size_t)b * a.kcap;
+  const int len = npad - base < SORT_CHUNK ? npad - base : SORT_CHUNK;      // power of two
+  for (int i = tid; i < len; i += 512) sk[i] = (base + i < n) ? K[base + i] : ~0ull;
   __syncthreads();
-  for (int k = 2; k <= npad; k <<= 1) {
+  for (int k = 2; k <= len; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < npad; i += 1024) {
-        int p = i ^ j;
-        if (p > i) {
-          unsigned long long x = K[i], y = K[p];
-          bool up = (i & k) == 0;
-          if ((x > y) == up) { K[i] = y; K[p] = x; }
-        }
+      for (int t = tid; t < (len >> 1); t += 512) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // lower index of pair t
+        const int p = i | j;
+        unsigned long long x = sk[i], y = sk[p];
+        const bool up = ((base + i) & k) == 0;
+        if ((x > y) == up) { sk[i] = y; sk[p] = x; }
       }
       __syncthreads();
     }
   }
+  for (int i = tid; i < len; i += 512) K[base + i] = sk[i];
+}
+
+// one pass (k, j) with j >= SORT_CHUNK: partner pairs straight in global memory (L2-resident), one pair per thread
+__global__ __launch_bounds__(256) void nms_sort_global_kernel(NmsArgs a, int k, int j) {
+  const int b = blockIdx.y;
+  const int npad = npad_of(a.ncand[b]);
+  if (k > npad) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= (npad >> 1)) return;
+  unsigned long long* K = a.keys + (size_t)b * a.kcap;
+  const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+  const int p = i | j;
+  unsigned long long x = K[i], y = K[p];
+  const bool up = (i & k) == 0;
+  if ((x > y) == up) { K[i] = y; K[p] = x; }
+}
+
+// the passes j = SORT_CHUNK/2 .. 1 of merge size k (k > SORT_CHUNK) inside LDS
+__global__ __launch_bounds__(512) void nms_sort_merge_kernel(NmsArgs a, int k) {
+  __shared__ unsigned long long sk[SORT_CHUNK];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int npad = npad_of(a.ncand[b]);
+  const int base = chunk * SORT_CHUNK;
+  if (k > npad || base >= npad) return;
+  unsigned long long* K = a.keys + (size_t)b * a.kcap;
+  for (int i = tid; i < SORT_CHUNK; i += 512) sk[i] = K[base + i];
+  __syncthreads();
+  const bool up = (base & k) == 0;                 // k > SORT_CHUNK: one direction per chunk
+  for (int j = SORT_CHUNK >> 1; j > 0; j >>= 1) {
+    for (int t = tid; t < (SORT_CHUNK >> 1); t += 512) {
+      const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+      const int p = i | j;
+      unsigned long long x = sk[i], y = sk[p];
+      if ((x > y) == up) { sk[i] = y; sk[p] = x; }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < SORT_CHUNK; i += 512) K[base + i] = sk[i];
 }
 
 __device__ __forceinline__ bool iou_gt(const float* A, float aa, const float* Bx, float ab, float thr) {
@@ -235,7 +291,13 @@ int kodhip_nms(const float* det, void* keys, int key_cap, int* ncand, float* out
   a.conf = conf_thres; a.iou_thr = nms_thres; a.max_wh = max_wh;
   hipLaunchKernelGGL(nms_candidates_kernel, dim3(B), dim3(1024), 0, stream, a);
   KOD_LAUNCH_CHECK("nms_candidates");
-  hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), 0, stream, a);
+  const int chunks = key_cap > SORT_CHUNK ? key_cap / SORT_CHUNK : 1;
+  hipLaunchKernelGGL(nms_sort_local_kernel, dim3(chunks, B), dim3(512), 0, stream, a);
+  for (int k = 2 * SORT_CHUNK; k <= key_cap; k <<= 1) {
+    for (int j = k >> 1; j >= SORT_CHUNK; j >>= 1)
+      hipLaunchKernelGGL(nms_sort_global_kernel, dim3(cdiv(key_cap / 2, 256), B), dim3(256), 0, stream, a, k, j);
+    hipLaunchKernelGGL(nms_sort_merge_kernel, dim3(chunks, B), dim3(512), 0, stream, a, k);
+  }
   KOD_LAUNCH_CHECK("nms_sort");
   hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(64), 0, stream, a);
   KOD_LAUNCH_CHECK("nms_greedy");

@@ -65,7 +65,9 @@ class Engine:
         self._pending = []
         self._packed_version = -1
         self.param_version = 0
-        self.profile = None           # list of (start_event, end_event, algorithmic bytes) for forward convs
+        self.stats_version = 0         # bumped whenever BatchNorm running statistics change (training forward, load)
+        self._eval_aff = None          # eval-mode BN constants of all units (flat), see _eval_affine_ptrs
+        self.profile = None           # list of (family, start_event, end_event, algorithmic bytes), see _t0 / _t1
 
     # ------------------------------------------------------------------ arenas
     def _build_arenas(self, device):
@@ -147,13 +149,14 @@ class Engine:
             st.Kp = _pad(K, 32)                       # K of the weight-gradient slabs (stem: 6x3 taps x 8 = 144 -> 160)
             # forward operand rows: the stem packs each kernel row as one 32-value K step (4 pixel pairs, the 4th
             # zero) so that it runs on the LDS-DMA path like every other layer
-            st.Kp_f = 6 * 32 if u.stem else st.Kp
-            st.Kdp = _pad(u.k * u.k * u.cout, 32)
+            # packed MFMA operands: K axis tap-major, every tap padded to a multiple of 32 channels (csrc/misc_ops.hip)
+            st.Kp_f = 6 * 32 if u.stem else u.k * u.k * _pad(u.cin, 32)
+            st.Kdp = u.k * u.k * _pad(u.cout, 32)
             st.f_off, st.d_off = foff, (-1 if u.stem else doff)
             foff += u.cout * st.Kp_f
             s2 = (not u.stem) and u.k == 3 and u.s == 2 and u.p == 1
             if s2:
-                doff += u.cin * sum(_pad(nt * u.cout, 32) for nt in (1, 2, 2, 4))
+                doff += u.cin * sum(nt * _pad(u.cout, 32) for nt in (1, 2, 2, 4))
             elif not u.stem:
                 doff += u.cin * st.Kdp
             st.w_off = layout[u.name + ".0.weight"][0]
@@ -163,7 +166,7 @@ class Engine:
             if u.stem:
                 add_desc(u.name + ".0.weight", st.f_off, -1, u.cout, 3, 6, 6, st.Kp_f, 0, 0, 0, 1)
             else:
-                add_desc(u.name + ".0.weight", st.f_off, st.d_off, u.cout, u.cin, u.k, u.k, st.Kp, st.Kdp,
+                add_desc(u.name + ".0.weight", st.f_off, st.d_off, u.cout, u.cin, u.k, u.k, st.Kp_f, st.Kdp,
                          u.cout, 0, 2 if s2 else 0)
             self.ustate[u.name] = st
         self.hstate = {}
@@ -383,6 +386,22 @@ class Engine:
     def _stream(self):
         return torch.cuda.current_stream().cuda_stream
 
+    # -- per-family kernel timing (bench.py's roofline table): HIP events around every launch of an eager step, recorded
+    #    on the stream the launch goes to.  self.profile = [] switches it on; entries (family, e0, e1, algorithmic bytes).
+    def _t0(self, stream=None):
+        if self.profile is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream) if stream is not None else e.record()
+        return e
+
+    def _t1(self, e0, family: str, nbytes: float, stream=None):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(stream) if stream is not None else e1.record()
+        self.profile.append((family, e0, e1, nbytes))
+
     def pack_weights(self):
         _lib.check(self.lib.kodhip_pack_weights(self.p_arena.data_ptr(), self.fpack.data_ptr(),
                                                 self.dpack.data_ptr(), self.pack_descs.data_ptr(),
@@ -412,6 +431,7 @@ class Engine:
         outs = []
         pool_i = 0
         fp, pa = self.fpack.data_ptr(), self.p_arena.data_ptr()
+        eval_aff = None if training else self._eval_affine_ptrs()
         for op in self.g.ops:
             if op.kind == "conv":
                 u: ConvUnit = op.unit
@@ -420,18 +440,15 @@ class Engine:
                 if u.stem:
                     geo = (B, st.H, st.W, 8, 0, 32, C_, 6, 1, 2, 1, 2, 1, st.Kp_f)      # wide-pixel form, see Kp_f
                 else:
-                    geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p, st.Kp)
-                if self.profile is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
+                    geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p, st.Kp_f)
+                e0 = self._t0()
                 chk(lib.kodhip_conv_fwd_raw(self._ptr(u.src), fp + 2 * st.f_off, st.raw.data_ptr(),
                                             st.stats.data_ptr(), *geo, C_, 0, s), u.name)
-                if self.profile is not None:
-                    e1.record()
-                    cin_true = 3 if u.stem else u.cin
-                    in_px = B * H * W if u.stem else B * st.H * st.W
-                    self.profile.append((e0, e1, 2 * (in_px * cin_true + st.M * C_)))
+                cin_true = 3 if u.stem else u.cin
+                in_px = B * H * W if u.stem else B * st.H * st.W
+                self._t1(e0, "conv_fwd", 2 * (in_px * cin_true + st.M * C_))
                 aff = st.aff.data_ptr()
+                e0 = self._t0()
                 if training and not (self.sync_bn and self.collectives):
                     chk(lib.kodhip_bn_finalize_partials(st.stats.data_ptr(), st.T, float(st.M), pa + 4 * st.g_off,
                                                         pa + 4 * st.b_off, self.rm_arena.data_ptr() + 4 * st.rs_off,
@@ -445,13 +462,15 @@ class Engine:
                                                self.rm_arena.data_ptr() + 4 * st.rs_off,
                                                self.rv_arena.data_ptr() + 4 * st.rs_off, BN_MOMENTUM, BN_EPS,
                                                aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
-                else:
-                    self._eval_affine(st)
+                self._t1(e0, "bn_finalize", 8.0 * C_ * st.T)
+                sc_p, sh_p = (aff, aff + 4 * C_) if training else eval_aff[u.name]
                 res = u.residual
-                chk(lib.kodhip_bn_silu_apply(st.raw.data_ptr(), st.raw_ld, aff, aff + 4 * C_,
+                e0 = self._t0()
+                chk(lib.kodhip_bn_silu_apply(st.raw.data_ptr(), st.raw_ld, sc_p, sh_p,
                                              self._ptr(res) if res else None, res.buf.C if res else 0,
                                              res.coff if res else 0,
                                              self._ptr(u.dst), u.dst.buf.C, u.dst.coff, st.M, C_, s), u.name)
+                self._t1(e0, "bn_silu_apply", (6.0 if res else 4.0) * st.M * C_)
             elif op.kind == "pool":
                 h, w = H // op.src.stride, W // op.src.stride
                 chk(lib.kodhip_maxpool5_fwd(self._ptr(op.src), op.src.buf.C, op.src.coff, self._ptr(op.dst),
@@ -472,19 +491,40 @@ class Engine:
                 outs.append(out)
         if training:
             self.nbt_arena += 1
-        self.training_ready = training          # an eval forward overwrites the saved pre-BN tensors / BN constants
+            self.stats_version += 1              # running statistics moved
+        self.training_ready = training          # an eval forward overwrites the saved pre-BN tensors
         return outs
 
-    def _eval_affine(self, st):
-        """Eval-mode BN constants from running statistics (torch ops on tiny per-layer vectors)."""
-        C_ = st.u.cout
-        g = self.p_arena[st.g_off:st.g_off + C_]
-        b = self.p_arena[st.b_off:st.b_off + C_]
-        rm = self.rm_arena[st.rs_off:st.rs_off + C_]
-        rv = self.rv_arena[st.rs_off:st.rs_off + C_]
-        sc = g * torch.rsqrt(rv + BN_EPS)
-        st.aff[:C_] = sc
-        st.aff[C_:2 * C_] = b - rm * sc
+    def _eval_affine_ptrs(self):
+        """Eval-mode BatchNorm constants of every unit (scale = gamma * rsqrt(running_var + eps), shift = beta -
+        running_mean * scale) in ONE flat buffer, recomputed with five whole-network tensor ops only when parameters or
+        running statistics changed - not per layer per forward (a validation epoch forwards many batches with frozen
+        weights).  Kept apart from the training constants (st.aff), so an eval forward never disturbs a pending backward.
+        Returns {unit name: (scale ptr, shift ptr)}."""
+        key = (self.param_version, self.stats_version)
+        if self._eval_aff is None:
+            gi, bi, ri, off = [], [], [], 0
+            self._eval_off = {}
+            for u in self.exec_units:
+                st = self.ustate[u.name]
+                ar = torch.arange(u.cout)
+                gi.append(st.g_off + ar); bi.append(st.b_off + ar); ri.append(st.rs_off + ar)
+                self._eval_off[u.name] = off
+                off += u.cout
+            dev = self.device
+            self._eval_idx = tuple(torch.cat(t).to(dev) for t in (gi, bi, ri))
+            self._eval_n = off
+            self._eval_aff = torch.empty(2 * off, dtype=torch.float32, device=dev)
+            self._eval_key = None
+        if self._eval_key != key:
+            gi, bi, ri = self._eval_idx
+            n = self._eval_n
+            sc = self.p_arena[gi] * torch.rsqrt(self.rv_arena[ri] + BN_EPS)
+            self._eval_aff[:n] = sc
+            self._eval_aff[n:] = self.p_arena[bi] - self.rm_arena[ri] * sc
+            self._eval_key = key
+        base, n = self._eval_aff.data_ptr(), self._eval_n
+        return {name: (base + 4 * o, base + 4 * (n + o)) for name, o in self._eval_off.items()}
 
     # ------------------------------------------------------------------ backward
     def backward(self, head_grads: List[torch.Tensor]):
@@ -516,6 +556,12 @@ class Engine:
                 return s
             wg.wait_stream(main)
             return wg.cuda_stream
+
+        def timed_wgrad(name, nbytes, *args):
+            ws = wgrad_stream()
+            e0 = self._t0(wg)
+            chk(lib.kodhip_conv_wgrad(*args, ws), name + ".wgrad")
+            self._t1(e0, "wgrad", nbytes, wg)
 
         def acc_flag(v: View) -> int:
             """0 = first writer (overwrite), 1 = accumulate; zero-fills on a partial first touch."""
@@ -549,14 +595,16 @@ class Engine:
                                              gp + 4 * offs[0], gp + 4 * offs[1], gp + 4 * offs[2],
                                              B, hs["H"] * hs["W"], A, nc, self.head_npad, s), hu.name)
                 src = hu.src
+                e0 = self._t0()
                 chk(lib.kodhip_conv_dgrad(hs["dy"].data_ptr(), dp + 2 * hs["d_off"], self._ptr(src, True),
                                           B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
                                           self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kdp"], self.head_npad, 0,
                                           acc_flag(src), s), hu.name + ".dgrad")
-                chk(lib.kodhip_conv_wgrad(self._ptr(src), hs["dy"].data_ptr(), wgp, gp + 4 * hs["w_off"],
-                                          B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
-                                          self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kp"], self.head_npad, 0,
-                                          A * (5 + nc), 0, 1.0, wgrad_stream()), hu.name + ".wgrad")
+                self._t1(e0, "dgrad", 2.0 * hs["M"] * (self.head_npad + hu.cin))
+                timed_wgrad(hu.name, 2.0 * hs["M"] * (hu.cin + self.head_npad),
+                            self._ptr(src), hs["dy"].data_ptr(), wgp, gp + 4 * hs["w_off"],
+                            B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
+                            self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kp"], self.head_npad, 0, A * (5 + nc), 0, 1.0)
             elif op.kind == "up":
                 h, w = H // op.src.stride, W // op.src.stride
                 chk(lib.kodhip_upsample2x_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
@@ -577,9 +625,12 @@ class Engine:
                 dA = u.dst
                 rawm = 1 if st.fused_red else 0        # partials came from the last dgrad into this tensor
                 if not st.fused_red:
+                    e0 = self._t0()
                     chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
                                                       aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
                                                       st.bpart.data_ptr(), st.M, C_, s), u.name)
+                    self._t1(e0, "bn_bwd_reduce", 4.0 * st.M * C_)
+                e0 = self._t0()
                 if self.sync_bn and self.collectives:
                     chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), C_, st.T2, s), u.name)
                     if self.comm is not None:             # out of place: the local sums stay for dgamma / dbeta
@@ -595,29 +646,45 @@ class Engine:
                     chk(lib.kodhip_bn_bwd_coeffs_partials(st.bpart.data_ptr(), st.T2, float(st.M), pa + 4 * st.g_off,
                                                           aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off,
                                                           gp + 4 * st.b_off, st.coef.data_ptr(), C_, rawm, s), u.name)
+                self._t1(e0, "bn_bwd_coeffs", 8.0 * C_ * st.T2)
                 res = u.residual
+                racc = acc_flag(res) if res else 0
+                e0 = self._t0()
                 chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
                                                  aff, aff + 4 * C_, st.coef.data_ptr(),
                                                  self._ptr(res, True) if res else None,
                                                  res.buf.C if res else 0, res.coff if res else 0,
-                                                 acc_flag(res) if res else 0, st.M, C_, s), u.name)
+                                                 racc, st.M, C_, s), u.name)
+                self._t1(e0, "bn_silu_bwd_apply", (6.0 + ((4.0 if racc else 2.0) if res else 0.0)) * st.M * C_)
                 # st.raw now holds dY
                 if u.stem:
                     geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1)
                 else:
                     geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p)
                     fz = () if st.segs is None else (C.cast(st.segs, C.c_void_p), len(st.segs), st.seg_slots)
+                    acc_src = acc_flag(u.src)
+                    in_px = B * st.H * st.W
+                    # dY read once, dX written once (+ read when accumulating), + the re-read of the producers' pre-BN
+                    # tensors when this launch carries their BatchNorm-backward reduction
+                    nb = 2.0 * st.M * C_ + (4.0 if acc_src else 2.0) * in_px * u.cin
+                    if st.segs is not None:
+                        nb += 2.0 * in_px * sum(sg.ch_count for sg in st.segs)
+                    e0 = self._t0()
                     if u.k == 3 and u.s == 2 and u.p == 1:
                         fn = lib.kodhip_conv_dgrad_s2 if st.segs is None else lib.kodhip_conv_dgrad_s2_bnred
                         chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
                                B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,
-                               acc_flag(u.src), *fz, s), u.name + ".dgrad")
+                               acc_src, *fz, s), u.name + ".dgrad")
                     else:
                         fn = lib.kodhip_conv_dgrad if st.segs is None else lib.kodhip_conv_dgrad_bnred
                         chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
-                               *geo, st.Kdp, C_, 0, acc_flag(u.src), *fz, s), u.name + ".dgrad")
-                chk(lib.kodhip_conv_wgrad(self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
-                                          *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0, wgrad_stream()), u.name + ".wgrad")
+                               *geo, st.Kdp, C_, 0, acc_src, *fz, s), u.name + ".dgrad")
+                    self._t1(e0, "dgrad" if st.segs is None else "dgrad+bn_reduce", nb)
+                cin_true = 3 if u.stem else u.cin
+                in_px_w = B * H * W if u.stem else B * st.H * st.W
+                timed_wgrad(u.name, 2.0 * (in_px_w * cin_true + st.M * C_),
+                            self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
+                            *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0)
             # gradient buckets complete from the arena's end toward its start
             if op.kind in ("conv", "head"):
                 unit_i -= 1

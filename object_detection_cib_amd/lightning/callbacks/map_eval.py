@@ -98,8 +98,7 @@ class DeviceMAPEvaluator:
                 ap[ti, c] = float(np.mean(q))
         return ap
 
-    def get_report(self) -> dict:
-        ap = self.average_precision()
+    def _report_of(self, ap: np.ndarray) -> dict:
         per_thr = np.nanmean(ap, axis=1)
         res = {"map": float(per_thr.mean())}
         for t, v in zip(IOUS, per_thr):
@@ -107,3 +106,44 @@ class DeviceMAPEvaluator:
         for c in range(self.nc):
             res[f"map50_{self.names[c]}"] = float(ap[IOUS.index(0.5), c])
         return res
+
+    def gather(self, process_group=None):
+        """Merge the match records of every rank into this evaluator (rank order => identical state everywhere):
+        the exact whole-validation-set mAP under data-parallel validation."""
+        import torch.distributed as dist
+        world = dist.get_world_size(process_group)
+        if world == 1:
+            return self
+        mine = ([[np.asarray(x) for x in c] for c in self._scores], [[np.asarray(x) for x in c] for c in self._tp], self._npig)
+        parts = [None] * world
+        dist.all_gather_object(parts, mine, group=process_group)
+        self.reset()
+        for scores, tps, npig in parts:
+            for c in range(self.nc):
+                self._scores[c].extend(scores[c])
+                self._tp[c].extend(tps[c])
+            self._npig += npig
+        return self
+
+    def get_report(self, process_group=None, sync: str = "mean") -> dict:
+        """Single process: the report of this evaluator.  With a process group (validation sharded over ranks):
+        sync="mean"   - every rank evaluates its own shard and the logged values are averaged over ranks, which is what
+                        the reference does (`pl_module.log_dict(results, sync_dist=True)`, pycoco_map_eval.py:139-142);
+        sync="global" - match records are gathered first (gather()), giving the mAP of the whole validation set."""
+        if process_group is None and sync == "mean":
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+                return self._report_of(self.average_precision())
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return self._report_of(self.average_precision())
+        if sync == "global":
+            return self.gather(process_group)._report_of(self.average_precision())
+        rep = self._report_of(self.average_precision())
+        keys = sorted(rep)
+        vals = torch.tensor([rep[k] for k in keys], dtype=torch.float64)
+        if dist.get_backend(process_group) == "nccl":
+            vals = vals.cuda()
+        dist.all_reduce(vals, group=process_group)
+        vals = (vals / dist.get_world_size(process_group)).cpu()
+        return {k: float(v) for k, v in zip(keys, vals)}

@@ -34,13 +34,13 @@ def pack(weights, stem=False, ntot=None, s2=False):
     lib = _lib.lib()
     N = sum(w.shape[0] for w in weights)
     Cin, KH, KW = weights[0].shape[1:]
-    K = 192 if stem else KH * KW * Cin          # stem: 6 kernel rows x (4 pixel pairs x 8), the 4th pair zero
-    Kp = pad(K, 32)
+    # packed K axes: tap-major, every tap padded to a multiple of 32 channels (stem: 6 kernel rows x (4 pixel pairs x 8))
+    Kp = 192 if stem else KH * KW * pad(Cin, 32)
     Ntot = ntot or N
-    Kdp = pad(KH * KW * Ntot, 32)
+    Kdp = KH * KW * pad(Ntot, 32)
     master = torch.cat([w.reshape(-1) for w in weights]).float().cuda()
     fpack = torch.zeros(Ntot * Kp, dtype=torch.bfloat16, device="cuda")
-    dsize = Cin * sum(pad(nt * N, 32) for nt in (1, 2, 2, 4)) if s2 else Cin * Kdp
+    dsize = Cin * sum(nt * pad(N, 32) for nt in (1, 2, 2, 4)) if s2 else Cin * Kdp
     dpack = torch.zeros(max(dsize, 8), dtype=torch.bfloat16, device="cuda")
     descs, w_off, n_off, blk = [], 0, 0, 0
     for w in weights:

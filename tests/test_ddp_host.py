@@ -75,3 +75,61 @@ def test_bucketed_allreduce_world2_gloo():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def _fake_records(ev, rng, n_img):
+    """Fill a DeviceMAPEvaluator's host-side state as add_batch would (scores + TP flags per class per image)."""
+    import numpy as np
+    for _ in range(n_img):
+        for c in range(ev.nc):
+            m = int(rng.integers(0, 6))
+            if m:
+                ev._scores[c].append(np.sort(rng.uniform(0, 1, m))[::-1].copy())
+                ev._tp[c].append(rng.uniform(0, 1, (4, m)) < 0.4)
+        ev._npig += rng.integers(0, 3, ev.nc)
+
+
+def _map_worker(rank, world, port, q):
+    import numpy as np
+    from object_detection_cib_amd.lightning.callbacks.map_eval import DeviceMAPEvaluator
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ev = DeviceMAPEvaluator(5)
+        _fake_records(ev, np.random.default_rng(100 + rank), 20)
+        local = ev.get_report(sync="local") if False else ev._report_of(ev.average_precision())
+        mean = ev.get_report(sync="mean")                 # reference semantics: log_dict(sync_dist=True)
+        glob = ev.get_report(sync="global")               # exact: match records gathered in rank order
+        q.put((rank, local, mean, glob))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cross_rank_map_reduction_world2_gloo():
+    """Validation sharded over two ranks: sync="mean" averages the per-rank reports (what the reference logs under DDP,
+    kod/lightning/callbacks/pycoco_map_eval.py:139-142), sync="global" equals one process that saw both shards."""
+    import numpy as np
+    from object_detection_cib_amd.lightning.callbacks.map_eval import DeviceMAPEvaluator
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_map_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    single = DeviceMAPEvaluator(5)
+    for r in range(2):
+        _fake_records(single, np.random.default_rng(100 + r), 20)
+    want_global = single._report_of(single.average_precision())
+    for rank, local, mean, glob in res:
+        for k in want_global:
+            a, b = glob[k], want_global[k]
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) < 1e-12, (k, a, b)
+            m = 0.5 * (res[0][1][k] + res[1][1][k])
+            assert (np.isnan(mean[k]) and np.isnan(m)) or abs(mean[k] - m) < 1e-12, (k, mean[k], m)
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
+    assert abs(want_global["map50"] - 0.5 * (res[0][1]["map50"] + res[1][1]["map50"])) > 1e-6    # the two semantics differ

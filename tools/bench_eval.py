@@ -1,6 +1,6 @@
 """Validation loop throughput: device resize/letter-box -> eval forward -> decode -> NMS -> mAP matching.  Diagnostic."""
-import sys, time
-sys.path.insert(0, '.')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import synth
 import bench

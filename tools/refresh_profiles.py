@@ -1,30 +1,112 @@
-"""Rewrite profiles/ from the latest gpurun_out/ collection (bench line, rocprof stats, PMC passes, step breakdown)."""
-import csv, json, re, subprocess, sys
-sys.path.insert(0, '.')
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-out = subprocess.run([sys.executable, "tools/pmc_traffic.py", "gpurun_out/pmc_fetch", "gpurun_out/pmc_write", "conv_igemm_kernel", ", 0, "],
-                     capture_output=True, text=True).stdout
-open(f"profiles/{tag}_pmc_traffic_conv_fwd.txt", "w").write(out)
-rd = float(re.search(r"read\s+([\d.]+) MB", out).group(1)) * 1e6
-wr = float(re.search(r"write\s+([\d.]+) MB", out).group(1)) * 1e6
-nd = int(re.search(r": (\d+) / \d+ dispatches", out).group(1))
-json.dump({"kernel": "conv_igemm_kernel<MODE_RAW> (forward conv, all 57 layers)", "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-           "traffic_bytes_per_launch": rd + wr,
-           "method": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), KiB units, FETCH_SIZE x2 (gfx950), mean over {nd} dispatches of bench.py --no-graph --steps 2 --warmup 1",
-           "workload": "yv5s B=64 640px"}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
-rows = list(csv.DictReader(open("gpurun_out/prof_r01_final/r01_kernel_stats.csv")))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-fw = [r for r in rows if re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, 0, ", r["Name"])]
-calls = sum(int(r["Calls"]) for r in fw); t = sum(float(r["TotalDurationNs"]) for r in fw)
-b = json.loads(open("gpurun_out/bench_r01_final.json").read().strip().splitlines()[-1])
-b["roofline"]["traffic"] = round(rd + wr)
-open(f"profiles/bench_{tag}_final.json", "w").write(json.dumps(b) + "\n")
-txt = ("rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (summary csv: profiles/%s_kernel_stats.csv)\n"
-       "forward conv family conv_igemm_kernel<..., MODE_RAW, ...>: %d calls, average %.2f us per launch, %.1f%% of GPU kernel time\n"
-       "bench.py roofline.avg_launch_us (HIP events around each launch of one eager step): %.2f us  (profiles/bench_%s_final.json)\n"
-       % (tag, calls, t / calls / 1e3, 100 * t / tot, b["roofline"]["avg_launch_us"], tag))
-open(f"profiles/{tag}_fwd_conv_family.txt", "w").write(txt)
-subprocess.run(["cp", "gpurun_out/prof_r01_final/r01_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv"])
-open(f"profiles/{tag}_step_breakdown.txt", "w").write(
-    subprocess.run([sys.executable, "tools/prof_summary.py", "gpurun_out/prof_r01k"], capture_output=True, text=True).stdout)
-print(txt, out, json.dumps(b["roofline"]), b["value"], b["ms_per_step"], b.get("cpu_baseline"))
+"""Rewrite profiles/<tag>_* from gpurun_out/ev_<tag>/ (tools/collect_evidence.sh): bench line, kernel stats, the step
+breakdown, HBM traffic per kernel family from the FETCH_SIZE / WRITE_SIZE PMC passes and MFMA counters of the
+convolution families.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE tallies the 128-byte
+requests of wide coalesced reads at 64 B, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact for 16-byte-per-lane
+stores.  Per launch = summed counter / number of dispatches of the family in the PMC run (an eager bench.py step)."""
+import csv, glob, json, os, re, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+EV = os.path.join(ROOT, "gpurun_out", f"ev_{tag}")
+PR = os.path.join(ROOT, "profiles")
+
+FAMILIES = {   # name -> regex on the demangled kernel name
+    "conv_fwd": r"conv_igemm_kernel<\d+, \d+, \d+, \d+, 0, ",
+    "dgrad": r"conv_igemm(_x4)?_kernel<\d+, \d+, \d+, \d+, 1, ",
+    "dgrad+bn_reduce": r"conv_igemm(_x4)?_kernel<\d+, \d+, \d+, \d+, 3, ",
+    "wgrad": r"conv_wgrad(_dma)?_kernel<",
+    "wgrad_reduce": r"wgrad_reduce_kernel",
+    "bn_silu_apply": r"bn_silu_apply_kernel",
+    "bn_silu_bwd_apply": r"bn_silu_bwd_apply_kernel",
+}
+
+
+def counter_rows(d):
+    f = (glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"))
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def per_family(rows, counter):
+    out = {}
+    for fam, pat in FAMILIES.items():
+        rx = re.compile(pat)
+        tot, disp = 0.0, set()
+        for r in rows:
+            if r["Counter_Name"] == counter and rx.search(r["Kernel_Name"]):
+                tot += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
+        out[fam] = (tot, len(disp))
+    return out
+
+
+def main():
+    from object_detection_cib_amd import build as kb
+    dig = kb._digest(sorted(glob.glob(os.path.join(kb.CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(kb.CSRC, "*.h"))))
+    bench = json.loads(open(os.path.join(EV, "bench.json")).read().strip().splitlines()[-1])
+    fam_alg = {r["family"]: r for r in bench.get("families", [])}
+    fr, wr = counter_rows(os.path.join(EV, "pmc_FETCH_SIZE")), counter_rows(os.path.join(EV, "pmc_WRITE_SIZE"))
+    F, W = per_family(fr, "FETCH_SIZE"), per_family(wr, "WRITE_SIZE")
+    fams, lines = {}, ["family                 launches   read MB/launch  write MB/launch  total MB/launch  algorithmic MB/launch  traffic/algorithmic"]
+    for fam in FAMILIES:
+        (f, nf), (w, nw) = F[fam], W[fam]
+        if not nf or not nw:
+            continue
+        rd, wrb = 2 * f * 1024 / nf, w * 1024 / nw
+        key = fam if fam in fam_alg else None
+        alg = 1e6 * fam_alg[key]["algorithmic_MB"] / fam_alg[key]["launches"] if key else None
+        fams[fam] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wrb, "traffic_bytes_per_launch": rd + wrb,
+                     "dispatches": nf, "algorithmic_bytes_per_launch": alg}
+        lines.append(f"{fam:22s} {nf:8d} {rd / 1e6:15.2f} {wrb / 1e6:16.2f} {(rd + wrb) / 1e6:16.2f} "
+                     + (f"{alg / 1e6:22.2f} {(rd + wrb) / alg:20.2f}" if alg else f"{'-':>22s} {'-':>20s}"))
+    json.dump({"csrc_digest": dig, "workload": "yv5s B=64 640px, one eager bench.py step per PMC pass",
+               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (--kernel-trace only); KiB units; "
+                         "read = 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B); mean over the family's dispatches",
+               "families": fams}, open(os.path.join(PR, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    open(os.path.join(PR, f"{tag}_pmc_traffic_by_family.txt"), "w").write("\n".join(lines) + "\n")
+    # MFMA counters
+    mr = counter_rows(os.path.join(EV, "pmc_mfma"))
+    if mr:
+        tr = {}
+        tf = glob.glob(os.path.join(EV, "pmc_mfma", "*kernel_trace.csv")) + glob.glob(os.path.join(EV, "pmc_mfma", "*/*kernel_trace.csv"))
+        for r in csv.DictReader(open(tf[0])):
+            tr[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        out = ["MFMA counters per kernel family (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
+               "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE, one eager step; durations from the same pass, i.e. with counter overhead)",
+               "FLOP = 512 x SQ_INSTS_VALU_MFMA_MOPS_BF16; TF/s = FLOP / sum of dispatch durations; MFMA pipe utilisation = "
+               "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x 256 CU x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCD",
+               "family                 launches   GFLOP/launch  us/launch    TF/s  of 2500   mfma busy cyc/launch  pipe util"]
+        for fam, pat in FAMILIES.items():
+            rx = re.compile(pat)
+            acc, disp = {}, set()
+            for r in mr:
+                if rx.search(r["Kernel_Name"]):
+                    acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
+            if not disp or not acc.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"):
+                continue
+            n = len(disp)
+            ns = sum(tr.get(d, 0) for d in disp)
+            flop = 512.0 * acc["SQ_INSTS_VALU_MFMA_MOPS_BF16"]
+            cyc = acc.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            util = acc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4 * 256 * cyc) if cyc else float("nan")
+            tfs = flop / (ns * 1e-9) / 1e12 if ns else float("nan")
+            out.append(f"{fam:22s} {n:8d} {flop / n / 1e9:13.2f} {ns / n / 1e3:10.1f} {tfs:7.0f} {tfs / 2500:8.3f} "
+                       f"{acc.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / n:22.0f} {util:10.3f}")
+        open(os.path.join(PR, f"{tag}_mfma_counters.txt"), "w").write("\n".join(out) + "\n")
+        print("\n".join(out))
+    # bench line (traffic filled in for the family it names), kernel stats, step breakdown
+    fam = bench["roofline"].get("family")
+    if fam in fams:
+        bench["roofline"]["traffic"] = round(fams[fam]["traffic_bytes_per_launch"])
+    open(os.path.join(PR, f"bench_{tag}.json"), "w").write(json.dumps(bench) + "\n")
+    ks = glob.glob(os.path.join(EV, "trace", "*kernel_stats.csv")) + glob.glob(os.path.join(EV, "trace", "*/*kernel_stats.csv"))
+    shutil.copy(ks[0], os.path.join(PR, f"{tag}_kernel_stats.csv"))
+    open(os.path.join(PR, f"{tag}_step_breakdown.txt"), "w").write(
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prof_summary.py"), os.path.join(EV, "trace")],
+                       capture_output=True, text=True, cwd=ROOT).stdout)
+    print("\n".join(lines))
+    print(json.dumps(bench["roofline"]), bench["value"], bench["ms_per_step"])
+
+
+if __name__ == "__main__":
+    main()
