@@ -308,8 +308,9 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        if eng.comm is not None:
-            eng.comm.close()
+        for c in (eng.comm, eng.comm_buckets):
+            if c is not None:
+                c.close()
         dist.destroy_process_group()
 
 

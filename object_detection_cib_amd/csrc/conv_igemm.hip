@@ -77,6 +77,9 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float rcp, int& q, int
 
 constexpr int BK = 32;
 
+template <int N>
+__device__ __forceinline__ void wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // launch bounds: 4 blocks per CU (one wave of each on every SIMD) => at most 128 VGPRs, so that one block's LDS /
 // global phases overlap another block's MFMA phase (measured: the phases of a single block do not overlap)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
@@ -181,12 +184,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     constexpr int B_INSTR = BN / 16;                  // weight-tile DMA instructions per K step (per block)
     constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    uint32_t dvoff[2], dmask[2], dbvoff[B_PER_WAVE];
+    constexpr int A_PER_WAVE = BM / (16 * NW);         // pixel-tile DMA instructions per wave (16 rows each)
+    static_assert(!FAST || A_PER_WAVE * 16 * NW == BM, "pixel tile rows must divide over the waves' DMA instructions");
+    uint32_t dvoff[A_PER_WAVE > 0 ? A_PER_WAVE : 1], dmask[A_PER_WAVE > 0 ? A_PER_WAVE : 1], dbvoff[B_PER_WAVE];
     int f_tap = 0, f_kh = 0, f_kw = 0, f_ci = 0;      // wave-uniform K-step state
     if constexpr (FAST) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int row = uwave * 32 + i * 16 + (lane >> 2);
+      for (int i = 0; i < A_PER_WAVE; ++i) {
+        int row = (uwave * A_PER_WAVE + i) * 16 + (lane >> 2);
         int m = m0 + row;
         bool valid = m < a.M;
         int mm = valid ? m : 0;
@@ -220,9 +225,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       char* Bs = As + BM * LDS_ROW * 2;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(KOD_ABL_NODMA)   // (the host pass only needs the kernel's stub)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < A_PER_WAVE; ++i) {
         uint32_t vo = ((dmask[i] >> f_tap) & 1u) ? dvoff[i] + soff : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(As + (uwave * 32 + i * 16) * 64),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(As + (uwave * A_PER_WAVE + i) * 16 * 64),
                                                  16, vo, 0, 0, 0);
       }
 #pragma unroll
@@ -361,9 +366,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       if (NST == 3 && nk > 1) dma_tile(1, 1);
       for (int kt = 0; kt < nk; ++kt) {
         if (NST == 3 && kt + 1 < nk) {
-          if (my_b == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else if (my_b == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          // the newer tile's instructions of this wave (A_PER_WAVE pixel pieces + my_b weight pieces) may stay in flight
+          if (my_b == 2) wait_vm_imm<A_PER_WAVE + 2>();
+          else if (my_b == 1) wait_vm_imm<A_PER_WAVE + 1>();
+          else wait_vm_imm<A_PER_WAVE>();
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -604,6 +610,9 @@ int slots_for(int bm, int bn, bool fast) {
 
 constexpr int MAX_STATS_SLOTS = 1024;
 
+bool wave_n1() { static int v = -1; if (v < 0) { const char* e = getenv("KODHIP_WAVE_N1"); v = e ? atoi(e) : 0; } return v != 0; }
+bool bm256_n32() { static int v = -1; if (v < 0) { const char* e = getenv("KODHIP_WAVE_N1"); v = (e && atoi(e) >= 2) ? 1 : 0; } return v != 0; }
+
 // Tile shape: the widest channel tile that fits N (or the next narrower one when that removes a badly quantised
 // last round).  256-pixel tiles (8 waves, 3-stage ring) when the reduction is long enough to amortise their deeper
 // pipeline fill (measured on gfx950: 3x3 layers with N >= 128 gain 15-25 %, short-K 1x1 layers lose ~5 %).
@@ -612,7 +621,7 @@ Plan make_plan(long M, int N, int K, bool fast) {
   if (force_bn < 0) { const char* e = getenv("KODHIP_FORCE_BN"); force_bn = e ? atoi(e) : 0; }
   if (force_bm < 0) { const char* e = getenv("KODHIP_FORCE_BM"); force_bm = e ? atoi(e) : 0; }
   const int widest = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
-  const bool can256 = fast && widest >= 64 && M >= 256 * 64;       // 256 x 128 and 256 x 64 tiles
+  const bool can256 = fast && (widest >= 64 || bm256_n32()) && M >= 256 * 64;       // 256 x 128 and 256 x 64 tiles
   const int bm = can256 && (force_bm ? force_bm == 256 : K >= 512) ? 256 : 128;
   Plan best = {};
   double best_cost = 1e30;
@@ -654,6 +663,12 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     args.slot_base = 0; args.slot_used = p.groups_m;
   }
   dim3 g(p.grid);
+  if (fast && wave_n1()) {
+    // experimental wave layouts: one wave column, 64-pixel x BN-channel wave tiles (fewer LDS fragment reads per MFMA)
+    if (p.bm == 256 && p.bn == 64) { hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 1, MODE, true>), g, dim3(256), 0, stream, args); KOD_LAUNCH_CHECK("conv_igemm"); return KOD_OK; }
+    if (p.bm == 128 && p.bn == 64) { hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 1, MODE, true>), g, dim3(128), 0, stream, args); KOD_LAUNCH_CHECK("conv_igemm"); return KOD_OK; }
+    if (p.bm == 256 && p.bn == 32) { hipLaunchKernelGGL((conv_igemm_kernel<256, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, args); KOD_LAUNCH_CHECK("conv_igemm"); return KOD_OK; }
+  }
   if (fast) {
     if (p.bm == 256 && p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
     else if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
@@ -689,6 +704,11 @@ int launch_x4(ConvArgs c[4], hipStream_t stream) {
     }
   }
   dim3 g(pl.grid * 4);
+  if (wave_n1()) {
+    if (pl.bm == 256 && pl.bn == 64) { hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 1, MODE, true>), g, dim3(256), 0, stream, p); KOD_LAUNCH_CHECK("conv_igemm_x4"); return KOD_OK; }
+    if (pl.bm == 128 && pl.bn == 64) { hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 1, MODE, true>), g, dim3(128), 0, stream, p); KOD_LAUNCH_CHECK("conv_igemm_x4"); return KOD_OK; }
+    if (pl.bm == 256 && pl.bn == 32) { hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, p); KOD_LAUNCH_CHECK("conv_igemm_x4"); return KOD_OK; }
+  }
   if (pl.bm == 256 && pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
   else if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
   else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true>), g, dim3(256), 0, stream, p);

@@ -58,6 +58,7 @@ class Engine:
         self.wg_stream = None          # side stream of the weight-gradient kernels (see backward)
         self.wgrad_overlap = os.environ.get("KODHIP_WGRAD_OVERLAP", "1") != "0"
         self.comm = None               # RcclComm when the process group is RCCL-backed (the product path)
+        self.comm_buckets = None       # second communicator: gradient buckets on the side stream (comm_overlap)
         self.comm_stream = None        # side stream of the gradient-bucket all-reduces
         self.comm_overlap = os.environ.get("KODHIP_COMM_OVERLAP", "0") == "1"
         self.collectives = False       # True when gradients / BN sums go through the process group (world > 1)
@@ -690,8 +691,11 @@ class Engine:
                 unit_i -= 1
                 if unit_i in buckets:
                     lo, hi = buckets[unit_i]
-                    self._pending.append(launch_bucket(ga, lo, hi, self.process_group, self._comm_stream(), self.comm,
-                                                       also_after=wg))
+                    cs = self._comm_stream()
+                    # overlapped buckets use their own communicator: SyncBN sums (main stream) and buckets (side stream)
+                    # never interleave on one communicator from two streams
+                    bc = self.comm_buckets if (cs is not None and self.comm_buckets is not None) else self.comm
+                    self._pending.append(launch_bucket(ga, lo, hi, self.process_group, cs, bc, also_after=wg))
         if wg is not None:
             main.wait_stream(wg)
         self._publish_grads()

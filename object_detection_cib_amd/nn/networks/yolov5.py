@@ -130,6 +130,8 @@ class Yolov5Network(nn.Module):
         if eng.collectives and native_rccl and eng.comm is None:
             from ...engine.comm import RcclComm
             eng.comm = RcclComm(process_group, eng.device)
+            if eng.comm_overlap:          # KODHIP_COMM_OVERLAP=1: gradient buckets on a side stream, own communicator
+                eng.comm_buckets = RcclComm(process_group, eng.device)
         if eng.collectives:
             # rank 0's parameters and BatchNorm buffers everywhere (torch DDP does this at wrap time)
             for t in (eng.p_arena, eng.rm_arena, eng.rv_arena):
