@@ -610,8 +610,6 @@ int slots_for(int bm, int bn, bool fast) {
 
 constexpr int MAX_STATS_SLOTS = 1024;
 
-bool wave_n1() { static int v = -1; if (v < 0) { const char* e = getenv("KODHIP_WAVE_N1"); v = e ? atoi(e) : 0; } return v != 0; }
-bool bm256_n32() { static int v = -1; if (v < 0) { const char* e = getenv("KODHIP_WAVE_N1"); v = (e && atoi(e) >= 2) ? 1 : 0; } return v != 0; }
 
 // Tile shape: the widest channel tile that fits N (or the next narrower one when that removes a badly quantised
 // last round).  256-pixel tiles (8 waves, 3-stage ring) when the reduction is long enough to amortise their deeper
@@ -621,7 +619,7 @@ Plan make_plan(long M, int N, int K, bool fast) {
   if (force_bn < 0) { const char* e = getenv("KODHIP_FORCE_BN"); force_bn = e ? atoi(e) : 0; }
   if (force_bm < 0) { const char* e = getenv("KODHIP_FORCE_BM"); force_bm = e ? atoi(e) : 0; }
   const int widest = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
-  const bool can256 = fast && (widest >= 64 || bm256_n32()) && M >= 256 * 64;       // 256 x 128 and 256 x 64 tiles
+  const bool can256 = fast && widest >= 64 && M >= 256 * 64;       // 256 x 128 and 256 x 64 tiles
   const int bm = can256 && (force_bm ? force_bm == 256 : K >= 512) ? 256 : 128;
   Plan best = {};
   double best_cost = 1e30;
@@ -663,12 +661,6 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     args.slot_base = 0; args.slot_used = p.groups_m;
   }
   dim3 g(p.grid);
-  if (fast && wave_n1()) {
-    // experimental wave layouts: one wave column, 64-pixel x BN-channel wave tiles (fewer LDS fragment reads per MFMA)
-    if (p.bm == 256 && p.bn == 64) { hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 1, MODE, true>), g, dim3(256), 0, stream, args); KOD_LAUNCH_CHECK("conv_igemm"); return KOD_OK; }
-    if (p.bm == 128 && p.bn == 64) { hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 1, MODE, true>), g, dim3(128), 0, stream, args); KOD_LAUNCH_CHECK("conv_igemm"); return KOD_OK; }
-    if (p.bm == 256 && p.bn == 32) { hipLaunchKernelGGL((conv_igemm_kernel<256, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, args); KOD_LAUNCH_CHECK("conv_igemm"); return KOD_OK; }
-  }
   if (fast) {
     if (p.bm == 256 && p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
     else if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
@@ -704,11 +696,6 @@ int launch_x4(ConvArgs c[4], hipStream_t stream) {
     }
   }
   dim3 g(pl.grid * 4);
-  if (wave_n1()) {
-    if (pl.bm == 256 && pl.bn == 64) { hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 1, MODE, true>), g, dim3(256), 0, stream, p); KOD_LAUNCH_CHECK("conv_igemm_x4"); return KOD_OK; }
-    if (pl.bm == 128 && pl.bn == 64) { hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 1, MODE, true>), g, dim3(128), 0, stream, p); KOD_LAUNCH_CHECK("conv_igemm_x4"); return KOD_OK; }
-    if (pl.bm == 256 && pl.bn == 32) { hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, p); KOD_LAUNCH_CHECK("conv_igemm_x4"); return KOD_OK; }
-  }
   if (pl.bm == 256 && pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
   else if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
   else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true>), g, dim3(256), 0, stream, p);

@@ -219,7 +219,12 @@ __device__ __forceinline__ int swz(int row, int mask) { return mask == 3 ? 4 * (
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int WN, int WK, int RN, int RK, int NST, int RS>
+// GM = how the X gather address of a step is produced: 1 pointwise (1x1 / stride 1 / no padding: a plain strided
+// stream like dY, no address arithmetic in the loop), 0 two magic divisions per step (any geometry).  A compile-time
+// choice: the loop is instruction-issue-bound (rocprofv3: MFMA pipe utilisation 12 %), a run-time switch would keep
+// both address generators and their branches in it.  (Measured and dropped: carrying (b, oy, ox) per lane with
+// branch-free wraps costs as many VALU instructions as the divisions.)
+template <int WN, int WK, int RN, int RK, int NST, int RS, int GM>
 __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs a, uint32_t x_bytes, uint32_t dy_bytes) {
   constexpr int NW = WN * WK;
   constexpr int TNB = WN * RN * 32;
@@ -262,17 +267,21 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
   //      The gather address of a step is recomputed from the row index with two exact magic divisions (branch-free,
   //      ~30 VALU per slot): the loop is instruction-issue-bound on address generation, not on MFMA or bandwidth.
   int s_row[SLOTS];                 // tile row this lane fills
-  uint32_t s_off[SLOTS];            // dY: running byte offset; X: byte offset of (xcoff + ci)
+  uint32_t s_off[SLOTS];            // dY (and X of a pointwise conv): running byte offset; X: byte offset of (xcoff + ci)
   bool s_ok[SLOTS];                 // channel / k column in range
   int s_cy[SLOTS], s_cx[SLOTS];     // X: kh - PH, kw - PW
   int my_slots = 0;
+  constexpr bool pointwise = GM == 1;
+  // slot roles: instruction t = wave + i * NW feeds dY when t < NIY, else X.  When NW divides NIY and NI the role of
+  // slot i is the same for every wave (compile-time): no per-slot branches in the loop
+  constexpr bool ROLE_STATIC = (NIY % NW == 0) && (NI % NW == 0);
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
     const int t = wave + i * NW;
     s_row[i] = 0; s_off[i] = 0; s_ok[i] = false; s_cy[i] = s_cx[i] = 0;
-    if (t >= NI) continue;
+    if (!ROLE_STATIC && t >= NI) continue;
     ++my_slots;
-    if (t < NIY) {
+    if (ROLE_STATIC ? (i < NIY / NW) : (t < NIY)) {
       const int L = t * 1024 + lane * 16;
       const int row = L / RBY, pc = (L % RBY) >> 4;
       const int c = pc ^ swz(row, MY);
@@ -291,10 +300,11 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
       s_ok[i] = k < a.K;
       s_cy[i] = kh - a.PH; s_cx[i] = ((int)tap - kh * a.KW) - a.PW;
       s_off[i] = (uint32_t)((a.xcoff + ci) * 2);
+      if (pointwise) s_off[i] = (uint32_t)(((long)(m_begin + row) * a.ldx + a.xcoff + ci) * 2);
     }
   }
   const uint32_t magic_hwo = a.magic_hwo, magic_wo = a.magic_wo;
-  const uint32_t ldx2 = (uint32_t)a.ldx * 2u, ystep = (uint32_t)(RS * a.ldy * 2);
+  const uint32_t ldx2 = (uint32_t)a.ldx * 2u, ystep = (uint32_t)(RS * a.ldy * 2), xstep = (uint32_t)(RS * a.ldx * 2);
 
   int issued = 0;                   // tiles issued so far (tile index = reduction step)
   auto issue = [&](int stage) {
@@ -303,13 +313,17 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
       const int t = wave + i * NW;
-      if (t >= NI) continue;
+      if (!ROLE_STATIC && t >= NI) continue;
       const int m = mb + s_row[i];
       uint32_t vo;
       bool ok = s_ok[i] && m < m_end;
-      if (t < NIY) {
+      const bool is_y = ROLE_STATIC ? (i < NIY / NW) : (t < NIY);
+      if (is_y) {
         vo = s_off[i];
         s_off[i] += ystep;
+      } else if (pointwise) {
+        vo = s_off[i];
+        s_off[i] += xstep;
       } else {
         // q = m / d with magic = ceil(2^32 / d): the estimate is q or q + 1 for any 31-bit m
         uint32_t b = magic_hwo ? __umulhi((uint32_t)m, magic_hwo) : (uint32_t)m;
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
       }
       vo = ok ? vo : 0xFFFFFFF0u;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(WG_ABL_NODMA)
-      if (t < NIY)
+      if (is_y)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (__attribute__((address_space(3))) void*)(Ys + t * 1024), 16, vo, 0, 0, 0);
       else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Ys + t * 1024), 16, vo, 0, 0, 0);
@@ -521,8 +535,10 @@ int launch_cfg(WgradArgs a, hipStream_t stream) {
   const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, yb = (long)a.M * a.ldy * 2;
   static const char* mode = getenv("KODHIP_WGRAD_DMA");
   if (!(mode && mode[0] == 'n') && xb < (1l << 32) - 64 && yb < (1l << 32) - 64) {
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<WN, WK, RN, RK, WGRAD_STAGES, WGRAD_ROWS>), dim3(grid), dim3(64 * WN * WK), 0, stream, a,
-                       (uint32_t)xb, (uint32_t)yb);
+    const bool pw = a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PH == 0 && a.PW == 0;
+    const dim3 g(grid), b(64 * WN * WK);
+    if (pw) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WN, WK, RN, RK, WGRAD_STAGES, WGRAD_ROWS, 1>), g, b, 0, stream, a, (uint32_t)xb, (uint32_t)yb);
+    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WN, WK, RN, RK, WGRAD_STAGES, WGRAD_ROWS, 0>), g, b, 0, stream, a, (uint32_t)xb, (uint32_t)yb);
     KOD_LAUNCH_CHECK("conv_wgrad_dma");
     return KOD_OK;
   }

@@ -85,86 +85,126 @@ __global__ void pack_weights_kernel(const float* master, bf16_t* fpack, bf16_t* 
 }
 
 // ------------------------------------------------------------------ SPPF max pool 5x5 s1 p2
+// One thread = PX consecutive output columns x 8 channels: the 5 x (PX + 4) input window is loaded once and shared
+// by the PX outputs (40 instead of 100 sixteen-byte loads per 4 outputs; the pool is L2-read-bound).  Argmax follows
+// torch's scan (row-major over the window, first maximum wins; a NaN replaces anything).
+constexpr int POOL_PX = 4;
+
 __global__ void maxpool5_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_t* y, int ldy, int ycoff,
                                     unsigned char* idx, int B, int H, int W, int C) {
   const int CC = C >> 3;
+  const int WG = (W + POOL_PX - 1) / POOL_PX;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = (long)B * H * W * CC;
+  long total = (long)B * H * WG * CC;
   if (i >= total) return;
   int cc = (int)(i % CC);
   long p = i / CC;
-  int ox = (int)(p % W);
-  long q = p / W;
+  int gx = (int)(p % WG);
+  long q = p / WG;
   int oy = (int)(q % H);
   int b = (int)(q / H);
-  float best[8];
-  unsigned char bi[8];
+  const int ox0 = gx * POOL_PX;
+  float best[POOL_PX][8];
+  unsigned char bi[POOL_PX][8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+  for (int o = 0; o < POOL_PX; ++o)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[o][e] = -INFINITY; bi[o][e] = 0; }
   for (int dy = 0; dy < 5; ++dy) {
     int iy = oy + dy - 2;
     if (iy < 0 || iy >= H) continue;
-    for (int dx = 0; dx < 5; ++dx) {
-      int ix = ox + dx - 2;
-      if (ix < 0 || ix >= W) continue;
-      bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)(b * H + iy) * W + ix) * ldx + xcoff + cc * 8);
+    bf16x8 col[POOL_PX + 4];
+    bool cok[POOL_PX + 4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float f = (float)v[e];
-        if (f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(dy * 5 + dx); }
-      }
+    for (int c = 0; c < POOL_PX + 4; ++c) {
+      int ix = ox0 + c - 2;
+      cok[c] = ix >= 0 && ix < W;
+      if (cok[c]) col[c] = *reinterpret_cast<const bf16x8*>(x + ((long)(b * H + iy) * W + ix) * ldx + xcoff + cc * 8);
     }
-  }
-  bf16x8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)best[e];
-  *reinterpret_cast<bf16x8*>(y + p * ldy + ycoff + cc * 8) = o;
-  // the 8 argmax bytes leave as one 8-byte store (C % 8 == 0 keeps it aligned)
-  uint2 packed;
-  packed.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
-  packed.y = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
-  *reinterpret_cast<uint2*>(idx + p * C + cc * 8) = packed;
+    for (int o = 0; o < POOL_PX; ++o)
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        if (!cok[o + dx]) continue;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = (float)col[o + dx][e];
+          if (f > best[o][e] || f != f) { best[o][e] = f; bi[o][e] = (unsigned char)(dy * 5 + dx); }
+        }
+      }
+  }
+#pragma unroll
+  for (int o = 0; o < POOL_PX; ++o) {
+    if (ox0 + o >= W) break;
+    const long op = (long)(b * H + oy) * W + ox0 + o;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)best[o][e];
+    *reinterpret_cast<bf16x8*>(y + op * ldy + ycoff + cc * 8) = v;
+    // the 8 argmax bytes leave as one 8-byte store (C % 8 == 0 keeps it aligned)
+    uint2 packed;
+    packed.x = (uint32_t)bi[o][0] | ((uint32_t)bi[o][1] << 8) | ((uint32_t)bi[o][2] << 16) | ((uint32_t)bi[o][3] << 24);
+    packed.y = (uint32_t)bi[o][4] | ((uint32_t)bi[o][5] << 8) | ((uint32_t)bi[o][6] << 16) | ((uint32_t)bi[o][7] << 24);
+    *reinterpret_cast<uint2*>(idx + op * C + cc * 8) = packed;
+  }
 }
 
-// dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic)
+// dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic; same column sharing)
 __global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const unsigned char* idx,
                                     bf16_t* dx, int ldx, int xcoff, int B, int H, int W, int C) {
   const int CC = C >> 3;
+  const int WG = (W + POOL_PX - 1) / POOL_PX;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = (long)B * H * W * CC;
+  long total = (long)B * H * WG * CC;
   if (i >= total) return;
   int cc = (int)(i % CC);
   long p = i / CC;
-  int ix = (int)(p % W);
-  long q = p / W;
+  int gx = (int)(p % WG);
+  long q = p / WG;
   int iy = (int)(q % H);
   int b = (int)(q / H);
-  float acc[8];
-  bf16_t* d = dx + p * ldx + xcoff + cc * 8;
-  bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
+  const int ix0 = gx * POOL_PX;
+  float acc[POOL_PX][8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = (float)old[e];
+  for (int o = 0; o < POOL_PX; ++o) {
+    const bool in = ix0 + o < W;
+    bf16x8 old = {};
+    if (in) old = *reinterpret_cast<const bf16x8*>(dx + ((long)(b * H + iy) * W + ix0 + o) * ldx + xcoff + cc * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[o][e] = in ? (float)old[e] : 0.f;
+  }
   for (int dyy = 0; dyy < 5; ++dyy) {
     int oy = iy - dyy + 2;                 // output row whose window tap dyy hits iy
     if (oy < 0 || oy >= H) continue;
-    for (int dxx = 0; dxx < 5; ++dxx) {
-      int ox = ix - dxx + 2;
-      if (ox < 0 || ox >= W) continue;
-      long op = (long)(b * H + oy) * W + ox;
-      const uint2 ib = *reinterpret_cast<const uint2*>(idx + op * C + cc * 8);     // 8 argmax bytes in one load
-      bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + op * ldy + ycoff + cc * 8);
-      const uint32_t want = (uint32_t)(dyy * 5 + dxx);
+    // output columns ox = ix - dxx + 2 for ix in [ix0, ix0 + PX), dxx in [0, 5): ox0 - 2 .. ox0 + PX + 1
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const uint32_t byte = ((e < 4 ? ib.x : ib.y) >> (8 * (e & 3))) & 0xffu;
-        if (byte == want) acc[e] += (float)g[e];
+    for (int c = 0; c < POOL_PX + 4; ++c) {
+      const int ox = ix0 + c - 2;
+      if (ox < 0 || ox >= W) continue;
+      const long op = (long)(b * H + oy) * W + ox;
+      const uint2 ib = *reinterpret_cast<const uint2*>(idx + op * C + cc * 8);     // 8 argmax bytes in one load
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + op * ldy + ycoff + cc * 8);
+#pragma unroll
+      for (int o = 0; o < POOL_PX; ++o) {
+        const int dxx = o - c + 4;         // ix = ix0 + o, ox = ix - dxx + 2  =>  dxx = ix - ox + 2
+        if (dxx < 0 || dxx > 4) continue;
+        const uint32_t want = (uint32_t)(dyy * 5 + dxx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t byte = ((e < 4 ? ib.x : ib.y) >> (8 * (e & 3))) & 0xffu;
+          if (byte == want) acc[o][e] += (float)g[e];
+        }
       }
     }
   }
-  bf16x8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
-  *reinterpret_cast<bf16x8*>(d) = o;
+  for (int o = 0; o < POOL_PX; ++o) {
+    if (ix0 + o >= W) break;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)acc[o][e];
+    *reinterpret_cast<bf16x8*>(dx + ((long)(b * H + iy) * W + ix0 + o) * ldx + xcoff + cc * 8) = v;
+  }
 }
 
 // ------------------------------------------------------------------ nearest x2 upsample
@@ -332,7 +372,7 @@ int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int
                         int B, int H, int W, int C, hipStream_t stream) {
   KOD_CHECK_ARG(x && y && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
                 "maxpool5_fwd: bad args");
-  long n = (long)B * H * W * (C / 8);
+  long n = (long)B * H * ((W + POOL_PX - 1) / POOL_PX) * (C / 8);
   hipLaunchKernelGGL(maxpool5_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, xcoff,
                      (bf16_t*)y, ldy, ycoff, (unsigned char*)idx, B, H, W, C);
   KOD_LAUNCH_CHECK("maxpool5_fwd");
@@ -343,7 +383,7 @@ int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, voi
                         int B, int H, int W, int C, hipStream_t stream) {
   KOD_CHECK_ARG(dy && dx && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
                 "maxpool5_bwd: bad args");
-  long n = (long)B * H * W * (C / 8);
+  long n = (long)B * H * ((W + POOL_PX - 1) / POOL_PX) * (C / 8);
   hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)dy, ldy, ycoff,
                      (const unsigned char*)idx, (bf16_t*)dx, ldx, xcoff, B, H, W, C);
   KOD_LAUNCH_CHECK("maxpool5_bwd");

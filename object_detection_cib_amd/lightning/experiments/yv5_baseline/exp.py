@@ -48,6 +48,7 @@ class DefaultYolov5Experiment:
         # graphed=True: the optimisation step is captured once as a hipGraph (engine/graphed.py) and replayed - same
         # arithmetic, no per-launch Python; batches must keep one shape and at most max_targets boxes
         self.graphed, self.max_targets, self._gstep = graphed, max_targets, None
+        self._geval = {}              # input shape -> GraphedEvalForward
 
     # exp.py:156-162
     def configure_optimizers(self):
@@ -81,6 +82,13 @@ class DefaultYolov5Experiment:
     @torch.no_grad()
     def validation_step(self, batch, batch_idx: int = 0):
         images, targets, _ = batch
+        if self.graphed:          # eval forward + decode replayed as one hipGraph per input shape (engine/graphed.py)
+            from ....engine.graphed import GraphedEvalForward
+            key = tuple(images.shape)
+            if key not in self._geval:
+                self._geval[key] = GraphedEvalForward(self.net, self.anchor_info, key[0], key[2], key[3])
+            det = self._geval[key](images if images.dtype == torch.float32 else images.float())
+            return targets, non_max_suppression(det, self.val_nms_conf_threshold, self.val_nms_iou_threshold)
         was = self.net.training
         self.net.eval()
         res = self.net(images)
