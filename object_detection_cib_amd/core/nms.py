@@ -10,7 +10,7 @@ from typing import Sequence
 
 import torch
 
-from .. import _lib
+from .. import _host, _lib
 
 
 def non_max_suppression(detections: torch.Tensor, conf_thres: float = 0.25, nms_thres: float = 0.45,
@@ -39,5 +39,5 @@ def non_max_suppression(detections: torch.Tensor, conf_thres: float = 0.25, nms_
     _lib.check(_lib.lib().kodhip_nms(det.data_ptr(), keys.data_ptr(), key_cap, ncand.data_ptr(), out.data_ptr(),
                                      nout.data_ptr(), B, rows, nc, float(conf_thres), float(nms_thres), max_det,
                                      max_nms, max_wh, torch.cuda.current_stream().cuda_stream), "nms")
-    counts = nout.tolist()                                           # one sync per batch (sizes the outputs)
+    counts = _host.fetch(nout)[0].tolist()                           # one polling hand-off per batch (sizes the outputs)
     return [out[b, :n] for b, n in enumerate(counts)]

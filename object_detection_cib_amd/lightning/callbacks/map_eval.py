@@ -19,7 +19,7 @@ from typing import Sequence
 import numpy as np
 import torch
 
-from ... import _lib
+from ... import _host, _lib
 from ...core.label_assignment.yv5 import BatchedTargets
 
 IOUS = (0.3, 0.5, 0.75, 0.9)            # pycoco_map_eval.py:45-48
@@ -52,8 +52,9 @@ class DeviceMAPEvaluator:
                 det[b, :d.shape[0]] = d
         bt = targets if isinstance(targets, BatchedTargets) else BatchedTargets.from_targets(targets, dev)
         counts = torch.bincount(bt.samples.long(), minlength=B) if bt.n else torch.zeros(B, dtype=torch.long, device=dev)
-        if bt.n and int(counts.max()) > MAX_GT_PER_IMAGE:
-            raise ValueError(f"an image carries {int(counts.max())} ground-truth boxes; the device matcher tracks at most "
+        most = int(_host.fetch(counts.max())[0]) if bt.n else 0
+        if most > MAX_GT_PER_IMAGE:
+            raise ValueError(f"an image carries {most} ground-truth boxes; the device matcher tracks at most "
                              f"{MAX_GT_PER_IMAGE} per image (csrc/map_match.hip)")
         start = torch.zeros(B + 1, dtype=torch.int32, device=dev)
         start[1:] = torch.cumsum(counts, 0).int()
@@ -65,10 +66,12 @@ class DeviceMAPEvaluator:
                                                bt.labels.data_ptr() if bt.n else None, start.data_ptr(),
                                                tp.data_ptr(), counted.data_ptr(), B, max_det, self.nc, thr, T,
                                                MAX_DETS, torch.cuda.current_stream().cuda_stream), "map_match")
-        det_h, tp_h, cnt_h = det.cpu().numpy(), tp.cpu().numpy().astype(bool), counted.cpu().numpy().astype(bool)
-        nd_h = ndet.cpu().numpy()
+        labels_dev = bt.labels if bt.n else torch.zeros(1, dtype=torch.int64, device=dev)
+        det_t, tp_t, cnt_t, nd_t, lab_t = _host.fetch(det, tp, counted, ndet, labels_dev)      # one polling hand-off
+        det_h, tp_h, cnt_h = det_t.numpy(), tp_t.numpy().astype(bool), cnt_t.numpy().astype(bool)
+        nd_h = nd_t.numpy()
         if bt.n:
-            self._npig += np.bincount(bt.labels.cpu().numpy(), minlength=self.nc)[:self.nc]
+            self._npig += np.bincount(lab_t.numpy(), minlength=self.nc)[:self.nc]
         for b in range(B):
             rows = np.arange(nd_h[b])
             rows = rows[cnt_h[b, :nd_h[b]]]
