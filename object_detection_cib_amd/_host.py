@@ -1,36 +1,40 @@
 """Low-latency device -> host hand-off for the few places the validation path needs values on the host (NMS counts,
-mAP match flags).  A blocking hipMemcpy / stream synchronize parks the host thread on an interrupt, whose wake-up
-latency (milliseconds on this stack) dwarfs the ~10 ms of GPU work of a validation batch: measured 21-26 ms per batch
-with `.tolist()` / `.cpu()` against 10 ms when nothing sleeps.  Here: asynchronous copies into cached pinned buffers,
-one event, and a polling wait on `event.query()`."""
+mAP match flags).  Two things make the obvious `.cpu()` / `.tolist()` expensive on this stack: a blocking copy parks
+the host thread on an interrupt (millisecond wake-ups against ~10 ms of GPU work per validation batch), and every new
+pinned allocation (what a pageable copy stages through, or a fresh `pin_memory()`) costs tens of milliseconds.  Here:
+ONE pinned arena allocated once (grown only if a request does not fit), asynchronous copies into slices of it, one
+event, and a polling wait on `event.query()`."""
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from typing import List
 
 import torch
 
-_pinned: Dict[Tuple[torch.dtype, int], List[torch.Tensor]] = {}
+_ARENA_BYTES = 8 << 20
+_arena = None
 
 
-def _buffer(dtype: torch.dtype, numel: int, slot: int) -> torch.Tensor:
-    cap = 1 << max(int(numel - 1).bit_length(), 6)
-    ring = _pinned.setdefault((dtype, cap), [])
-    while len(ring) <= slot:
-        ring.append(torch.empty(cap, dtype=dtype).pin_memory())
-    return ring[slot]
+def _get_arena(nbytes: int) -> torch.Tensor:
+    global _arena
+    if _arena is None or _arena.numel() < nbytes:
+        _arena = torch.empty(max(_ARENA_BYTES, 2 * nbytes), dtype=torch.uint8).pin_memory()
+    return _arena
 
 
 def fetch(*tensors: torch.Tensor) -> List[torch.Tensor]:
-    """Host copies of device tensors (same shapes / dtypes).  The returned tensors alias cached pinned buffers: they
-    stay valid until the next fetch() that asks for a buffer of the same dtype and size class, so consume them (or
-    `.clone()` / `.numpy().copy()`) before calling fetch again."""
-    outs, used = [], {}
-    for t in tensors:
-        t = t.contiguous()
-        key = (t.dtype, 1 << max(int(t.numel() - 1).bit_length(), 6))
-        slot = used.get(key, 0)
-        used[key] = slot + 1
-        host = _buffer(t.dtype, max(t.numel(), 1), slot)[:t.numel()].view(t.shape)
+    """Host copies of device tensors (same shapes / dtypes).  The returned tensors are views of the shared pinned
+    arena: they are valid until the next fetch(), so consume them (or `.clone()` / `.numpy().copy()`) before that."""
+    srcs = [t.contiguous() for t in tensors]
+    offs, total = [], 0
+    for t in srcs:
+        total = (total + 63) // 64 * 64
+        offs.append(total)
+        total += t.numel() * t.element_size()
+    arena = _get_arena(total + 64)
+    outs = []
+    for t, o in zip(srcs, offs):
+        n = t.numel() * t.element_size()
+        host = arena[o:o + n].view(t.dtype).view(t.shape)
         host.copy_(t, non_blocking=True)
         outs.append(host)
     ev = torch.cuda.Event()

@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle runs on torch's intra-op pool: size it to the cores the cgroup grants (a GPU box shows 256 CPUs
+    # but a 16-core quota; 128 spinning threads get the whole process throttled)
+    import torch
+    from object_detection_cib_amd._lib import cpu_share
+    torch.set_num_threads(min(torch.get_num_threads(), cpu_share()))
 
 
 @pytest.fixture(scope="session")
