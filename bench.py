@@ -26,6 +26,28 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_IMG_BF16 = 371.5e6        # 3 * (sum conv inputs + sum conv outputs) * 2 B
 ALGO_FLOP_PER_IMG = 46.785e9             # fwd + dgrad + wgrad, 2*MAC
 HBM_PEAK = 8.0e12                        # B/s, MI355X_MICROARCH.md chip table
+VARIANTS = {"yv5n": (0.25, 0.33), "yv5s": (0.5, 0.33), "yv5m": (0.75, 0.67)}      # (widen, deepen); yv5m = BASELINE configs[4]
+
+
+def algorithmic_work(widen, deepen, nc, S):
+    """SURVEY 8(d) per-image work from the network's static program: bytes = 3 * (sum conv inputs + sum conv outputs)
+    * 2 B over the 57 conv units + 9 head convs, FLOP = 3 * forward 2*MAC - the stem's data gradient.  Reproduces the
+    survey's figures (yv5s 371.5 MB / 46.785 GFLOP, yv5m 670.4 MB / 142.845 GFLOP, yv5n 12.147 GFLOP)."""
+    from object_detection_cib_amd.engine.graph import build_graph
+    g = build_graph(3, nc, widen, deepen)
+    sin = sout = fl = 0
+    for op in g.ops:
+        if op.kind == "conv":
+            u = op.unit
+            hin, cin, k = (S, 3, 6) if u.stem else (S // u.src.stride, u.cin, u.k)
+            ho = hin // u.s
+            sin += hin * hin * cin; sout += ho * ho * u.cout; fl += 2 * ho * ho * u.cout * cin * k * k
+        elif op.kind == "head":
+            hh = S // op.unit.stride
+            for n in (4 * g.num_anchors, g.num_anchors, nc * g.num_anchors):
+                sin += hh * hh * op.unit.cin; sout += hh * hh * n; fl += 2 * hh * hh * n * op.unit.cin
+    stem_dgrad = 2 * (S // 2) ** 2 * g.units[0].cout * 3 * 36
+    return 3.0 * (sin + sout) * 2, 3.0 * fl - stem_dgrad
 FAMILY_KERNELS = {
     "conv_fwd": "conv_igemm_kernel<MODE_RAW> (forward conv + BN statistics, 57 layers)",
     "dgrad": "conv_igemm[_x4]_kernel<MODE_PLAIN> (data gradient)",
@@ -65,14 +87,14 @@ def synth_batch(B, size, nc, seed, device):
     return x.to(device), BatchedTargets.from_targets(tuple(tg), device)
 
 
-def build(nc, device, seed=2023):
+def build(nc, device, seed=2023, widen=0.5, deepen=0.33):
     from object_detection_cib_amd.core.anchors.info import voc_anchor_info
     from object_detection_cib_amd.core.bbox.iou import IoUCalculator
     from object_detection_cib_amd.core.label_assignment.yv5 import Yolov5LabelAssigner, AssignmentAnchorInfo
     from object_detection_cib_amd.lightning.experiments.yv5_baseline.loss import Yolov5Loss, Yolov5LossParams
     from object_detection_cib_amd.nn.networks.yolov5 import Yolov5Network
     torch.manual_seed(seed)
-    net = Yolov5Network(3, nc, widen_factor=0.5, deepen_factor=0.33).to(device).train()
+    net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen).to(device).train()
     asg = Yolov5LabelAssigner(AssignmentAnchorInfo(voc_anchor_info(8), voc_anchor_info(16), voc_anchor_info(32)), 4.0)
     loss = Yolov5Loss(asg, Yolov5LossParams.get_default(), IoUCalculator("ciou", 1e-7), None)
     return net, loss
@@ -153,6 +175,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--variant", default="yv5s", choices=sorted(VARIANTS), help="network scale (yv5m = BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -178,7 +201,11 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     nc, B, S = 10, args.batch, args.size
-    net, loss_fn = build(nc, device)
+    widen, deepen = VARIANTS[args.variant]
+    net, loss_fn = build(nc, device, widen=widen, deepen=deepen)
+    algo_bytes, algo_flop = algorithmic_work(widen, deepen, nc, S)
+    if args.variant == "yv5s" and S == 640:
+        assert abs(algo_bytes - ALGO_BYTES_PER_IMG_BF16) < 1e-3 * ALGO_BYTES_PER_IMG_BF16 and abs(algo_flop - ALGO_FLOP_PER_IMG) < 1e-3 * ALGO_FLOP_PER_IMG
     eng = net.engine()
     if use_dist:
         net.configure_distributed(None, sync_batchnorm=not args.no_sync_bn, native_rccl=True)
@@ -283,22 +310,22 @@ def main():
         top = table[0]
         n_launch = max(top["launches"], 1)
         out = {
-            "metric": "images/sec YOLOv5s 640px train", "value": round(ips, 2), "unit": "images/sec",
+            "metric": f"images/sec YOLOv5{args.variant[-1]} {S}px train", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "yv5s coco-zipf-like synthetic, 640px, bf16 storage/fp32 accumulate, "
+            "config": {"workload": f"{args.variant} coco-zipf-like synthetic, {S}px, bf16 storage/fp32 accumulate, "
                                    f"batch {B}/GPU, fwd+assign+loss+bwd+SGD, targets 4-30 boxes/img",
                        "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if use_dist and not args.no_sync_bn else ""),
                        "launch": launch_note, "collectives": ("RCCL, native in-stream" if use_dist else "none")},
             "final_loss": final_loss,
-            "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_img": ALGO_BYTES_PER_IMG_BF16,
-                              "achieved": round(ips / world * ALGO_BYTES_PER_IMG_BF16 / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                              "unit": "GB/s", "frac": round(ips / world * ALGO_BYTES_PER_IMG_BF16 / HBM_PEAK, 4),
-                              "tflops": round(ips / world * ALGO_FLOP_PER_IMG / 1e12, 1)},
+            "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_img": algo_bytes,
+                              "achieved": round(ips / world * algo_bytes / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                              "unit": "GB/s", "frac": round(ips / world * algo_bytes / HBM_PEAK, 4),
+                              "tflops": round(ips / world * algo_flop / 1e12, 1)},
             "roofline": {"kernel": FAMILY_KERNELS.get(top["family"], top["family"]), "family": top["family"], "bound": "hbm",
                          "achieved": top["GB/s"], "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": top["frac"],
-                         "traffic": pmc_traffic(top["family"], B, S),
+                         "traffic": pmc_traffic(top["family"], B, S) if args.variant == "yv5s" else None,
                          "avg_launch_us": round(1e3 * top["ms"] / n_launch, 2), "launches": top["launches"],
                          "algorithmic_bytes_per_launch_avg": round(1e6 * top["algorithmic_MB"] / n_launch),
                          "share_of_step": top["share_of_step"]},

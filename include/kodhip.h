@@ -205,6 +205,9 @@ int kodhip_comm_destroy(void* comm);
 int kodhip_comm_allreduce_sum(void* comm, void* buf, long count, int elem_bytes /* 4: fp32, 8: fp64 */, kodStream_t stream);
 int kodhip_comm_allreduce_sum_to(void* comm, const void* send, void* recv, long count, int elem_bytes, kodStream_t stream);
 int kodhip_comm_broadcast(void* comm, void* buf, long bytes, int root, kodStream_t stream);
+/* collectives enqueued between the two calls are launched as one fused operation (ncclGroupStart / ncclGroupEnd) */
+int kodhip_comm_group_start(void);
+int kodhip_comm_group_end(void);
 
 #ifdef __cplusplus
 }

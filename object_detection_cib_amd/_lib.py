@@ -71,6 +71,8 @@ SIGNATURES = {
     "kodhip_comm_allreduce_sum": (i32, [vp, vp, i64, i32, vp]),
     "kodhip_comm_allreduce_sum_to": (i32, [vp, vp, vp, i64, i32, vp]),
     "kodhip_comm_broadcast": (i32, [vp, vp, i64, i32, vp]),
+    "kodhip_comm_group_start": (i32, []),
+    "kodhip_comm_group_end": (i32, []),
     "kodhip_compose_desc_bytes": (i32, []),
     "kodhip_compose_batch": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_val_prep_desc_bytes": (i32, []),

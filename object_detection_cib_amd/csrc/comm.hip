@@ -119,6 +119,19 @@ int kodhip_comm_allreduce_sum_to(void* comm, const void* send, void* recv, long 
   return KOD_OK;
 }
 
+// ncclGroupStart / ncclGroupEnd: the collectives enqueued in between are launched as one fused operation - the
+// SyncBN statistic exchanges of sibling layers (a CSP layer's main and short convs) travel together
+int kodhip_comm_group_start(void) {
+  KOD_CHECK_ARG(g_api.handle, "comm_group_start: RCCL not loaded");
+  KOD_RCCL(g_api.GroupStart(), "comm_group_start");
+  return KOD_OK;
+}
+int kodhip_comm_group_end(void) {
+  KOD_CHECK_ARG(g_api.handle, "comm_group_end: RCCL not loaded");
+  KOD_RCCL(g_api.GroupEnd(), "comm_group_end");
+  return KOD_OK;
+}
+
 // in-place broadcast of `bytes` bytes from `root` (initial parameters and BatchNorm buffers)
 int kodhip_comm_broadcast(void* comm, void* buf, long bytes, int root, hipStream_t stream) {
   KOD_CHECK_ARG(comm && buf && bytes > 0 && root >= 0, "comm_broadcast: bad args");

@@ -56,6 +56,19 @@ class RcclComm:
         _lib.check(self.lib.kodhip_comm_broadcast(self._handle, t.data_ptr(), t.numel() * t.element_size(), root, s),
                    "comm_broadcast")
 
+    def group(self):
+        """Context manager: the collectives issued inside are launched as ONE fused RCCL operation."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _g():
+            _lib.check(self.lib.kodhip_comm_group_start(), "comm_group_start")
+            try:
+                yield
+            finally:
+                _lib.check(self.lib.kodhip_comm_group_end(), "comm_group_end")
+        return _g()
+
     def close(self):
         if self._handle:
             torch.cuda.synchronize(self.device)

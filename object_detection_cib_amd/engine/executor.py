@@ -417,6 +417,25 @@ class Engine:
             else:
                 torch.distributed.all_reduce(t, group=self.process_group)
 
+    def _allreduce_group(self, tensors, outs=None):
+        """In-place (or, with `outs`, out-of-place) sum all-reduce of several small tensors as ONE collective launch
+        (ncclGroupStart / End) on the native communicator; one call each on a torch.distributed group."""
+        if not self.collectives:
+            return
+        if self.comm is not None:
+            if len(tensors) == 1:
+                self.comm.all_reduce(tensors[0]) if outs is None else self.comm.all_reduce_to(tensors[0], outs[0])
+                return
+            with self.comm.group():
+                for k, t in enumerate(tensors):
+                    self.comm.all_reduce(t) if outs is None else self.comm.all_reduce_to(t, outs[k])
+        else:
+            for k, t in enumerate(tensors):
+                if outs is not None:
+                    outs[k].copy_(t)
+                    t = outs[k]
+                torch.distributed.all_reduce(t, group=self.process_group)
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor, training: bool = True):
         """x: [B,3,H,W] fp32 NCHW on this device.  Returns 3 tensors [B,A,h,w,5+nc] fp32 (ll, ml, hl)."""
@@ -433,45 +452,76 @@ class Engine:
         pool_i = 0
         fp, pa = self.fpack.data_ptr(), self.p_arena.data_ptr()
         eval_aff = None if training else self._eval_affine_ptrs()
-        for op in self.g.ops:
-            if op.kind == "conv":
-                u: ConvUnit = op.unit
-                st = self.ustate[u.name]
-                C_ = u.cout
-                if u.stem:
-                    geo = (B, st.H, st.W, 8, 0, 32, C_, 6, 1, 2, 1, 2, 1, st.Kp_f)      # wide-pixel form, see Kp_f
-                else:
-                    geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p, st.Kp_f)
-                e0 = self._t0()
-                chk(lib.kodhip_conv_fwd_raw(self._ptr(u.src), fp + 2 * st.f_off, st.raw.data_ptr(),
-                                            st.stats.data_ptr(), *geo, C_, 0, s), u.name)
-                cin_true = 3 if u.stem else u.cin
-                in_px = B * H * W if u.stem else B * st.H * st.W
-                self._t1(e0, "conv_fwd", 2 * (in_px * cin_true + st.M * C_))
-                aff = st.aff.data_ptr()
-                e0 = self._t0()
-                if training and not (self.sync_bn and self.collectives):
+        sync = training and self.sync_bn and self.collectives
+        rm, rv = self.rm_arena.data_ptr(), self.rv_arena.data_ptr()
+
+        def conv_stage(u: ConvUnit):
+            st, C_ = self.ustate[u.name], u.cout
+            if u.stem:
+                geo = (B, st.H, st.W, 8, 0, 32, C_, 6, 1, 2, 1, 2, 1, st.Kp_f)      # wide-pixel form, see Kp_f
+            else:
+                geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p, st.Kp_f)
+            e0 = self._t0()
+            chk(lib.kodhip_conv_fwd_raw(self._ptr(u.src), fp + 2 * st.f_off, st.raw.data_ptr(),
+                                        st.stats.data_ptr(), *geo, C_, 0, s), u.name)
+            cin_true = 3 if u.stem else u.cin
+            in_px = B * H * W if u.stem else B * st.H * st.W
+            self._t1(e0, "conv_fwd", 2 * (in_px * cin_true + st.M * C_))
+
+        def stats_stage(group):
+            """Batch statistics -> BatchNorm constants.  Under SyncBN the [sum, sum of squares] vectors of the group's
+            units (a CSP layer's main + short convs) are exchanged as ONE grouped collective."""
+            e0 = self._t0()
+            if not sync:
+                for u in group:
+                    st, C_ = self.ustate[u.name], u.cout
+                    aff = st.aff.data_ptr()
                     chk(lib.kodhip_bn_finalize_partials(st.stats.data_ptr(), st.T, float(st.M), pa + 4 * st.g_off,
-                                                        pa + 4 * st.b_off, self.rm_arena.data_ptr() + 4 * st.rs_off,
-                                                        self.rv_arena.data_ptr() + 4 * st.rs_off, BN_MOMENTUM, BN_EPS,
-                                                        aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
-                elif training:
-                    chk(lib.kodhip_bn_reduce_partials(st.stats.data_ptr(), st.sums.data_ptr(), C_, st.T, s), u.name)
-                    self._allreduce(st.sums)
-                    count = float(st.M) * self.world_size
-                    chk(lib.kodhip_bn_finalize(st.sums.data_ptr(), count, pa + 4 * st.g_off, pa + 4 * st.b_off,
-                                               self.rm_arena.data_ptr() + 4 * st.rs_off,
-                                               self.rv_arena.data_ptr() + 4 * st.rs_off, BN_MOMENTUM, BN_EPS,
-                                               aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
-                self._t1(e0, "bn_finalize", 8.0 * C_ * st.T)
-                sc_p, sh_p = (aff, aff + 4 * C_) if training else eval_aff[u.name]
-                res = u.residual
-                e0 = self._t0()
-                chk(lib.kodhip_bn_silu_apply(st.raw.data_ptr(), st.raw_ld, sc_p, sh_p,
-                                             self._ptr(res) if res else None, res.buf.C if res else 0,
-                                             res.coff if res else 0,
-                                             self._ptr(u.dst), u.dst.buf.C, u.dst.coff, st.M, C_, s), u.name)
-                self._t1(e0, "bn_silu_apply", (6.0 if res else 4.0) * st.M * C_)
+                                                        pa + 4 * st.b_off, rm + 4 * st.rs_off, rv + 4 * st.rs_off,
+                                                        BN_MOMENTUM, BN_EPS, aff, aff + 4 * C_, aff + 8 * C_,
+                                                        aff + 12 * C_, C_, 1, s), u.name)
+            else:
+                for u in group:
+                    st = self.ustate[u.name]
+                    chk(lib.kodhip_bn_reduce_partials(st.stats.data_ptr(), st.sums.data_ptr(), u.cout, st.T, s), u.name)
+                self._allreduce_group([self.ustate[u.name].sums for u in group])
+                for u in group:
+                    st, C_ = self.ustate[u.name], u.cout
+                    aff = st.aff.data_ptr()
+                    chk(lib.kodhip_bn_finalize(st.sums.data_ptr(), float(st.M) * self.world_size, pa + 4 * st.g_off,
+                                               pa + 4 * st.b_off, rm + 4 * st.rs_off, rv + 4 * st.rs_off, BN_MOMENTUM,
+                                               BN_EPS, aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
+            self._t1(e0, "bn_finalize", sum(8.0 * u.cout * self.ustate[u.name].T for u in group))
+
+        def apply_stage(u: ConvUnit):
+            st, C_ = self.ustate[u.name], u.cout
+            aff = st.aff.data_ptr()
+            sc_p, sh_p = (aff, aff + 4 * C_) if training else eval_aff[u.name]
+            res = u.residual
+            e0 = self._t0()
+            chk(lib.kodhip_bn_silu_apply(st.raw.data_ptr(), st.raw_ld, sc_p, sh_p,
+                                         self._ptr(res) if res else None, res.buf.C if res else 0,
+                                         res.coff if res else 0,
+                                         self._ptr(u.dst), u.dst.buf.C, u.dst.coff, st.M, C_, s), u.name)
+            self._t1(e0, "bn_silu_apply", (6.0 if res else 4.0) * st.M * C_)
+
+        ops = self.g.ops
+        i = 0
+        while i < len(ops):
+            op = ops[i]
+            i += 1
+            if op.kind == "conv":
+                group = [op.unit]
+                # SyncBN: a unit and its sibling (same input, next in the program) share one statistic exchange
+                if sync and op.unit.sibling is not None and i < len(ops) and ops[i].unit is op.unit.sibling:
+                    group.append(ops[i].unit)
+                    i += 1
+                for u in group:
+                    conv_stage(u)
+                if training:
+                    stats_stage(group)
+                for u in group:
+                    apply_stage(u)
             elif op.kind == "pool":
                 h, w = H // op.src.stride, W // op.src.stride
                 chk(lib.kodhip_maxpool5_fwd(self._ptr(op.src), op.src.buf.C, op.src.coff, self._ptr(op.dst),
@@ -583,7 +633,59 @@ class Engine:
         unit_i = len(self.unit_starts)
         pool_i = len(self.pool_idx)
         head_i = len(self.g.heads)
-        for op in reversed(self.g.ops):
+        sync = self.sync_bn and self.collectives
+
+        def bucket_tick():
+            """one conv / head unit's gradients are complete: buckets finish from the arena's end toward its start"""
+            nonlocal unit_i
+            unit_i -= 1
+            if unit_i in buckets:
+                lo, hi = buckets[unit_i]
+                cs = self._comm_stream()
+                # overlapped buckets use their own communicator: SyncBN sums (main stream) and buckets (side stream)
+                # never interleave on one communicator from two streams
+                bc = self.comm_buckets if (cs is not None and self.comm_buckets is not None) else self.comm
+                self._pending.append(launch_bucket(ga, lo, hi, self.process_group, cs, bc, also_after=wg))
+
+        def bn_bwd_stats(group):
+            """BatchNorm-backward sums -> coefficients.  Under SyncBN the [sum dz, sum dz*xhat] vectors of the group's
+            units (a CSP layer's short + main convs) are exchanged as ONE grouped collective."""
+            for u in group:
+                st, C_ = self.ustate[u.name], u.cout
+                if not st.fused_red:
+                    aff, dA = st.aff.data_ptr(), u.dst
+                    e0 = self._t0()
+                    chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
+                                                      aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
+                                                      st.bpart.data_ptr(), st.M, C_, s), u.name)
+                    self._t1(e0, "bn_bwd_reduce", 4.0 * st.M * C_)
+            e0 = self._t0()
+            if sync:
+                for u in group:
+                    st = self.ustate[u.name]
+                    chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), u.cout, st.T2, s), u.name)
+                # out of place: the local sums stay for dgamma / dbeta
+                self._allreduce_group([self.ustate[u.name].bsums for u in group], [self.ustate[u.name].bsums_g for u in group])
+            for u in group:
+                st, C_ = self.ustate[u.name], u.cout
+                aff = st.aff.data_ptr()
+                rawm = 1 if st.fused_red else 0        # partials came from the last dgrad into this tensor
+                if sync:
+                    chk(lib.kodhip_bn_bwd_coeffs(st.bsums.data_ptr(), st.bsums_g.data_ptr(),
+                                                 float(st.M) * self.world_size, pa + 4 * st.g_off,
+                                                 aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off, gp + 4 * st.b_off,
+                                                 st.coef.data_ptr(), C_, rawm, s), u.name)
+                else:
+                    chk(lib.kodhip_bn_bwd_coeffs_partials(st.bpart.data_ptr(), st.T2, float(st.M), pa + 4 * st.g_off,
+                                                          aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off,
+                                                          gp + 4 * st.b_off, st.coef.data_ptr(), C_, rawm, s), u.name)
+            self._t1(e0, "bn_bwd_coeffs", sum(8.0 * u.cout * self.ustate[u.name].T2 for u in group))
+
+        rops = list(reversed(self.g.ops))
+        ri = 0
+        while ri < len(rops):
+            op = rops[ri]
+            ri += 1
             if op.kind == "head":
                 head_i -= 1
                 hu: HeadUnit = op.unit
@@ -619,86 +721,70 @@ class Engine:
                                             self.pool_idx[pool_i].data_ptr(), self._ptr(op.src, True),
                                             op.src.buf.C, op.src.coff, B, h, w, op.src.C, s), "maxpool_bwd")
             else:
-                u: ConvUnit = op.unit
-                st = self.ustate[u.name]
-                C_ = u.cout
-                aff = st.aff.data_ptr()
-                dA = u.dst
-                rawm = 1 if st.fused_red else 0        # partials came from the last dgrad into this tensor
-                if not st.fused_red:
-                    e0 = self._t0()
-                    chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
-                                                      aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
-                                                      st.bpart.data_ptr(), st.M, C_, s), u.name)
-                    self._t1(e0, "bn_bwd_reduce", 4.0 * st.M * C_)
-                e0 = self._t0()
-                if self.sync_bn and self.collectives:
-                    chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), C_, st.T2, s), u.name)
-                    if self.comm is not None:             # out of place: the local sums stay for dgamma / dbeta
-                        self.comm.all_reduce_to(st.bsums, st.bsums_g)
-                    else:
-                        st.bsums_g.copy_(st.bsums)
-                        self._allreduce(st.bsums_g)
-                    chk(lib.kodhip_bn_bwd_coeffs(st.bsums.data_ptr(), st.bsums_g.data_ptr(),
-                                                 float(st.M) * self.world_size, pa + 4 * st.g_off,
-                                                 aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off, gp + 4 * st.b_off,
-                                                 st.coef.data_ptr(), C_, rawm, s), u.name)
-                else:
-                    chk(lib.kodhip_bn_bwd_coeffs_partials(st.bpart.data_ptr(), st.T2, float(st.M), pa + 4 * st.g_off,
-                                                          aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off,
-                                                          gp + 4 * st.b_off, st.coef.data_ptr(), C_, rawm, s), u.name)
-                self._t1(e0, "bn_bwd_coeffs", 8.0 * C_ * st.T2)
-                res = u.residual
-                racc = acc_flag(res) if res else 0
-                e0 = self._t0()
-                chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
-                                                 aff, aff + 4 * C_, st.coef.data_ptr(),
-                                                 self._ptr(res, True) if res else None,
-                                                 res.buf.C if res else 0, res.coff if res else 0,
-                                                 racc, st.M, C_, s), u.name)
-                self._t1(e0, "bn_silu_bwd_apply", (6.0 + ((4.0 if racc else 2.0) if res else 0.0)) * st.M * C_)
-                # st.raw now holds dY
-                if u.stem:
-                    geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1)
-                else:
-                    geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p)
-                    fz = () if st.segs is None else (C.cast(st.segs, C.c_void_p), len(st.segs), st.seg_slots)
-                    acc_src = acc_flag(u.src)
-                    in_px = B * st.H * st.W
-                    # dY read once, dX written once (+ read when accumulating), + the re-read of the producers' pre-BN
-                    # tensors when this launch carries their BatchNorm-backward reduction
-                    nb = 2.0 * st.M * C_ + (4.0 if acc_src else 2.0) * in_px * u.cin
-                    if st.segs is not None:
-                        nb += 2.0 * in_px * sum(sg.ch_count for sg in st.segs)
-                    e0 = self._t0()
-                    if u.k == 3 and u.s == 2 and u.p == 1:
-                        fn = lib.kodhip_conv_dgrad_s2 if st.segs is None else lib.kodhip_conv_dgrad_s2_bnred
-                        chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
-                               B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,
-                               acc_src, *fz, s), u.name + ".dgrad")
-                    else:
-                        fn = lib.kodhip_conv_dgrad if st.segs is None else lib.kodhip_conv_dgrad_bnred
-                        chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
-                               *geo, st.Kdp, C_, 0, acc_src, *fz, s), u.name + ".dgrad")
-                    self._t1(e0, "dgrad" if st.segs is None else "dgrad+bn_reduce", nb)
-                cin_true = 3 if u.stem else u.cin
-                in_px_w = B * H * W if u.stem else B * st.H * st.W
-                timed_wgrad(u.name, 2.0 * (in_px_w * cin_true + st.M * C_),
-                            self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
-                            *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0)
+                group = [op.unit]
+                # SyncBN: short_conv (reached first in reverse order) and its main_conv share one exchange - main's
+                # output gradient is complete by now (everything between them in the forward program ran backward)
+                if sync and ri < len(rops) and rops[ri].kind == "conv" and rops[ri].unit.sibling is op.unit:
+                    group.append(rops[ri].unit)
+                    ri += 1
+                bn_bwd_stats(group)
+                for u in group:
+                    self._bwd_unit(u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad)
+                    bucket_tick()
+                continue
             # gradient buckets complete from the arena's end toward its start
-            if op.kind in ("conv", "head"):
-                unit_i -= 1
-                if unit_i in buckets:
-                    lo, hi = buckets[unit_i]
-                    cs = self._comm_stream()
-                    # overlapped buckets use their own communicator: SyncBN sums (main stream) and buckets (side stream)
-                    # never interleave on one communicator from two streams
-                    bc = self.comm_buckets if (cs is not None and self.comm_buckets is not None) else self.comm
-                    self._pending.append(launch_bucket(ga, lo, hi, self.process_group, cs, bc, also_after=wg))
+            if op.kind == "head":
+                bucket_tick()
         if wg is not None:
             main.wait_stream(wg)
         self._publish_grads()
+
+    def _bwd_unit(self, u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad):
+        """bn/silu backward apply -> data gradient -> weight gradient of one conv unit (coefficients already in st.coef)."""
+        lib, chk = self.lib, _lib.check
+        st = self.ustate[u.name]
+        C_ = u.cout
+        aff = st.aff.data_ptr()
+        dA = u.dst
+        res = u.residual
+        racc = acc_flag(res) if res else 0
+        e0 = self._t0()
+        chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
+                                         aff, aff + 4 * C_, st.coef.data_ptr(),
+                                         self._ptr(res, True) if res else None,
+                                         res.buf.C if res else 0, res.coff if res else 0,
+                                         racc, st.M, C_, s), u.name)
+        self._t1(e0, "bn_silu_bwd_apply", (6.0 + ((4.0 if racc else 2.0) if res else 0.0)) * st.M * C_)
+        # st.raw now holds dY
+        if u.stem:
+            geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1)
+        else:
+            geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p)
+            fz = () if st.segs is None else (C.cast(st.segs, C.c_void_p), len(st.segs), st.seg_slots)
+            acc_src = acc_flag(u.src)
+            in_px = B * st.H * st.W
+            # dY read once, dX written once (+ read when accumulating), + the re-read of the producers' pre-BN
+            # tensors when this launch carries their BatchNorm-backward reduction
+            nb = 2.0 * st.M * C_ + (4.0 if acc_src else 2.0) * in_px * u.cin
+            if st.segs is not None:
+                nb += 2.0 * in_px * sum(sg.ch_count for sg in st.segs)
+            e0 = self._t0()
+            if u.k == 3 and u.s == 2 and u.p == 1:
+                fn = lib.kodhip_conv_dgrad_s2 if st.segs is None else lib.kodhip_conv_dgrad_s2_bnred
+                chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
+                       B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,
+                       acc_src, *fz, s), u.name + ".dgrad")
+            else:
+                fn = lib.kodhip_conv_dgrad if st.segs is None else lib.kodhip_conv_dgrad_bnred
+                chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
+                       *geo, st.Kdp, C_, 0, acc_src, *fz, s), u.name + ".dgrad")
+            self._t1(e0, "dgrad" if st.segs is None else "dgrad+bn_reduce", nb)
+        cin_true = 3 if u.stem else u.cin
+        in_px_w = B * H * W if u.stem else B * st.H * st.W
+        timed_wgrad(u.name, 2.0 * (in_px_w * cin_true + st.M * C_),
+                    self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
+                    *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0)
+
 
     def _comm_stream(self):
         """Side stream of the gradient-bucket all-reduces, or None: by default every collective of the step (SyncBN

@@ -60,6 +60,7 @@ class ConvUnit:
     dst: Optional[View] = None
     residual: Optional[View] = None
     stem: bool = False
+    sibling: Optional["ConvUnit"] = None      # CSP main_conv -> its short_conv: same input, executed back to back
 
 
 @dataclass
@@ -111,8 +112,9 @@ class _Builder:
         self.g.ops.append(Op("conv", u, src, dst))
 
     def csp(self, name, src: View, dst: View, cin, cout, n, identity):
-        """CSPLayer (csp.py:66-111): registration order short, main, last, blocks; exec order main, blocks,
-        short, last.  cat([main_branch, short]) is the buffer `cat`."""
+        """CSPLayer (csp.py:66-111): registration order short, main, last, blocks; exec order main, short, blocks,
+        last (main and short read the same input and are independent: back to back, their SyncBN statistic
+        exchanges travel as one grouped collective).  cat([main_branch, short]) is the buffer `cat`."""
         stride = src.stride
         mid = int(cout * 0.5)
         short = self.unit(f"{name}.short_conv", cin, mid)
@@ -123,13 +125,14 @@ class _Builder:
         cat = self.buf(f"{name}.cat", stride, 2 * mid)
         cur = self.full(self.buf(f"{name}.m0", stride, mid))
         self.run(main, src, cur)
+        self.run(short, src, View(cat, mid, mid))
+        main.sibling = short
         for j, (c1, c2) in enumerate(blocks):
             hid = self.full(self.buf(f"{name}.b{j}.h", stride, mid))
             self.run(c1, cur, hid)
             out = View(cat, 0, mid) if j == n - 1 else self.full(self.buf(f"{name}.m{j + 1}", stride, mid))
             self.run(c2, hid, out, residual=cur if identity else None)
             cur = out
-        self.run(short, src, View(cat, mid, mid))
         self.run(last, self.full(cat), dst)
 
 

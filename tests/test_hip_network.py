@@ -98,6 +98,32 @@ def test_train_step_vs_oracle(case):
     assert all(int(sd_h[k]) == int(sd_r[k]) == 1 for k in sd_r if k.endswith("num_batches_tracked"))
 
 
+def test_train_step_yv5m_640_vs_oracle():
+    """BASELINE configs[4] scale (widen .75, deepen .67: 48 / 96 / 192 / 384 / 768 channels, 88 convs, 20.9 M parameters) at
+    640 px, B=2, end to end against the fp32 oracle: the 48-channel layers run on the LDS-DMA path through the padded-tap
+    K axis (k = tap * round_up(Cin, 32) + ci).  Same bars as the yv5s B=2 case."""
+    widen, deepen, nc, B, size, seed = 0.75, 0.67, 10, 2, 640, 31
+    torch.manual_seed(seed)
+    ref = OracleYolov5(3, nc, widen, deepen).train()
+    torch.manual_seed(seed)
+    net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen)
+    assert sum(p.numel() for p in net.parameters()) == 20907687
+    for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+        assert torch.equal(a, b), k
+    net = net.cuda().train()
+    x, tg = synth.batch(B, size, nc, seed)
+    lr = D.yolo_loss(size, size, ref(x), [D.Target(b, l) for b, l in tg])
+    tot = D.train_step_total(lr, B)
+    tot.backward()
+    gn_r = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ref.parameters())).item()
+    _, lr_h, tot_h = _step(net, x.cuda(), tg, size, B)
+    got = np.array([lr_h.localization.item(), lr_h.objectness.item(), lr_h.classification.item(), tot_h.item()])
+    want = np.array([lr.localization.item(), lr.objectness.item(), lr.classification.item(), tot.item()])
+    np.testing.assert_allclose(got, want, rtol=1e-2)
+    gn_h = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())).item()
+    assert abs(gn_h - gn_r) <= 1e-1 * gn_r, (gn_h, gn_r)
+
+
 def test_train_step_well_conditioned_batch():
     """B=16 at 640 px: BatchNorm statistics are well conditioned (>= 6400 samples per channel in the deepest layers).
     Bars: losses <= 1e-2 and global gradient norm <= 5e-2 against the fp32 oracle (pinned to the reference).
