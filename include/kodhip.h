@@ -83,6 +83,17 @@ int kodhip_conv_dgrad_s2_bnred(const void* dy, const void* w_dgrad_s2, void* dx,
                                int B, int H, int W, int ldx, int xcoff, int Cin, int N,
                                int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
                                kodStream_t stream);
+/* dX of TWO pointwise (1x1/s1/p0) convs that read the same tensor - a CSP layer's main_conv and short_conv
+ * (kod/nn/layers/csp.py:96-111) - as one launch over the concatenated reduction: dx is written once instead of written
+ * and then accumulated into by a second launch.  dy1 / dy2: [B*H*W][ldy] (+ycoff, N channels each), w1 / w2: their
+ * dgrad packs [Cin][Kp], Kp = round_up(N, 32). */
+int kodhip_conv_dgrad_dual(const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
+                           int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
+                           int accumulate, kodStream_t stream);
+int kodhip_conv_dgrad_dual_bnred_slots(int B, int H, int W, int Cin, int N, int ldy);
+int kodhip_conv_dgrad_dual_bnred(const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
+                                 int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
+                                 int accumulate, const void* segments, int nseg, int slots, kodStream_t stream);
 int kodhip_conv_wgrad_splits(long M, int N, int Kp);
 int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* grad,
                       int B, int H, int W, int ldx, int xcoff, int Cin,

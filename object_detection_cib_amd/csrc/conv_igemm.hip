@@ -57,6 +57,13 @@ struct ConvArgs {
   int tiles_m, tiles_n, groups_m, stats_slots;
   float rcp_hwo, rcp_wo;       // reciprocals for the row -> (b, oy, ox) decomposition (m < 2^24: one fix-up step)
   uint32_t x_bytes, w_bytes;   // FAST path: byte extents of the gather source / weight pack (buffer descriptors)
+  // dual-source pointwise gather (FAST, 1x1): K = [channels of x through w | channels of x2 through w2], both sources
+  // with the geometry of x (same ld / channel offset / channel count / Kp).  The data gradients of two convs that read
+  // the same tensor (a CSP layer's main and short convs) become ONE launch that writes dX once: no second launch, no
+  // read-modify-write accumulation pass over dX.  nk1 = K steps taken from the first source (0 = single source).
+  const bf16_t* x2;
+  const bf16_t* w2;
+  int nk1;
   int wide_px;                 // FAST path: a tap reads Cin = wide_px * ldx channels = wide_px consecutive pixels (stem)
   // MODE_PLAIN_BN (stats_slots = slot capacity of every seg_part buffer)
   int nseg, slot_base, slot_used;
@@ -132,14 +139,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
   float bn_run = 0.f;                        // MODE_PLAIN_BN: running sum of (channel tid>>1, statistic tid&1)
 
-  const int nk = a.Kp / BK;
+  const int nk = a.nk1 ? 2 * a.nk1 : a.Kp / BK;
   // FAST path (Cin % 32 == 0, unit tap stride, no K tail): operands come through raw buffer loads - the tap of a
   // K step is wave-uniform (scalar registers), invalid (padding) elements are fetched from an out-of-range offset
   // that the buffer unit returns as zeros, so a step costs ~10 VALU instead of ~110 and has no branches.
-  __amdgpu_buffer_rsrc_t rs_x, rs_w;
+  __amdgpu_buffer_rsrc_t rs_x, rs_w, rs_x2, rs_w2;
   if constexpr (FAST) {
     rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+    rs_x2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.nk1 ? a.x2 : a.x), 0, a.x_bytes, 0x00020000);
+    rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.nk1 ? a.w2 : a.w), 0, a.w_bytes, 0x00020000);
   }
 
   for (int mt = gm; mt < a.tiles_m; mt += a.groups_m) {
@@ -223,19 +232,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       const uint32_t soff = (uint32_t)((a.tap_sign * (f_kh * a.Ws + f_kw) * a.ldx + f_ci) * 2);
       char* As = reinterpret_cast<char*>(lds + buf * STAGE_ELEMS);
       char* Bs = As + BM * LDS_ROW * 2;
+      // dual-source pointwise gather: K steps nk1 .. 2*nk1-1 come from the second source / weight pack
+      const bool second = a.nk1 != 0 && kt >= a.nk1;
+      const int kw_step = second ? kt - a.nk1 : kt;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(KOD_ABL_NODMA)   // (the host pass only needs the kernel's stub)
+      const __amdgpu_buffer_rsrc_t rx = second ? rs_x2 : rs_x, rw = second ? rs_w2 : rs_w;
 #pragma unroll
       for (int i = 0; i < A_PER_WAVE; ++i) {
         uint32_t vo = ((dmask[i] >> f_tap) & 1u) ? dvoff[i] + soff : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(As + (uwave * A_PER_WAVE + i) * 16 * 64),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(As + (uwave * A_PER_WAVE + i) * 16 * 64),
                                                  16, vo, 0, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < B_PER_WAVE; ++q) {
         int blk = uwave * B_PER_WAVE + q;
         if (blk < B_INSTR)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Bs + blk * 16 * 64),
-                                                   16, dbvoff[q], kt * (BK * 2), 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(Bs + blk * 16 * 64),
+                                                   16, dbvoff[q], kw_step * (BK * 2), 0, 0);
       }
 #else
       (void)soff; (void)As; (void)Bs; (void)kt;
@@ -244,6 +257,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       if (f_ci >= a.cin_step) {
         f_ci = 0; ++f_tap;
         if (++f_kw == a.KW) { f_kw = 0; ++f_kh; }
+        if (a.nk1 != 0) f_tap = f_kh = f_kw = 0;      // dual source: one tap, the channel counter restarts on the second source
       }
     };
 
@@ -651,7 +665,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   const bool fast = fast_eligible(a);
   KOD_CHECK_ARG(fast || a.wide_px == 1, "conv: wide-pixel taps need the FAST path");
   args.x_bytes = (uint32_t)xb; args.w_bytes = (uint32_t)wb;
-  const Plan p = make_plan(a.M, a.N, a.K, fast);
+  const Plan p = make_plan(a.M, a.N, a.nk1 ? 2 * a.K : a.K, fast);
   args.tiles_n = p.tiles_n; args.tiles_m = p.tiles_m; args.groups_m = p.groups_m;
   if (MODE == MODE_RAW) {
     KOD_CHECK_ARG(a.stats_slots >= p.groups_m, "conv: stats buffer has %d slots, launch needs %d", a.stats_slots, p.groups_m);
@@ -906,6 +920,47 @@ int kodhip_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* dx,
                             hipStream_t stream) {
   ConvArgs a;
   if (int rc = prep_dgrad(a, dy, w_dgrad, dx, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, accumulate)) return rc;
+  if (int rc = set_segments(a, (const BnRedSeg*)segments, nseg, slots, Cin)) return rc;
+  return launch<MODE_PLAIN_BN>(a, stream);
+}
+
+// ---- data gradient of TWO pointwise convs that read the same tensor (a CSP layer's main_conv and short_conv,
+// kod/nn/layers/csp.py:96-111): dx = conv_transpose(dy1, w1) + conv_transpose(dy2, w2) as one launch over the
+// concatenated reduction [dy1 channels | dy2 channels] - dx is written once instead of written and then
+// read-modified-written by a second launch.  1x1 / stride 1 / no padding; dy1, dy2: [B*H*W][ldy] (+ycoff, N channels
+// each); w1, w2: [Cin][Kp] dgrad packs (Kp = round_up(N, 32)).  *_bnred: also the BatchNorm-backward reduction of the
+// units whose output gradient dx completes (see kodhip_conv_dgrad_bnred).
+static int prep_dgrad_dual(ConvArgs& a, const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
+                           int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff, int accumulate) {
+  if (int rc = prep_dgrad(a, dy1, w1, dx, B, H, W, ldx, xcoff, Cin, N, 1, 1, 1, 1, 0, 0, Kp, ldy, ycoff, accumulate)) return rc;
+  KOD_CHECK_ARG(dy2 && w2, "conv_dgrad_dual: null second source");
+  KOD_CHECK_ARG(fast_eligible(a), "conv_dgrad_dual: needs the LDS-DMA path (operands within a 32-bit buffer range)");
+  a.x2 = (const bf16_t*)dy2; a.w2 = (const bf16_t*)w2; a.nk1 = Kp / 32;
+  return KOD_OK;
+}
+
+int kodhip_conv_dgrad_dual(const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
+                           int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
+                           int accumulate, hipStream_t stream) {
+  ConvArgs a;
+  if (int rc = prep_dgrad_dual(a, dy1, w1, dy2, w2, dx, B, H, W, ldx, xcoff, Cin, N, Kp, ldy, ycoff, accumulate)) return rc;
+  return launch<MODE_PLAIN>(a, stream);
+}
+
+int kodhip_conv_dgrad_dual_bnred_slots(int B, int H, int W, int Cin, int N, int ldy) {
+  const void* fake = (const void*)64;
+  if (getenv("KODHIP_NO_BNRED")) return 0;
+  ConvArgs a;
+  const int Kp = (N + 31) / 32 * 32;
+  if (prep_dgrad_dual(a, fake, fake, fake, fake, (void*)fake, B, H, W, Cin, 0, Cin, N, Kp, ldy, 0, 0)) return 0;
+  return make_plan(a.M, a.N, 2 * a.K, true).groups_m;
+}
+
+int kodhip_conv_dgrad_dual_bnred(const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
+                                 int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
+                                 int accumulate, const void* segments, int nseg, int slots, hipStream_t stream) {
+  ConvArgs a;
+  if (int rc = prep_dgrad_dual(a, dy1, w1, dy2, w2, dx, B, H, W, ldx, xcoff, Cin, N, Kp, ldy, ycoff, accumulate)) return rc;
   if (int rc = set_segments(a, (const BnRedSeg*)segments, nseg, slots, Cin)) return rc;
   return launch<MODE_PLAIN_BN>(a, stream);
 }

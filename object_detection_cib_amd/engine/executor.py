@@ -325,6 +325,16 @@ class Engine:
         for u in self.exec_units:
             st = self.ustate[u.name]
             st.fused_red, st.segs, st.seg_slots = False, None, 0
+        # dual data gradients: a CSP layer's main_conv and short_conv (both pointwise, same input) write dX in ONE launch
+        self._dual = {}                # main unit name -> its short_conv unit
+        if os.environ.get("KODHIP_NO_DUAL") != "1":
+            for u in self.exec_units:
+                v = u.sibling
+                if (v is not None and u.k == v.k == 1 and u.s == v.s == 1 and u.p == v.p == 0 and u.cout == v.cout
+                        and (u.src.buf.name, u.src.coff, u.src.C) == (v.src.buf.name, v.src.coff, v.src.C)
+                        and u.cout % 8 == 0):
+                    self._dual[u.name] = v
+        dual_shorts = {v.name for v in self._dual.values()}
         if os.environ.get("KODHIP_NO_BNRED") == "1":
             return
         writes, upos, pos = [], {}, 0      # (position, writer unit name | None, buffer, lo, hi)
@@ -337,7 +347,7 @@ class Engine:
                     r = u.residual
                     writes.append((pos, None, r.buf.name, r.coff, r.coff + r.C))
                     pos += 1
-                if not u.stem:
+                if not u.stem and u.name not in dual_shorts:       # (a fused short_conv's dX is written by its main_conv's launch)
                     writes.append((pos, u.name, u.src.buf.name, u.src.coff, u.src.coff + u.src.C))
                     pos += 1
             else:
@@ -361,7 +371,10 @@ class Engine:
             # (A/B knob: only fuse into launches whose reduction length is at least KODHIP_BNRED_MINK; measured best: all)
             if w.k * w.k * w.cout < int(os.environ.get("KODHIP_BNRED_MINK", "0")):
                 continue
-            slots = lib.kodhip_conv_dgrad_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.k, w.k, w.s, w.s, w.p, w.p, w.cout, s2)
+            if wname in self._dual:
+                slots = lib.kodhip_conv_dgrad_dual_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.cout)
+            else:
+                slots = lib.kodhip_conv_dgrad_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.k, w.k, w.s, w.s, w.p, w.p, w.cout, s2)
             if slots <= 0:
                 continue
             prods = prods[:3]                        # MAX_SEG of the kernel
@@ -724,12 +737,16 @@ class Engine:
                 group = [op.unit]
                 # SyncBN: short_conv (reached first in reverse order) and its main_conv share one exchange - main's
                 # output gradient is complete by now (everything between them in the forward program ran backward)
-                if sync and ri < len(rops) and rops[ri].kind == "conv" and rops[ri].unit.sibling is op.unit:
+                if ri < len(rops) and rops[ri].kind == "conv" and rops[ri].unit.sibling is op.unit and \
+                        (sync or rops[ri].unit.name in self._dual):
                     group.append(rops[ri].unit)
                     ri += 1
                 bn_bwd_stats(group)
+                dual = len(group) == 2 and group[1].name in self._dual          # [short, main]: one data-gradient launch
                 for u in group:
-                    self._bwd_unit(u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad)
+                    self._bwd_unit(u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad,
+                                   dgrad="skip" if (dual and u is group[0]) else ("dual" if dual else "own"),
+                                   partner=group[0] if dual else None)
                     bucket_tick()
                 continue
             # gradient buckets complete from the arena's end toward its start
@@ -739,8 +756,10 @@ class Engine:
             main.wait_stream(wg)
         self._publish_grads()
 
-    def _bwd_unit(self, u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad):
-        """bn/silu backward apply -> data gradient -> weight gradient of one conv unit (coefficients already in st.coef)."""
+    def _bwd_unit(self, u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad, dgrad="own", partner=None):
+        """bn/silu backward apply -> data gradient -> weight gradient of one conv unit (coefficients already in st.coef).
+        dgrad: "own" = this unit's launch; "skip" = none (a fused short_conv: its main_conv's launch covers it);
+        "dual" = one launch for this unit and `partner` (kodhip_conv_dgrad_dual)."""
         lib, chk = self.lib, _lib.check
         st = self.ustate[u.name]
         C_ = u.cout
@@ -761,6 +780,11 @@ class Engine:
         else:
             geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p)
             fz = () if st.segs is None else (C.cast(st.segs, C.c_void_p), len(st.segs), st.seg_slots)
+            if dgrad == "skip":
+                timed_wgrad(u.name, 2.0 * (B * st.H * st.W * u.cin + st.M * C_),
+                            self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
+                            *geo, st.Kp, C_, 0, C_, 0, 1.0)
+                return
             acc_src = acc_flag(u.src)
             in_px = B * st.H * st.W
             # dY read once, dX written once (+ read when accumulating), + the re-read of the producers' pre-BN
@@ -769,7 +793,13 @@ class Engine:
             if st.segs is not None:
                 nb += 2.0 * in_px * sum(sg.ch_count for sg in st.segs)
             e0 = self._t0()
-            if u.k == 3 and u.s == 2 and u.p == 1:
+            if dgrad == "dual":
+                ps = self.ustate[partner.name]
+                nb += 2.0 * ps.M * partner.cout
+                fn = lib.kodhip_conv_dgrad_dual if st.segs is None else lib.kodhip_conv_dgrad_dual_bnred
+                chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, ps.raw.data_ptr(), dp + 2 * ps.d_off, self._ptr(u.src, True),
+                       B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, st.Kdp, C_, 0, acc_src, *fz, s), u.name + ".dgrad2")
+            elif u.k == 3 and u.s == 2 and u.p == 1:
                 fn = lib.kodhip_conv_dgrad_s2 if st.segs is None else lib.kodhip_conv_dgrad_s2_bnred
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
                        B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,

@@ -398,3 +398,78 @@ def test_conv_dgrad_with_fused_bn_backward_reduction(case):
         for got, want, what in zip(out_f, out_s, ("dgamma", "dbeta", "coef")):
             assert torch.isfinite(got).all(), what
             _close(got.cpu(), want.cpu(), 2e-4, 2e-4 * want.abs().max().item(), what)
+
+
+@pytest.mark.parametrize("case", [
+    # B, Cin (dX channels), H, W, N (dY channels of EACH of the two convolutions), ld of dX, coff, producer split
+    (2, 64, 24, 20, 32, 64, 0, None),
+    (3, 128, 20, 12, 64, 192, 64, (64, 64)),       # dX is a channel slice of a concat buffer + fused BN-backward reduction
+    (2, 96, 14, 10, 48, 96, 0, (96,)),             # 48 dY channels: the K axis of each source is padded to 64
+    (4, 256, 40, 40, 128, 256, 0, None),           # 6400 rows: 256-pixel tiles
+])
+def test_conv_dgrad_dual_source(case):
+    """kodhip_conv_dgrad_dual[_bnred]: dX = dgrad(dY1, W1) + dgrad(dY2, W2) of two pointwise convolutions that read the
+    same input (a CSP layer's main_conv / short_conv) in ONE launch; equals the two separate launches' sum and torch."""
+    from object_detection_cib_amd._lib import KodBnRedSeg
+    import ctypes as C
+    B, Cin, H, W, N, ld, coff, split = case
+    g = torch.Generator().manual_seed(sum(case[:7]))
+    x = bf(torch.randn(B, Cin, H, W, generator=g)).requires_grad_(True)
+    ws = [bf(torch.randn(N, Cin, 1, 1, generator=g) / Cin ** 0.5) for _ in range(2)]
+    dys = [bf(torch.randn(B, N, H, W, generator=g)) for _ in range(2)]
+    for w, dy in zip(ws, dys):
+        F.conv2d(x, w).backward(dy)
+    lib = _lib.lib()
+    pks = [pack([w]) for w in ws]
+    dyb = [nhwc(dy) for dy in dys]
+    M = B * H * W
+    for acc in (0, 1):
+        dxb = torch.full((B, H, W, ld), 0.5, dtype=torch.bfloat16, device="cuda")
+        if split is None:
+            _lib.check(lib.kodhip_conv_dgrad_dual(dyb[0].data_ptr(), pks[0]["d"].data_ptr(), dyb[1].data_ptr(),
+                                                  pks[1]["d"].data_ptr(), dxb.data_ptr(), B, H, W, ld, coff, Cin, N,
+                                                  pks[0]["Kdp"], N, 0, acc, stream()), "dgrad_dual")
+        else:
+            slots = lib.kodhip_conv_dgrad_dual_bnred_slots(B, H, W, Cin, N, N)
+            assert slots > 0
+            prods, ch0 = [], 0
+            for c in split:
+                raw = bf(torch.randn(B, c, H, W, generator=g))
+                aff = torch.cat([torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3,
+                                 torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5]).cuda()
+                prods.append(dict(c=c, ch0=ch0, raw=nhwc(raw), aff=aff,
+                                  part=torch.full((2 * c * slots,), float("nan"), device="cuda")))
+                ch0 += c
+            segs = (KodBnRedSeg * len(prods))()
+            for i, pr in enumerate(prods):
+                segs[i].ch_begin, segs[i].ch_count = pr["ch0"], pr["c"]
+                segs[i].raw, segs[i].ldr = pr["raw"].data_ptr(), pr["c"]
+                segs[i].aff, segs[i].partials = pr["aff"].data_ptr(), pr["part"].data_ptr()
+            _lib.check(lib.kodhip_conv_dgrad_dual_bnred(dyb[0].data_ptr(), pks[0]["d"].data_ptr(), dyb[1].data_ptr(),
+                                                        pks[1]["d"].data_ptr(), dxb.data_ptr(), B, H, W, ld, coff, Cin, N,
+                                                        pks[0]["Kdp"], N, 0, acc, C.cast(segs, C.c_void_p), len(prods),
+                                                        slots, stream()), "dgrad_dual_bnred")
+        got = nchw(dxb)
+        _close(got[:, coff:coff + Cin], x.grad + 0.5 * acc, 2e-2, 4e-2, f"dual dgrad acc={acc}")
+        rest = torch.cat([got[:, :coff], got[:, coff + Cin:]], 1)
+        assert (rest == 0.5).all(), "channels outside the view must stay untouched"
+        if split is not None:
+            # the fused reduction's coefficients == those of the separate reduce pass over the written dX
+            for pr in prods:
+                c, a = pr["c"], pr["aff"].data_ptr()
+                T2 = lib.kodhip_bn_bwd_slots(M, c)
+                bpart = torch.zeros(2 * c * T2, device="cuda")
+                _lib.check(lib.kodhip_bn_silu_bwd_reduce(dxb.data_ptr(), ld, coff + pr["ch0"], pr["raw"].data_ptr(), c, a,
+                                                         a + 4 * c, a + 8 * c, a + 12 * c, bpart.data_ptr(), M, c,
+                                                         stream()), "reduce")
+                gamma = torch.ones(c, device="cuda")
+                outs = []
+                for part, T, rawm in ((pr["part"], slots, 1), (bpart, T2, 0)):
+                    o = [torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(3 * c, device="cuda")]
+                    _lib.check(lib.kodhip_bn_bwd_coeffs_partials(part.data_ptr(), T, float(M), gamma.data_ptr(), a + 8 * c,
+                                                                 a + 12 * c, o[0].data_ptr(), o[1].data_ptr(),
+                                                                 o[2].data_ptr(), c, rawm, stream()), "coeffs")
+                    outs.append(o)
+                for got_, want_, what in zip(outs[0], outs[1], ("dgamma", "dbeta", "coef")):
+                    assert torch.isfinite(got_).all(), what
+                    _close(got_.cpu(), want_.cpu(), 2e-4, 2e-4 * want_.abs().max().item(), what)
