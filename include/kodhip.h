@@ -83,6 +83,19 @@ int kodhip_conv_dgrad_s2_bnred(const void* dy, const void* w_dgrad_s2, void* dx,
                                int B, int H, int W, int ldx, int xcoff, int Cin, int N,
                                int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
                                kodStream_t stream);
+/* The same data gradient "folded": one stride-1 gather over the 2x2 dY neighbourhood of each 2x2 output-pixel block,
+ * 4 parity classes x Cin output columns, depth-to-space epilogue (16 tap-class products instead of 9, but dY is staged
+ * once and both x parities of a pixel pair are stored together: faster for the shallow, staging-bound layers).
+ * w_fold: [4*Cin][4*round_up(N,32)] (pack mode 3).  kodhip_conv_dgrad_s2_folded: which form to pack / call (1 = folded). */
+int kodhip_conv_dgrad_s2_folded(int Cin, int N);
+int kodhip_conv_dgrad_s2f(const void* dy, const void* w_fold, void* dx,
+                          int B, int H, int W, int ldx, int xcoff, int Cin, int N,
+                          int ldy, int ycoff, int accumulate, kodStream_t stream);
+int kodhip_conv_dgrad_s2f_bnred_slots(int B, int H, int W, int Cin, int N, int ldy);
+int kodhip_conv_dgrad_s2f_bnred(const void* dy, const void* w_fold, void* dx,
+                                int B, int H, int W, int ldx, int xcoff, int Cin, int N,
+                                int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                                kodStream_t stream);
 /* dX of TWO pointwise (1x1/s1/p0) convs that read the same tensor - a CSP layer's main_conv and short_conv
  * (kod/nn/layers/csp.py:96-111) - as one launch over the concatenated reduction: dx is written once instead of written
  * and then accumulated into by a second launch.  dy1 / dy2: [B*H*W][ldy] (+ycoff, N channels each), w1 / w2: their

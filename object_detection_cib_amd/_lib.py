@@ -46,6 +46,10 @@ SIGNATURES = {
     "kodhip_conv_dgrad_bnred_slots": (i32, [i32] * 13),
     "kodhip_conv_dgrad_bnred": (i32, [vp, vp, vp] + [i32] * 17 + [vp, i32, i32, vp]),
     "kodhip_conv_dgrad_s2_bnred": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, i32, vp]),
+    "kodhip_conv_dgrad_s2_folded": (i32, [i32, i32]),
+    "kodhip_conv_dgrad_s2f": (i32, [vp, vp, vp] + [i32] * 10 + [vp]),
+    "kodhip_conv_dgrad_s2f_bnred_slots": (i32, [i32] * 6),
+    "kodhip_conv_dgrad_s2f_bnred": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, i32, vp]),
     "kodhip_conv_dgrad_dual": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),
     "kodhip_conv_dgrad_dual_bnred_slots": (i32, [i32] * 6),
     "kodhip_conv_dgrad_dual_bnred": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp, i32, i32, vp]),

@@ -52,6 +52,8 @@ struct ConvArgs {
   int mul_h, mul_w, add_h, add_w, tap_sign, sh_shift, sw_shift;
   int ldy, ycoff, accumulate;
   int out_mul, out_off_y, out_off_x, out_H, out_W;   // PLAIN: output pixel (oy,ox) -> (oy*mul+off_y, ox*mul+off_x) of an out_H x out_W image
+  int d2s_C;                   // PLAIN, folded stride-2 data gradient: output column n = class * d2s_C + channel, class (py,px)
+                               // = (n / d2s_C) >> 1, & 1 is the pixel's parity offset (depth-to-space epilogue); 0 = off
   int head_A, head_P, head_nc;
   uint32_t magic_cin, magic_kw;
   int tiles_m, tiles_n, groups_m, stats_slots;
@@ -448,6 +450,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       const int c = tid % CPR;
       const int r0 = tid / CPR;
       const int n = n0 + c * 8;
+      // folded stride-2 data gradient: this thread's 8 columns are 8 channels of ONE parity class (d2s_C % 8 == 0)
+      int nch = n, pix_off = a.out_off_y * a.out_W + a.out_off_x;
+      if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
+        if (a.d2s_C != 0) {
+          const int cls = n / a.d2s_C;
+          nch = n - cls * a.d2s_C; pix_off = (cls >> 1) * a.out_W + (cls & 1);
+        }
+      }
+      const bool col_ok = n < a.N;
       // MODE_PLAIN_BN: this thread's 8 channels belong to at most one segment (boundaries are multiples of 8)
       const bf16_t* sg_raw = nullptr;
       int sg_ldr = 0;
@@ -455,8 +466,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       if constexpr (MODE == MODE_PLAIN_BN) {
 #pragma unroll
         for (int sgi = 0; sgi < MAX_SEG; ++sgi)
-          if (sgi < a.nseg && n >= a.seg_begin[sgi] && n < a.seg_end[sgi]) {
-            const int cl = n - a.seg_begin[sgi];
+          if (sgi < a.nseg && nch >= a.seg_begin[sgi] && nch < a.seg_end[sgi]) {
+            const int cl = nch - a.seg_begin[sgi];
             sg_raw = a.seg_raw[sgi] + cl;
             sg_ldr = a.seg_ldr[sgi];
 #pragma unroll
@@ -467,7 +478,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       for (int p = 0; p < BM / RPP; ++p) {
         int row = r0 + p * RPP;
         int m = m0 + row;
-        if (m < a.M && n < a.N) {
+        if (m < a.M && col_ok) {
           bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS_ROW + c * 8);
           size_t opix = (size_t)m;
           if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
@@ -476,10 +487,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
               int rem = m - b * HWo;
               int oy = rem / a.Wo;
               int ox = rem - oy * a.Wo;
-              opix = ((size_t)b * a.out_H + oy * a.out_mul + a.out_off_y) * a.out_W + ox * a.out_mul + a.out_off_x;
+              opix = ((size_t)b * a.out_H + oy * a.out_mul) * a.out_W + ox * a.out_mul + pix_off;
             }
           }
-          bf16_t* dst = a.y + opix * a.ldy + a.ycoff + n;
+          bf16_t* dst = a.y + opix * a.ldy + a.ycoff + nch;
           if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
             if (a.accumulate) {
               bf16x8 o = *reinterpret_cast<const bf16x8*>(dst);
@@ -548,13 +559,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   if constexpr (MODE == MODE_PLAIN_BN) {
     if (tid < BN * 2) {
       const int ch = tid >> 1, st = tid & 1;
-      const int nn = n0 + ch;
+      int nn = n0 + ch, sbase = a.slot_base;
+      if (a.d2s_C != 0) {       // folded stride-2 form: the four parity classes of a channel reduce into disjoint slot ranges
+        const int cls = nn / a.d2s_C;
+        nn -= cls * a.d2s_C; sbase = cls * a.groups_m;
+        if (cls > 3) nn = -1;
+      }
 #pragma unroll
       for (int sgi = 0; sgi < MAX_SEG; ++sgi)
         if (sgi < a.nseg && nn >= a.seg_begin[sgi] && nn < a.seg_end[sgi]) {
           float* slot = a.seg_part[sgi] + ((size_t)st * a.seg_C[sgi] + (nn - a.seg_begin[sgi])) * a.stats_slots;
-          slot[a.slot_base + gm] = bn_run;
-          for (int t = a.slot_base + gm + a.slot_used; t < a.stats_slots; t += a.slot_used) slot[t] = 0.f;
+          slot[sbase + gm] = bn_run;
+          for (int t = sbase + gm + a.slot_used; t < a.stats_slots; t += a.slot_used) slot[t] = 0.f;
         }
     }
   }
@@ -671,8 +687,9 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     KOD_CHECK_ARG(a.stats_slots >= p.groups_m, "conv: stats buffer has %d slots, launch needs %d", a.stats_slots, p.groups_m);
   }
   if (MODE == MODE_PLAIN_BN) {
-    KOD_CHECK_ARG(a.stats_slots >= p.groups_m, "conv: partial buffers have %d slots, launch needs %d", a.stats_slots, p.groups_m);
-    args.slot_base = 0; args.slot_used = p.groups_m;
+    const int need = (a.d2s_C ? 4 : 1) * p.groups_m;
+    KOD_CHECK_ARG(a.stats_slots >= need, "conv: partial buffers have %d slots, launch needs %d", a.stats_slots, need);
+    args.slot_base = 0; args.slot_used = need;
   }
   dim3 g(p.grid);
   if (fast) {
@@ -858,6 +875,27 @@ int prep_dgrad_s2(ConvArgs cls[4], bool& all_fast, const void* dy, const void* w
   return KOD_OK;
 }
 
+// the same data gradient "folded": ONE stride-1 gather over the 2x2 dY neighbourhood {i, i+1} x {j, j+1} of the output
+// pixel block (2i..2i+1, 2j..2j+1) with N = 4 classes x Cin columns (class (py,px) uses tap (dy,dx) iff py >= dy and
+// px >= dx; the other weights are zero) and a depth-to-space epilogue.  16 tap-class products instead of 9, but dY is
+// staged once instead of 9/4 times, the K loop is 4x round_up(N,32) long for every tile, and the epilogue writes
+// both x parities of a pixel pair: the shallow layers (Cin <= 64), which are bound by staging / pipeline fill and
+// half-line stores and not by the MFMA, run 2x faster this way.
+int prep_dgrad_s2f(ConvArgs& a, const void* dy, const void* w_fold, void* dx, int B, int H, int W,
+                   int ldx, int xcoff, int Cin, int N, int ldy, int ycoff, int accumulate) {
+  KOD_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "conv_dgrad_s2f: input dims must be even");
+  const int Ho = H / 2, Wo = W / 2;
+  const int Kp = 4 * ((N + 31) / 32 * 32);
+  a = ConvArgs{};
+  if (int rc = fill_common(a, dy, w_fold, B, Ho, Wo, ldy, ycoff, N, Ho, Wo, 4 * Cin, 2, 2, Kp)) return rc;
+  KOD_CHECK_ARG(dx && Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0 && xcoff + Cin <= ldx, "conv_dgrad_s2f: bad output slice");
+  a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff; a.accumulate = accumulate;
+  a.mul_h = 1; a.mul_w = 1; a.add_h = 0; a.add_w = 0; a.tap_sign = 1; a.sh_shift = 0; a.sw_shift = 0;
+  a.out_mul = 2; a.out_off_y = 0; a.out_off_x = 0; a.out_H = H; a.out_W = W; a.d2s_C = Cin;
+  KOD_CHECK_ARG(fast_eligible(a), "conv_dgrad_s2f: needs the LDS-DMA path (operands within a 32-bit buffer range)");
+  return KOD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -887,6 +925,44 @@ int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
   for (int c = 0; c < 4; ++c)
     if (int rc = launch<MODE_PLAIN>(cls[c], stream)) return rc;
   return KOD_OK;
+}
+
+// Which form the engine should pack and call for a 3x3 / stride 2 / pad 1 layer with Cin input and N output channels:
+// 1 = folded (kodhip_conv_dgrad_s2f, pack mode 3), 0 = parity classes (kodhip_conv_dgrad_s2, pack mode 2).
+// KODHIP_S2_FOLD_MAXC overrides the channel threshold (0 = never fold).
+int kodhip_conv_dgrad_s2_folded(int Cin, int N) {
+  static int maxc = -1;
+  if (maxc < 0) { const char* e = getenv("KODHIP_S2_FOLD_MAXC"); maxc = e ? atoi(e) : 64; }
+  (void)N;
+  return Cin <= maxc ? 1 : 0;
+}
+
+// Folded form of kodhip_conv_dgrad_s2 (see prep_dgrad_s2f).  w_fold: [4 * Cin][4 * round_up(N, 32)], row = class * Cin
+// + ci (class = 2 * py + px), k = (dy * 2 + dx) * round_up(N, 32) + n.
+int kodhip_conv_dgrad_s2f(const void* dy, const void* w_fold, void* dx,
+                          int B, int H, int W, int ldx, int xcoff, int Cin, int N,
+                          int ldy, int ycoff, int accumulate, hipStream_t stream) {
+  ConvArgs a;
+  if (int rc = prep_dgrad_s2f(a, dy, w_fold, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate)) return rc;
+  return launch<MODE_PLAIN>(a, stream);
+}
+
+int kodhip_conv_dgrad_s2f_bnred_slots(int B, int H, int W, int Cin, int N, int ldy) {
+  const void* fake = (const void*)64;
+  if (getenv("KODHIP_NO_BNRED")) return 0;
+  ConvArgs a;
+  if (prep_dgrad_s2f(a, fake, fake, (void*)fake, B, H, W, Cin, 0, Cin, N, ldy, 0, 0)) return 0;
+  return 4 * make_plan(a.M, a.N, a.K, true).groups_m;
+}
+
+int kodhip_conv_dgrad_s2f_bnred(const void* dy, const void* w_fold, void* dx,
+                                int B, int H, int W, int ldx, int xcoff, int Cin, int N,
+                                int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                                hipStream_t stream) {
+  ConvArgs a;
+  if (int rc = prep_dgrad_s2f(a, dy, w_fold, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate)) return rc;
+  if (int rc = set_segments(a, (const BnRedSeg*)segments, nseg, slots, Cin)) return rc;
+  return launch<MODE_PLAIN_BN>(a, stream);
 }
 
 // ---- data gradient + BatchNorm-backward reduction of the units whose output gradient this launch completes.

@@ -28,7 +28,8 @@ struct PackDesc {          // all int64 so the host can fill it as a plain int64
   long Kp, Kdp;            // padded row lengths of the two packs
   long Ntot, n_off;        // dgrad pack: channels per tap (padded total) and this weight's first channel
   long stem;               // 1: 6x6/s2 stem in pixel-pair form, k = kh*32 + kw'*8 + dx*4 + c (kw' = 0..2 of a 4-pair,
-                           //    32-value window: the 4th pair's weights stay zero); 2: 3x3/s2 parity-class dgrad packs
+                           //    32-value window: the 4th pair's weights stay zero); 2: 3x3/s2 parity-class dgrad packs;
+                           //    3: 3x3/s2 folded dgrad pack (kodhip_conv_dgrad_s2f)
   long blk_begin;          // first block of this descriptor in the grid
 };
 
@@ -77,6 +78,12 @@ __global__ void pack_weights_kernel(const float* master, bf16_t* fpack, bf16_t* 
         long KW = 1 + px;
         long Kc = (1 + py) * KW * ns;
         dpack[base + ci * Kc + (khp * KW + kwp) * ns + n] = v;
+      } else if (d.stem == 3) {
+        // 3x3 stride-2 layer, folded form: row = class * Cin + ci, k = (dy * 2 + dx) * ns + n over the 2x2 dY neighbourhood
+        long kh = tap / 3, kw = tap - kh * 3;
+        long cls = 2 * (kh != 1) + (kw != 1);
+        long t2 = 2 * (kh == 0) + (kw == 0);
+        dpack[d.d_off + (cls * d.Cin + ci) * (4 * ns) + t2 * ns + n] = v;
       } else {
         dpack[d.d_off + ci * d.Kdp + tap * ns + d.n_off + n] = v;
       }

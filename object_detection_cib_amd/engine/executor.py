@@ -32,7 +32,7 @@ def _pad(n: int, a: int = 64) -> int:
 class _UnitState:
     __slots__ = ("u", "w_off", "g_off", "b_off", "f_off", "d_off", "Kp", "Kdp", "rs_off", "stats", "T",
                  "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho", "Wo",
-                 "fused_red", "segs", "seg_slots", "Kp_f", "raw_ld")
+                 "fused_red", "segs", "seg_slots", "Kp_f", "raw_ld", "s2_fold")
 
 
 class Engine:
@@ -156,8 +156,9 @@ class Engine:
             st.f_off, st.d_off = foff, (-1 if u.stem else doff)
             foff += u.cout * st.Kp_f
             s2 = (not u.stem) and u.k == 3 and u.s == 2 and u.p == 1
-            if s2:
-                doff += u.cin * sum(nt * _pad(u.cout, 32) for nt in (1, 2, 2, 4))
+            st.s2_fold = bool(s2 and self.lib.kodhip_conv_dgrad_s2_folded(u.cin, u.cout))
+            if s2:       # parity-class packs (1 + 2 + 2 + 4 taps) or the folded pack (4 classes x 4 taps), csrc/conv_igemm.hip
+                doff += u.cin * (16 if st.s2_fold else 9) * _pad(u.cout, 32)
             elif not u.stem:
                 doff += u.cin * st.Kdp
             st.w_off = layout[u.name + ".0.weight"][0]
@@ -168,7 +169,7 @@ class Engine:
                 add_desc(u.name + ".0.weight", st.f_off, -1, u.cout, 3, 6, 6, st.Kp_f, 0, 0, 0, 1)
             else:
                 add_desc(u.name + ".0.weight", st.f_off, st.d_off, u.cout, u.cin, u.k, u.k, st.Kp_f, st.Kdp,
-                         u.cout, 0, 2 if s2 else 0)
+                         u.cout, 0, (3 if st.s2_fold else 2) if s2 else 0)
             self.ustate[u.name] = st
         self.hstate = {}
         self.head_npad = _pad(A * (5 + nc), 8)
@@ -374,7 +375,10 @@ class Engine:
             if wname in self._dual:
                 slots = lib.kodhip_conv_dgrad_dual_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.cout)
             else:
-                slots = lib.kodhip_conv_dgrad_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.k, w.k, w.s, w.s, w.p, w.p, w.cout, s2)
+                if s2 and ws.s2_fold:
+                    slots = lib.kodhip_conv_dgrad_s2f_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.cout)
+                else:
+                    slots = lib.kodhip_conv_dgrad_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.k, w.k, w.s, w.s, w.p, w.p, w.cout, s2)
             if slots <= 0:
                 continue
             prods = prods[:3]                        # MAX_SEG of the kernel
@@ -800,7 +804,10 @@ class Engine:
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, ps.raw.data_ptr(), dp + 2 * ps.d_off, self._ptr(u.src, True),
                        B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, st.Kdp, C_, 0, acc_src, *fz, s), u.name + ".dgrad2")
             elif u.k == 3 and u.s == 2 and u.p == 1:
-                fn = lib.kodhip_conv_dgrad_s2 if st.segs is None else lib.kodhip_conv_dgrad_s2_bnred
+                if st.s2_fold:
+                    fn = lib.kodhip_conv_dgrad_s2f if st.segs is None else lib.kodhip_conv_dgrad_s2f_bnred
+                else:
+                    fn = lib.kodhip_conv_dgrad_s2 if st.segs is None else lib.kodhip_conv_dgrad_s2_bnred
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
                        B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,
                        acc_src, *fz, s), u.name + ".dgrad")

@@ -40,12 +40,13 @@ def pack(weights, stem=False, ntot=None, s2=False):
     Kdp = KH * KW * pad(Ntot, 32)
     master = torch.cat([w.reshape(-1) for w in weights]).float().cuda()
     fpack = torch.zeros(Ntot * Kp, dtype=torch.bfloat16, device="cuda")
-    dsize = Cin * sum(nt * pad(N, 32) for nt in (1, 2, 2, 4)) if s2 else Cin * Kdp
+    # s2: True = the four parity-class packs, "fold" = the folded pack of kodhip_conv_dgrad_s2f
+    dsize = Cin * (16 if s2 == "fold" else 9) * pad(N, 32) if s2 else Cin * Kdp
     dpack = torch.zeros(max(dsize, 8), dtype=torch.bfloat16, device="cuda")
     descs, w_off, n_off, blk = [], 0, 0, 0
     for w in weights:
         n = w.shape[0]
-        descs.append([w_off, n_off * Kp, -1 if stem else 0, n, Cin, KH, KW, Kp, Kdp, Ntot, n_off, 1 if stem else (2 if s2 else 0), blk])
+        descs.append([w_off, n_off * Kp, -1 if stem else 0, n, Cin, KH, KW, Kp, Kdp, Ntot, n_off, 1 if stem else ((3 if s2 == "fold" else 2) if s2 else 0), blk])
         blk += (w.numel() + 255) // 256
         w_off += w.numel()
         n_off += n

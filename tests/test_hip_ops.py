@@ -83,9 +83,13 @@ def test_conv_fwd_dgrad_wgrad(case):
     _close(gw.cpu(), wr.grad, 2e-3, 2e-3 * wr.grad.abs().max().item(), "wgrad")
 
 
-@pytest.mark.parametrize("case", [(2, 32, 16, 16, 64), (1, 128, 10, 12, 128), (3, 48, 6, 8, 96), (1, 256, 4, 4, 512)])
-def test_conv_dgrad_stride2_parity_classes(case):
-    """3x3/s2/p1 data gradient through the 4 parity-class launches (+ accumulate form, channel slice)."""
+@pytest.mark.parametrize("form", ["classes", "folded"])
+@pytest.mark.parametrize("case", [(2, 32, 16, 16, 64), (1, 128, 10, 12, 128), (3, 48, 6, 8, 96), (1, 256, 4, 4, 512),
+                                  (4, 32, 96, 64, 64)])
+def test_conv_dgrad_stride2_parity_classes(case, form):
+    """3x3/s2/p1 data gradient through the 4 parity-class problems of one launch (kodhip_conv_dgrad_s2) and through the
+    folded form (kodhip_conv_dgrad_s2f: one 2x2-tap gather, 4 x Cin columns, depth-to-space epilogue)
+    (+ accumulate form, channel slice)."""
     B, Cin, H, W, Cout = case
     g = torch.Generator().manual_seed(sum(case))
     x = bf(torch.randn(B, Cin, H, W, generator=g)).requires_grad_(True)
@@ -94,15 +98,16 @@ def test_conv_dgrad_stride2_parity_classes(case):
     dy = bf(torch.randn(y.shape, generator=g))
     y.backward(dy)
     lib = _lib.lib()
-    pk = pack([w], s2=True)
+    pk = pack([w], s2=True if form == "classes" else "fold")
+    fn = lib.kodhip_conv_dgrad_s2 if form == "classes" else lib.kodhip_conv_dgrad_s2f
     dyb = nhwc(dy)
     ld = Cin + 16
     dxb = torch.zeros((B, H, W, ld), dtype=torch.bfloat16, device="cuda")
     for acc, mult in ((0, 1.0), (1, 2.0)):
-        _lib.check(lib.kodhip_conv_dgrad_s2(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, ld, 8, Cin,
-                                            Cout, Cout, 0, acc, stream()), "dgrad_s2")
+        _lib.check(fn(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, ld, 8, Cin,
+                      Cout, Cout, 0, acc, stream()), "dgrad_s2 " + form)
         got = nchw(dxb)
-        _close(got[:, 8:8 + Cin], mult * x.grad, 1e-2 * mult, 3e-2 * mult, "dgrad s2")
+        _close(got[:, 8:8 + Cin], mult * x.grad, 1e-2 * mult, 3e-2 * mult, "dgrad s2 " + form)
         assert (got[:, :8] == 0).all() and (got[:, 8 + Cin:] == 0).all()
 
 
@@ -333,6 +338,8 @@ def test_sgd_nesterov():
     (2, 128, 16, 12, 32, 1, 1, 0, (64, 64)),        # concat buffer: two producers, short reduction
     (3, 96, 10, 14, 64, 1, 1, 0, (32, 64)),         # ragged split, segment boundary inside a 128-wide tile
     (2, 64, 16, 24, 128, 3, 2, 1, (32, 32)),        # stride-2 form (four parity classes share the slot range)
+    (2, 64, 16, 24, 128, 3, 2, 1, (32, 32), "fold"),  # the same through the folded stride-2 form
+    (4, 32, 64, 96, 64, 3, 2, 1, (32,), "fold"),
     (4, 128, 72, 64, 128, 3, 1, 1, (128,)),         # M = 18432 rows, K = 1152: 256-pixel tiles
 ])
 def test_conv_dgrad_with_fused_bn_backward_reduction(case):
@@ -340,7 +347,8 @@ def test_conv_dgrad_with_fused_bn_backward_reduction(case):
     sum dz*y), turned into coefficients with raw_moment=1, equal the separate reduce pass over the same tensors."""
     from object_detection_cib_amd._lib import KodBnRedSeg
     import ctypes as C
-    B, Cin, H, W, Cout, k, s, p, split = case
+    B, Cin, H, W, Cout, k, s, p, split = case[:9]
+    fold = len(case) > 9
     g = torch.Generator().manual_seed(sum(case[:8]))
     x = bf(torch.randn(B, Cin, H, W, generator=g)).requires_grad_(True)
     w = bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
@@ -349,10 +357,13 @@ def test_conv_dgrad_with_fused_bn_backward_reduction(case):
     y.backward(dy)
     lib = _lib.lib()
     s2 = (k, s, p) == (3, 2, 1)
-    pk = pack([w], s2=s2)
+    pk = pack([w], s2="fold" if fold else s2)
     dyb = nhwc(dy)
     M = B * H * W
-    slots = lib.kodhip_conv_dgrad_bnred_slots(B, H, W, Cin, Cout, k, k, s, s, p, p, Cout, int(s2))
+    if fold:
+        slots = lib.kodhip_conv_dgrad_s2f_bnred_slots(B, H, W, Cin, Cout, Cout)
+    else:
+        slots = lib.kodhip_conv_dgrad_bnred_slots(B, H, W, Cin, Cout, k, k, s, s, p, p, Cout, int(s2))
     assert slots > 0
     # producers of dX's channel ranges: pre-BN tensors + BN constants
     prods, ch0 = [], 0
@@ -372,8 +383,9 @@ def test_conv_dgrad_with_fused_bn_backward_reduction(case):
     dxb = torch.zeros((B, H, W, Cin), dtype=torch.bfloat16, device="cuda")
     sp = C.cast(segs, C.c_void_p)
     if s2:
-        _lib.check(lib.kodhip_conv_dgrad_s2_bnred(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
-                                                  Cout, Cout, 0, 0, sp, len(prods), slots, stream()), "dgrad_s2_bnred")
+        fn = lib.kodhip_conv_dgrad_s2f_bnred if fold else lib.kodhip_conv_dgrad_s2_bnred
+        _lib.check(fn(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
+                      Cout, Cout, 0, 0, sp, len(prods), slots, stream()), "dgrad_s2_bnred")
     else:
         _lib.check(lib.kodhip_conv_dgrad_bnred(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
                                                Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 0, sp, len(prods), slots,

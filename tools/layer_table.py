@@ -14,19 +14,19 @@ B = 64
 isk = lambda r, s: s in r['Kernel_Name']
 import re
 def mode(r):
-    m = re.search(r'conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d), ', r['Kernel_Name'])
+    m = re.search(r'conv_igemm(?:_x4)?_kernel<\d+, \d+, \d+, \d+, (\d), ', r['Kernel_Name'])
     return int(m.group(1)) if m else -1
 fw = [r for r in step if mode(r) == 0]
-dg = [r for r in step if mode(r) == 1]
+dg = [r for r in step if mode(r) in (1, 3)]
 wg = [r for r in step if isk(r, 'conv_wgrad')]
 # backward per unit in reverse order; the three heads come first (one dgrad + one wgrad each)
 ru = list(reversed(units))
 dmap, wmap = {}, {}
 dpos, wpos = 3, 3
+dual_shorts = {u.sibling.name for u in units if u.sibling is not None}     # their dX comes from the main_conv's launch
 for u in ru:
-    if not u.stem:
-        n = 4 if (u.k == 3 and u.s == 2) else 1
-        dmap[u.name] = sum(dur(r) for r in dg[dpos:dpos + n]); dpos += n
+    if not u.stem and u.name not in dual_shorts:
+        dmap[u.name] = dur(dg[dpos]); dpos += 1
     wmap[u.name] = dur(wg[wpos]); wpos += 1
 tot = [0, 0, 0]
 for i, u in enumerate(units):
@@ -49,5 +49,5 @@ for r in step:
     key = n.split('(')[0][:48]
     fam.setdefault(key, [0, 0.0]); fam[key][0] += 1; fam[key][1] += dur(r)
 print("step kernel time %.2f ms" % (sum(v[1] for v in fam.values()) / 1e3))
-for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:16]:
+for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:60]:
     print("   %8.1f us  x%-4d %s" % (t, c, k))
