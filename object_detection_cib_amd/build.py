@@ -22,9 +22,15 @@ def _digest(paths):
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode() + b"\0" + f.read())
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())      # (not the path: the tree moves between machines)
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
+
+
+def source_digest() -> str:
+    """Digest of the kernel sources + flags the library is built from (stamped next to the .so; the PMC evidence under
+    profiles/ records the digest it was collected on)."""
+    return _digest(sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "*.h"))))
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

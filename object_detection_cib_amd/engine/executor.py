@@ -68,6 +68,8 @@ class Engine:
         self.param_version = 0
         self.stats_version = 0         # bumped whenever BatchNorm running statistics change (training forward, load)
         self._eval_aff = None          # eval-mode BN constants of all units (flat), see _eval_affine_ptrs
+        self.br_stream = None         # side stream of the CSP short_conv branch in forward()
+        self.branch_overlap = os.environ.get("KODHIP_BRANCH_OVERLAP", "1") != "0"
         self.profile = None           # list of (family, start_event, end_event, algorithmic bytes), see _t0 / _t1
 
     # ------------------------------------------------------------------ arenas
@@ -472,7 +474,7 @@ class Engine:
         sync = training and self.sync_bn and self.collectives
         rm, rv = self.rm_arena.data_ptr(), self.rv_arena.data_ptr()
 
-        def conv_stage(u: ConvUnit):
+        def conv_stage(u: ConvUnit, s=s):
             st, C_ = self.ustate[u.name], u.cout
             if u.stem:
                 geo = (B, st.H, st.W, 8, 0, 32, C_, 6, 1, 2, 1, 2, 1, st.Kp_f)      # wide-pixel form, see Kp_f
@@ -485,7 +487,7 @@ class Engine:
             in_px = B * H * W if u.stem else B * st.H * st.W
             self._t1(e0, "conv_fwd", 2 * (in_px * cin_true + st.M * C_))
 
-        def stats_stage(group):
+        def stats_stage(group, s=s):
             """Batch statistics -> BatchNorm constants.  Under SyncBN the [sum, sum of squares] vectors of the group's
             units (a CSP layer's main + short convs) are exchanged as ONE grouped collective."""
             e0 = self._t0()
@@ -510,7 +512,7 @@ class Engine:
                                                BN_EPS, aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
             self._t1(e0, "bn_finalize", sum(8.0 * u.cout * self.ustate[u.name].T for u in group))
 
-        def apply_stage(u: ConvUnit):
+        def apply_stage(u: ConvUnit, s=s):
             st, C_ = self.ustate[u.name], u.cout
             aff = st.aff.data_ptr()
             sc_p, sh_p = (aff, aff + 4 * C_) if training else eval_aff[u.name]
@@ -522,11 +524,37 @@ class Engine:
                                          self._ptr(u.dst), u.dst.buf.C, u.dst.coff, st.M, C_, s), u.name)
             self._t1(e0, "bn_silu_apply", (6.0 if res else 4.0) * st.M * C_)
 
+        # A CSP layer's short_conv (conv -> statistics -> apply) depends only on the layer input and is needed only by
+        # last_conv: it runs on a side stream next to main_conv and the blocks, where it fills the chip while the main
+        # branch sits in a single-block statistics kernel or a latency-bound deep layer.  (Not under SyncBN - the two
+        # statistic exchanges travel as one grouped collective on the main stream - and not while timing families.)
+        main_stream = torch.cuda.current_stream()
+        branch = training and not sync and self.branch_overlap and self.profile is None
+        joined_buf = None                # concat buffer whose short_conv half is being written on the side stream
         ops = self.g.ops
         i = 0
         while i < len(ops):
             op = ops[i]
             i += 1
+            if op.kind == "conv" and joined_buf is not None and op.unit.src.buf.name == joined_buf:
+                main_stream.wait_stream(self.br_stream)
+                joined_buf = None
+            if op.kind == "conv" and branch and op.unit.sibling is not None and i < len(ops) and \
+                    ops[i].unit is op.unit.sibling and joined_buf is None:
+                short = ops[i].unit
+                i += 1
+                if self.br_stream is None:
+                    self.br_stream = torch.cuda.Stream(device=self.device)
+                self.br_stream.wait_stream(main_stream)
+                bs = self.br_stream.cuda_stream
+                conv_stage(short, bs)
+                stats_stage([short], bs)
+                apply_stage(short, bs)
+                joined_buf = short.dst.buf.name
+                conv_stage(op.unit)
+                stats_stage([op.unit])
+                apply_stage(op.unit)
+                continue
             if op.kind == "conv":
                 group = [op.unit]
                 # SyncBN: a unit and its sibling (same input, next in the program) share one statistic exchange
@@ -557,6 +585,8 @@ class Engine:
                                              out.data_ptr(), B, hs["H"], hs["W"], hu.src.buf.C, hu.src.coff,
                                              hu.cin, A, nc, hs["Kp"], s), hu.name)
                 outs.append(out)
+        if joined_buf is not None:
+            main_stream.wait_stream(self.br_stream)
         if training:
             self.nbt_arena += 1
             self.stats_version += 1              # running statistics moved

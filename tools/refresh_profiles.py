@@ -42,7 +42,7 @@ def per_family(rows, counter):
 
 def main():
     from object_detection_cib_amd import build as kb
-    dig = kb._digest(sorted(glob.glob(os.path.join(kb.CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(kb.CSRC, "*.h"))))
+    dig = kb.source_digest()
     bench = json.loads(open(os.path.join(EV, "bench.json")).read().strip().splitlines()[-1])
     fam_alg = {r["family"]: r for r in bench.get("families", [])}
     fr, wr = counter_rows(os.path.join(EV, "pmc_FETCH_SIZE")), counter_rows(os.path.join(EV, "pmc_WRITE_SIZE"))
