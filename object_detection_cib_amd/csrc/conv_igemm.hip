@@ -614,17 +614,26 @@ void conv_igemm_kernel(ConvArgs a) {
   conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(a, blockIdx.x);
 }
 
-// Four problems of identical tiling in one launch (the parity classes of a stride-2 dgrad): blocks 8j .. 8j+31 are
-// {XCD 0-7} x {class 0-3} of virtual block group j, so the four classes that gather the same dY rows run next to
-// each other on the same XCD and share them through its L2 instead of streaming dY from HBM four times.
-struct ConvArgs4 { ConvArgs c[4]; };
+// Four problems of identical tiling in one launch (the parity classes of a stride-2 dgrad).  The classes have 4, 2, 2
+// and 1 taps - reductions of very different length - and the launch is a few rounds of resident blocks at most, so
+// blocks are dispatched longest class first (class 3, then 1 and 2, then 0): a long block never starts in the last
+// round behind short ones.  (The layers that still take this form are the deep ones, whose dY stays in L2 / MALL
+// whatever the order; `interleave` != 0 restores the round-1 order - blocks 8j .. 8j+31 = {XCD 0-7} x {class 0-3} -
+// for A/B.)
+struct ConvArgs4 { ConvArgs c[4]; int per_class, interleave; };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ ? 2 : (FAST ? 4 : 3)))   /* waves per SIMD */
 void conv_igemm_x4_kernel(ConvArgs4 p) {
   const int bid = blockIdx.x;
-  const int cls = (bid >> 3) & 3;
-  conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(p.c[cls], ((bid >> 5) << 3) | (bid & 7));
+  if (p.interleave) {
+    const int cls = (bid >> 3) & 3;
+    conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(p.c[cls], ((bid >> 5) << 3) | (bid & 7));
+  } else {
+    const int q = bid / p.per_class;                     // 0..3 in dispatch order
+    const int cls = q == 0 ? 3 : (q == 3 ? 0 : q);
+    conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(p.c[cls], bid - q * p.per_class);
+  }
 }
 
 // ---- launch planning --------------------------------------------------------------------------------
@@ -726,6 +735,8 @@ int launch_x4(ConvArgs c[4], hipStream_t stream) {
       p.c[i].slot_base = i * pl.groups_m; p.c[i].slot_used = 4 * pl.groups_m;
     }
   }
+  static const bool interleave = getenv("KODHIP_S2_INTERLEAVE") != nullptr;
+  p.per_class = pl.grid; p.interleave = interleave;
   dim3 g(pl.grid * 4);
   if (pl.bm == 256 && pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
   else if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
