@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--autograd", action="store_true",
+                    help="drive the step through torch autograd (net(x) -> loss -> .backward()) instead of Yolov5Network.train_step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,10 +225,13 @@ def main():
     def step():
         for p in params:
             p.grad = None
-        res = net(x)
-        lr_ = loss_fn(shape, res, targets)
-        total = B * (lr_.localization + lr_.classification + lr_.objectness)
-        total.backward()
+        if args.autograd:          # the reference's own call sequence through torch autograd (same numbers, more launches)
+            res = net(x)
+            lr_ = loss_fn(shape, res, targets)
+            total = B * (lr_.localization + lr_.classification + lr_.objectness)
+            total.backward()
+        else:
+            total, _ = net.train_step(x, loss_fn, shape, targets, float(B))
         eng.wait_grads()
         eng.sgd_step_device()
         return total

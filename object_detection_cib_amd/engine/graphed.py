@@ -48,9 +48,7 @@ class GraphedTrainStep:
     def _step(self):
         for p in self.params:
             p.grad = None
-        lr = self.loss(self.shape, self.net(self.x), self.targets)
-        total = self.scale * (lr.localization + lr.classification + lr.objectness)
-        total.backward()
+        total, lr = self.net.train_step(self.x, self.loss, self.shape, self.targets, self.scale)
         self.eng.wait_grads()
         self.eng.sgd_step_device()
         return total, (lr.localization.detach(), lr.objectness.detach(), lr.classification.detach())

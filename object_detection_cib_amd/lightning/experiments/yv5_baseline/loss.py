@@ -121,3 +121,34 @@ class Yolov5Loss(nn.Module):
             self.weights = self.weights.to(raws[0].device)
         loc, obj, cls = _LossFn.apply(self, image_feature_shape, targets, *raws)
         return LossResult(localization=loc, objectness=obj, classification=cls)
+
+    def value_and_grad(self, image_feature_shape: FeatureShape, raws, targets: Sequence,
+                       upstream: Sequence[float] = (1.0, 1.0, 1.0)):
+        """Loss values AND d(sum_k upstream_k * loss_k) / d(head tensors) in ONE pass of the loss kernels - what
+        `forward()` followed by autograd's backward computes in two passes (the second pass recomputes every row and
+        cell).  raws: the three contiguous [B, A, h, w, 5+nc] fp32 head tensors; upstream = (d total / d localization,
+        d total / d objectness, d total / d classification), e.g. (B, B, B) for the reference's `B * (loc + cls + obj)`
+        (exp.py:104-121).  Same kernels, same arithmetic, same results bit for bit (tests/test_hip_training.py).
+        Returns (LossResult, [grad_ll, grad_ml, grad_hl])."""
+        raws = [t.contiguous() for t in raws]
+        dev = raws[0].device
+        if self.weights is not None and self.weights.device != dev:
+            self.weights = self.weights.to(dev)
+        key = (tuple(float(u) for u in upstream), dev)
+        cache = self.__dict__.setdefault("_upstream_cache", {})
+        if key not in cache:          # (first call = warm-up, outside any graph capture)
+            cache[key] = torch.tensor(key[0], dtype=torch.float32, device=dev)
+        asg, cap = self.assigner.assign_device(image_feature_shape, targets, dev)
+        B, A, _, _, P = raws[0].shape
+        nslots = max((cap + 255) // 256, 1024)
+        work = dict(
+            maps=[torch.empty(3 * B * A * t.shape[2] * t.shape[3], dtype=torch.int32, device=dev) for t in raws],
+            prev=[torch.empty(cap, dtype=torch.int32, device=dev) for _ in raws],
+            rowgrad=[torch.empty(cap * (P - 1), dtype=torch.float32, device=dev) for _ in raws],
+            tobj=[torch.empty(cap, dtype=torch.float32, device=dev) for _ in raws],
+            partials=torch.zeros(9 * nslots, dtype=torch.float32, device=dev), nslots=nslots,
+            out=torch.empty(12, dtype=torch.float32, device=dev))
+        grads = [torch.empty_like(t) for t in raws]
+        _run(self, image_feature_shape, raws, asg, cap, grads, cache[key], work)
+        out = work["out"]
+        return LossResult(localization=out[0], objectness=out[1], classification=out[2]), grads

@@ -161,6 +161,24 @@ class Yolov5Network(nn.Module):
         with torch.no_grad():
             return tuple(eng.forward(x, training=self.training))
 
+    def train_step(self, x: torch.Tensor, loss, image_feature_shape, targets, scale: float):
+        """forward -> assigner + loss -> backward of `scale * (localization + classification + objectness)` (the
+        reference's training_step, exp.py:104-121) as straight calls into the engine: no autograd graph, and the loss
+        kernels run once (value and gradient together, `Yolov5Loss.value_and_grad`) instead of once per direction.
+        Leaves the parameter gradients in `.grad` exactly like `total.backward()` does; returns (total, LossResult).
+        The autograd route (`net(x)` -> `loss(...)` -> `.backward()`) stays available and gives the same numbers bit for
+        bit; this is the route the captured step (engine/graphed.py) and bench.py take."""
+        eng = self.engine()
+        assert self.training, "train_step() needs train mode"
+        if x.dtype != torch.float32:
+            x = x.float()
+        with torch.no_grad():
+            outs = eng.forward(x.contiguous(), training=True)
+            lr, grads = loss.value_and_grad(image_feature_shape, outs, targets, (scale, scale, scale))
+            eng.backward(grads)
+            total = scale * (lr.localization + lr.classification + lr.objectness)
+        return total, lr
+
     def forward(self, x: torch.Tensor) -> Yolov5NetworkResult:
         raws = self.forward_raw(x)
         return Yolov5NetworkResult(*[DetectionHeadResult(t[..., 0:4], t[..., 4:5], t[..., 5:]) for t in raws])

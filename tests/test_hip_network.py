@@ -433,3 +433,39 @@ def test_forward_is_deterministic_and_eval_mode_runs():
         e = net(x.cuda())
     assert all(torch.isfinite(t).all() for h in e for t in h)
     assert set(net2_state) == set(net.state_dict())
+
+
+@pytest.mark.parametrize("pos_weight", [False, True])
+def test_train_step_without_autograd_equals_autograd_route(pos_weight):
+    """Yolov5Network.train_step (engine forward -> Yolov5Loss.value_and_grad: ONE pass of the loss kernels -> engine
+    backward; what the captured step and bench.py run) against the reference's call sequence through torch autograd
+    (net(x) -> loss(...) -> (B * sum).backward(): the loss kernels run once per direction): every loss value and every
+    parameter gradient bit for bit, BatchNorm buffers included."""
+    size, B, nc = 160, 4, 10
+    x, _ = synth.batch(B, size, nc, 11)
+    tg = synth.targets(B, size, nc, 11, nmin=1, nmax=9)
+    targets = tuple(DetectionTarget(b, l) for b, l in tg)
+    shape = FeatureShape(width=size, height=size)
+    got = []
+    for route in ("autograd", "direct"):
+        torch.manual_seed(3)
+        net = Yolov5Network(3, nc, widen_factor=0.25, deepen_factor=0.33).cuda().train()
+        loss = _loss()
+        if pos_weight:
+            loss.weights = torch.linspace(0.5, 2.0, nc)
+        if route == "autograd":
+            lr = loss(shape, net(x.cuda()), targets)
+            total = B * (lr.localization + lr.classification + lr.objectness)
+            total.backward()
+        else:
+            total, lr = net.train_step(x.cuda(), loss, shape, targets, float(B))
+        net.engine().wait_grads()
+        torch.cuda.synchronize()
+        got.append(dict(total=total.detach().cpu(), parts=torch.stack([lr.localization, lr.objectness, lr.classification]).detach().cpu(),
+                        grads=torch.cat([p.grad.flatten() for p in net.parameters()]).cpu(),
+                        rm=net.engine().rm_arena.cpu(), rv=net.engine().rv_arena.cpu()))
+    a, d = got
+    assert torch.equal(a["parts"], d["parts"]) and torch.equal(a["total"], d["total"]), (a["parts"], d["parts"])
+    assert torch.isfinite(d["grads"]).all() and d["grads"].abs().max() > 0
+    assert torch.equal(a["grads"], d["grads"])
+    assert torch.equal(a["rm"], d["rm"]) and torch.equal(a["rv"], d["rv"])
