@@ -153,6 +153,7 @@ int kodhip_upsample2x_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, i
                           int B, int H, int W, int C, kodStream_t stream);
 int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx, int xcoff, int accumulate,
                           int B, int H, int W, int C, kodStream_t stream);
+/* workspace: 2048 * Npad floats (per-block bias partials) */
 int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_box, float* db_obj, float* db_cls,
                          int B, int HW, int A, int nc, int Npad, kodStream_t stream);
 

@@ -86,7 +86,10 @@ class Yolov5LabelAssigner(object):
                 raise ValueError("HIP assigner kernel is built for 3 anchors per cell")
 
     # -- sync-free device path ------------------------------------------------------------------
-    def assign_device(self, input_image_shape: FeatureShape, targets, device) -> tuple:
+    def assign_device(self, input_image_shape: FeatureShape, targets, device, stream=None) -> tuple:
+        """stream: torch stream the assignment kernel is launched on (default: the current one).  The outputs are
+        allocated in the current stream's context either way; a caller that passes a side stream joins it before use
+        (the assignment depends only on the targets, so a training step runs it beside the network's forward pass)."""
         _lib.require_gpu()
         lib = _lib.lib()
         bt = targets if isinstance(targets, BatchedTargets) else BatchedTargets.from_targets(targets, device)
@@ -114,7 +117,7 @@ class Yolov5LabelAssigner(object):
                                              samples.data_ptr() if n else None, n, cap,
                                              int(input_image_shape.width), int(input_image_shape.height),
                                              float(self.threshold), levels,
-                                             torch.cuda.current_stream().cuda_stream), "assign_targets")
+                                             (stream or torch.cuda.current_stream()).cuda_stream), "assign_targets")
         self._keepalive = (boxes, labels, samples)
         return tuple(outs), cap
 

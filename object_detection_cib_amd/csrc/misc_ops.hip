@@ -268,41 +268,57 @@ __global__ void upsample2x_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, bf16
 
 // ------------------------------------------------------------------ head gradient re-layout
 // g[B][A][HW][P] fp32 -> dy[M = B*HW][Npad] bf16 with n = box(4A) | obj(A) | cls(nc*A); bias partials
-// bpart[blk][Npad] (summed by bias_reduce).
-__global__ void head_bwd_prep_kernel(const float* g, bf16_t* dy, float* bpart, int B, int HW, int A, int nc,
-                                     int Npad) {
-  extern __shared__ float sm[];            // [blockDim.x / Npad][Npad]
+// bpart[blk][Npad] (summed by bias_reduce).  A transpose through LDS: a block takes PREP_ROWS consecutive rows of M,
+// reads each anchor's [rows][P] run of g as one contiguous stream (the rows of an image are consecutive pixels), and
+// writes the rows of dy as 16-byte chunks of one contiguous run; blocks are persistent over tiles, so the bias partial
+// of a block is a fixed-order sum (deterministic).
+__global__ __launch_bounds__(256) void head_bwd_prep_kernel(const float* g, bf16_t* dy, float* bpart, int B, int HW,
+                                                            int A, int nc, int Npad, uint32_t magic_p, int PREP_ROWS) {
+  extern __shared__ float sm[];            // [PREP_ROWS][Npad + 1]
   const int P = 5 + nc;
   const int N = A * P;
-  const int n = threadIdx.x % Npad;
-  const int rl = threadIdx.x / Npad;
-  const int rpb = blockDim.x / Npad;
-  long M = (long)B * HW;
-  float s = 0.f;
-  int an = 0, slot = 0;
-  if (n < N) {
-    if (n < 4 * A) { an = n >> 2; slot = n & 3; }
-    else if (n < 5 * A) { an = n - 4 * A; slot = 4; }
-    else { int q = n - 5 * A; an = q / nc; slot = 5 + q - an * nc; }
-  }
-  if (rl < rpb) {
-    for (long m = (long)blockIdx.x * rpb + rl; m < M; m += (long)gridDim.x * rpb) {
-      float v = 0.f;
-      if (n < N) {
-        long b = m / HW, pix = m - b * HW;
-        v = g[((b * A + an) * HW + pix) * P + slot];
-      }
-      dy[m * Npad + n] = (bf16_t)v;
-      s += v;
-    }
-    sm[rl * Npad + n] = s;
-  }
+  const int ldt = Npad + 1;
+  const long M = (long)B * HW;
+  const int ntiles = (int)((M + PREP_ROWS - 1) / PREP_ROWS);
+  float bsum = 0.f;                         // thread n < Npad: running column sum over this block's tiles
+  for (int i = threadIdx.x; i < PREP_ROWS * ldt; i += blockDim.x) sm[i] = 0.f;      // (padding columns stay zero)
   __syncthreads();
-  if (threadIdx.x < Npad) {
-    float t = 0.f;
-    for (int r = 0; r < rpb; ++r) t += sm[r * Npad + threadIdx.x];
-    bpart[(size_t)blockIdx.x * Npad + threadIdx.x] = t;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long m0 = (long)t * PREP_ROWS;
+    const int b0 = (int)(m0 / HW), pix0 = (int)(m0 - (long)b0 * HW);
+    for (int an = 0; an < A; ++an)
+      for (int idx = threadIdx.x; idx < PREP_ROWS * P; idx += blockDim.x) {
+        const int r = (int)__umulhi((uint32_t)idx, magic_p);          // idx / P (idx < 2^13: exact)
+        const int slot = idx - r * P;
+        float v = 0.f;
+        if (m0 + r < M) {
+          int b = b0, pix = pix0 + r;
+          while (pix >= HW) { pix -= HW; ++b; }
+          v = g[(((long)b * A + an) * HW + pix) * P + slot];
+        }
+        const int n = slot < 4 ? 4 * an + slot : (slot == 4 ? 4 * A + an : 5 * A + an * nc + slot - 5);
+        sm[r * ldt + n] = v;
+      }
+    __syncthreads();
+    const int cpr = Npad / 8;               // 16-byte chunks per row
+    for (int c = threadIdx.x; c < PREP_ROWS * cpr; c += blockDim.x) {
+      const int r = c / cpr, n0 = (c - r * cpr) * 8;
+      if (m0 + r < M) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)sm[r * ldt + n0 + e];
+        *reinterpret_cast<bf16x8*>(dy + (m0 + r) * Npad + n0) = o;
+      }
+    }
+    if (threadIdx.x < Npad) {
+      float s = 0.f;
+      for (int r = 0; r < PREP_ROWS; ++r) s += sm[r * ldt + threadIdx.x];       // rows past M hold zeros
+      bsum += s;
+    }
+    __syncthreads();
   }
+  if (threadIdx.x < Npad) bpart[(size_t)blockIdx.x * Npad + threadIdx.x] = bsum;
+  (void)N;
 }
 
 // bias grads of the three heads: db_box[4A], db_obj[A], db_cls[nc*A] are consecutive in n order.
@@ -419,18 +435,18 @@ int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx,
   return KOD_OK;
 }
 
-// workspace: bias partials, 512 * Npad floats
+// workspace: bias partials, 2048 * Npad floats
 int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_box, float* db_obj, float* db_cls,
                          int B, int HW, int A, int nc, int Npad, hipStream_t stream) {
   KOD_CHECK_ARG(g && dy && workspace && db_box && db_obj && db_cls, "head_bwd_prep: null pointer");
   KOD_CHECK_ARG(Npad % 8 == 0 && Npad >= A * (5 + nc) && Npad <= 256, "head_bwd_prep: bad Npad");
-  int rpb = 256 / Npad;
-  int threads = rpb * Npad;
+  KOD_CHECK_ARG(nc > 0 && 5 + nc <= 128, "head_bwd_prep: bad class count");
   long M = (long)B * HW;
-  int grid = (int)((M + rpb - 1) / rpb);
-  if (grid > 512) grid = 512;
-  hipLaunchKernelGGL(head_bwd_prep_kernel, dim3(grid), dim3(threads), rpb * Npad * sizeof(float), stream, g,
-                     (bf16_t*)dy, workspace, B, HW, A, nc, Npad);
+  const int PREP_ROWS = Npad <= 128 ? 64 : 32;          // rows per tile: [rows][Npad + 1] floats of LDS (<= 33 KB)
+  int grid = (int)((M + PREP_ROWS - 1) / PREP_ROWS);
+  if (grid > 2048) grid = 2048;           // 8 blocks per CU: the load / store phases of a tile are latency-bound
+  hipLaunchKernelGGL(head_bwd_prep_kernel, dim3(grid), dim3(256), PREP_ROWS * (Npad + 1) * sizeof(float), stream, g,
+                     (bf16_t*)dy, workspace, B, HW, A, nc, Npad, magic_u32((uint32_t)(5 + nc)), PREP_ROWS);
   KOD_LAUNCH_CHECK("head_bwd_prep");
   hipLaunchKernelGGL(head_bias_reduce_kernel, dim3(cdiv(A * (5 + nc), 4)), dim3(256), 0, stream,
                      (const float*)workspace, grid, Npad, db_box, db_obj, db_cls, A, nc);

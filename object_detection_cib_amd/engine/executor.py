@@ -69,6 +69,7 @@ class Engine:
         self.stats_version = 0         # bumped whenever BatchNorm running statistics change (training forward, load)
         self._eval_aff = None          # eval-mode BN constants of all units (flat), see _eval_affine_ptrs
         self.br_stream = None         # side stream of the CSP short_conv branch in forward()
+        self.aux_stream = None        # side stream of work that only depends on the step's inputs (label assignment)
         self.branch_overlap = os.environ.get("KODHIP_BRANCH_OVERLAP", "1") != "0"
         self.profile = None           # list of (family, start_event, end_event, algorithmic bytes), see _t0 / _t1
 
@@ -295,7 +296,7 @@ class Engine:
             hh, ww = H // h.stride, W // h.stride
             hs.update(H=hh, W=ww, M=B * hh * ww)
             hs["dy"] = torch.empty((B * hh * ww, self.head_npad), dtype=torch.bfloat16, device=dev)
-            hs["ws"] = torch.empty(512 * self.head_npad, dtype=torch.float32, device=dev)
+            hs["ws"] = torch.empty(2048 * self.head_npad, dtype=torch.float32, device=dev)
             splits = lib.kodhip_conv_wgrad_splits(hs["M"], self.head_npad, hs["Kp"])
             max_part = max(max_part, splits * self.head_npad * hs["Kp"])
         self.wg_part = torch.empty(max_part, dtype=torch.float32, device=dev)

@@ -123,13 +123,14 @@ class Yolov5Loss(nn.Module):
         return LossResult(localization=loc, objectness=obj, classification=cls)
 
     def value_and_grad(self, image_feature_shape: FeatureShape, raws, targets: Sequence,
-                       upstream: Sequence[float] = (1.0, 1.0, 1.0)):
+                       upstream: Sequence[float] = (1.0, 1.0, 1.0), assignment=None):
         """Loss values AND d(sum_k upstream_k * loss_k) / d(head tensors) in ONE pass of the loss kernels - what
         `forward()` followed by autograd's backward computes in two passes (the second pass recomputes every row and
         cell).  raws: the three contiguous [B, A, h, w, 5+nc] fp32 head tensors; upstream = (d total / d localization,
         d total / d objectness, d total / d classification), e.g. (B, B, B) for the reference's `B * (loc + cls + obj)`
         (exp.py:104-121).  Same kernels, same arithmetic, same results bit for bit (tests/test_hip_training.py).
-        Returns (LossResult, [grad_ll, grad_ml, grad_hl])."""
+        assignment: a precomputed `assigner.assign_device(...)` result (a training step computes it on a side stream
+        while the network's forward pass runs).  Returns (LossResult, [grad_ll, grad_ml, grad_hl])."""
         raws = [t.contiguous() for t in raws]
         dev = raws[0].device
         if self.weights is not None and self.weights.device != dev:
@@ -138,7 +139,7 @@ class Yolov5Loss(nn.Module):
         cache = self.__dict__.setdefault("_upstream_cache", {})
         if key not in cache:          # (first call = warm-up, outside any graph capture)
             cache[key] = torch.tensor(key[0], dtype=torch.float32, device=dev)
-        asg, cap = self.assigner.assign_device(image_feature_shape, targets, dev)
+        asg, cap = assignment if assignment is not None else self.assigner.assign_device(image_feature_shape, targets, dev)
         B, A, _, _, P = raws[0].shape
         nslots = max((cap + 255) // 256, 1024)
         work = dict(

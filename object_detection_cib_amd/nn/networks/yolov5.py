@@ -173,8 +173,16 @@ class Yolov5Network(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         with torch.no_grad():
+            # the assignment depends only on the targets: its (three-block, latency-bound) kernel runs on a side stream
+            # beside the forward pass instead of between the heads and the loss
+            cur = torch.cuda.current_stream()
+            if eng.aux_stream is None:
+                eng.aux_stream = torch.cuda.Stream(device=eng.device)
+            eng.aux_stream.wait_stream(cur)
+            asg = loss.assigner.assign_device(image_feature_shape, targets, eng.device, stream=eng.aux_stream)
             outs = eng.forward(x.contiguous(), training=True)
-            lr, grads = loss.value_and_grad(image_feature_shape, outs, targets, (scale, scale, scale))
+            cur.wait_stream(eng.aux_stream)
+            lr, grads = loss.value_and_grad(image_feature_shape, outs, targets, (scale, scale, scale), assignment=asg)
             eng.backward(grads)
             total = scale * (lr.localization + lr.classification + lr.objectness)
         return total, lr

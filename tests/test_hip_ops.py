@@ -186,7 +186,7 @@ def test_head_conv_fwd_bwd():
     _close(out.cpu(), ref.detach(), 2e-3, 2e-3, "head fwd")
     # backward
     dy = torch.zeros((B * H * W, npad), dtype=torch.bfloat16, device="cuda")
-    ws_ = torch.zeros(512 * npad, dtype=torch.float32, device="cuda")
+    ws_ = torch.zeros(2048 * npad, dtype=torch.float32, device="cuda")
     db = [torch.zeros(n, device="cuda") for n in (4 * A, A, nc * A)]
     _lib.check(lib.kodhip_head_bwd_prep(gout.cuda().contiguous().data_ptr(), dy.data_ptr(), ws_.data_ptr(),
                                         db[0].data_ptr(), db[1].data_ptr(), db[2].data_ptr(), B, H * W, A, nc, npad,
