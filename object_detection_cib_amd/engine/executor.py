@@ -57,6 +57,7 @@ class Engine:
         self.world_size = 1
         self.wg_stream = None          # side stream of the weight-gradient kernels (see backward)
         self.wgrad_overlap = os.environ.get("KODHIP_WGRAD_OVERLAP", "1") != "0"
+        self.wgrad_fork = os.environ.get("KODHIP_WGRAD_FORK", "apply")     # see backward(): deferred capture of the wgrad launches
         self.comm = None               # RcclComm when the process group is RCCL-backed (the product path)
         self.comm_buckets = None       # second communicator: gradient buckets on the side stream (comm_overlap)
         self.comm_stream = None        # side stream of the gradient-bucket all-reduces
@@ -68,6 +69,9 @@ class Engine:
         self.param_version = 0
         self.stats_version = 0         # bumped whenever BatchNorm running statistics change (training forward, load)
         self._eval_aff = None          # eval-mode BN constants of all units (flat), see _eval_affine_ptrs
+        self._fork_ev = None
+        self._fork_n = 0
+        self.wgrad_group = max(int(os.environ.get("KODHIP_WGRAD_GROUP", "1")), 1)
         self.br_stream = None         # side stream of the CSP short_conv branch in forward()
         self.aux_stream = None        # side stream of work that only depends on the step's inputs (label assignment)
         self.branch_overlap = os.environ.get("KODHIP_BRANCH_OVERLAP", "1") != "0"
@@ -546,15 +550,19 @@ class Engine:
                 i += 1
                 if self.br_stream is None:
                     self.br_stream = torch.cuda.Stream(device=self.device)
-                self.br_stream.wait_stream(main_stream)
+                # the fork's dependency is taken here, the side branch is CAPTURED after the main branch's kernels: the
+                # graph executor keeps a node's first captured successor on its queue (see backward())
+                fork = torch.cuda.Event()
+                fork.record(main_stream)
+                conv_stage(op.unit)
+                stats_stage([op.unit])
+                apply_stage(op.unit)
+                self.br_stream.wait_event(fork)
                 bs = self.br_stream.cuda_stream
                 conv_stage(short, bs)
                 stats_stage([short], bs)
                 apply_stage(short, bs)
                 joined_buf = short.dst.buf.name
-                conv_stage(op.unit)
-                stats_stage([op.unit])
-                apply_stage(op.unit)
                 continue
             if op.kind == "conv":
                 group = [op.unit]
@@ -650,14 +658,46 @@ class Engine:
                 self.wg_stream = torch.cuda.Stream(device=self.device)
             wg = self.wg_stream
 
-        def wgrad_stream():
-            if wg is None:
-                return s
-            wg.wait_stream(main)
-            return wg.cuda_stream
+        # How a weight gradient joins the side stream matters in the captured graph: this stack's graph executor keeps a
+        # node's FIRST captured successor on the node's queue and hands later ones to other queues (~11 us per
+        # hand-over).  So the dependency is taken (event on the main stream) where dY is ready, but the launch itself is
+        # captured only after the main stream's next kernel - the critical chain ... -> dgrad -> next unit's
+        # coefficients -> ... then stays on one queue and only the off-path weight gradients pay the hand-over.
+        # KODHIP_WGRAD_FORK=legacy: wait_stream at the call site (round 1).  With collectives in the step the legacy form
+        # stays: a captured step that mixes these event edges with RCCL nodes crashed in hipGraphLaunch on this stack.
+        deferred = []                  # [(event, name, nbytes, args)]
+        defer = wg is not None and self.wgrad_fork != "legacy" and not self.collectives
+
+        def flush_wgrads(final=False):
+            while deferred and (final or deferred[0][0] is not None):
+                ev, name, nbytes, args = deferred.pop(0)
+                if ev is None:         # (its group never got an event: the end of backward)
+                    wg.wait_stream(main)
+                else:
+                    wg.wait_event(ev)
+                e0 = self._t0(wg)
+                chk(lib.kodhip_conv_wgrad(*args, wg.cuda_stream), name + ".wgrad")
+                self._t1(e0, "wgrad", nbytes, wg)
 
         def timed_wgrad(name, nbytes, *args):
-            ws = wgrad_stream()
+            if defer:
+                ev = self._fork_ev          # KODHIP_WGRAD_FORK=apply: dependency taken right after bn_silu_bwd_apply
+                self._fork_ev = None
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                if ev == "group":           # this unit shares the event of a later unit of its group (KODHIP_WGRAD_GROUP)
+                    deferred.append([None, name, nbytes, args])
+                else:
+                    for d in deferred:
+                        if d[0] is None:
+                            d[0] = ev
+                    deferred.append([ev, name, nbytes, args])
+                return
+            ws = s
+            if wg is not None:
+                wg.wait_stream(main)
+                ws = wg.cuda_stream
             e0 = self._t0(wg)
             chk(lib.kodhip_conv_wgrad(*args, ws), name + ".wgrad")
             self._t1(e0, "wgrad", nbytes, wg)
@@ -688,6 +728,7 @@ class Engine:
             nonlocal unit_i
             unit_i -= 1
             if unit_i in buckets:
+                flush_wgrads(final=True)   # the bucket's last weight gradients must be on the side stream before the collective
                 lo, hi = buckets[unit_i]
                 cs = self._comm_stream()
                 # overlapped buckets use their own communicator: SyncBN sums (main stream) and buckets (side stream)
@@ -728,6 +769,7 @@ class Engine:
                                                           aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off,
                                                           gp + 4 * st.b_off, st.coef.data_ptr(), C_, rawm, s), u.name)
             self._t1(e0, "bn_bwd_coeffs", sum(8.0 * u.cout * self.ustate[u.name].T2 for u in group))
+            flush_wgrads()             # (the previous unit's weight gradient: captured after this main-stream kernel)
 
         rops = list(reversed(self.g.ops))
         ri = 0
@@ -787,6 +829,7 @@ class Engine:
             # gradient buckets complete from the arena's end toward its start
             if op.kind == "head":
                 bucket_tick()
+        flush_wgrads(final=True)
         if wg is not None:
             main.wait_stream(wg)
         self._publish_grads()
@@ -809,6 +852,13 @@ class Engine:
                                          res.buf.C if res else 0, res.coff if res else 0,
                                          racc, st.M, C_, s), u.name)
         self._t1(e0, "bn_silu_bwd_apply", (6.0 + ((4.0 if racc else 2.0) if res else 0.0)) * st.M * C_)
+        if self.wgrad_fork == "apply" and self.wgrad_overlap and not self.collectives:
+            self._fork_n += 1
+            if self._fork_n % self.wgrad_group == 0:
+                self._fork_ev = torch.cuda.Event()
+                self._fork_ev.record()
+            else:
+                self._fork_ev = "group"
         # st.raw now holds dY
         if u.stem:
             geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1)

@@ -178,9 +178,13 @@ class Yolov5Network(nn.Module):
             cur = torch.cuda.current_stream()
             if eng.aux_stream is None:
                 eng.aux_stream = torch.cuda.Stream(device=eng.device)
-            eng.aux_stream.wait_stream(cur)
-            asg = loss.assigner.assign_device(image_feature_shape, targets, eng.device, stream=eng.aux_stream)
+            fork = torch.cuda.Event()
+            fork.record(cur)
             outs = eng.forward(x.contiguous(), training=True)
+            # (launched - and captured - after the forward pass, dependent only on the step's start: the graph executor
+            # keeps a node's first captured successor on its queue, and that must be the forward chain)
+            eng.aux_stream.wait_event(fork)
+            asg = loss.assigner.assign_device(image_feature_shape, targets, eng.device, stream=eng.aux_stream)
             cur.wait_stream(eng.aux_stream)
             lr, grads = loss.value_and_grad(image_feature_shape, outs, targets, (scale, scale, scale), assignment=asg)
             eng.backward(grads)

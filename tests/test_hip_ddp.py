@@ -129,9 +129,9 @@ def _native_worker(port, size, out):
             def step():
                 for p in params:
                     p.grad = None
-                lr = loss(FeatureShape(width=size, height=size), net(xb), bt)
-                total = 4 * (lr.localization + lr.classification + lr.objectness)
-                total.backward()
+                # Yolov5Network.train_step: the route bench.py and the captured training loop take (label assignment on
+                # a side stream, one pass of the loss kernels, engine backward)
+                total, _ = net.train_step(xb, loss, FeatureShape(width=size, height=size), bt, 4.0)
                 eng.wait_grads()
                 eng.sgd_step_device()
                 return total
