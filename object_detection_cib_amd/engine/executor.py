@@ -70,8 +70,6 @@ class Engine:
         self.stats_version = 0         # bumped whenever BatchNorm running statistics change (training forward, load)
         self._eval_aff = None          # eval-mode BN constants of all units (flat), see _eval_affine_ptrs
         self._fork_ev = None
-        self._fork_n = 0
-        self.wgrad_group = max(int(os.environ.get("KODHIP_WGRAD_GROUP", "1")), 1)
         self.br_stream = None         # side stream of the CSP short_conv branch in forward()
         self.aux_stream = None        # side stream of work that only depends on the step's inputs (label assignment)
         self.branch_overlap = os.environ.get("KODHIP_BRANCH_OVERLAP", "1") != "0"
@@ -659,40 +657,39 @@ class Engine:
             wg = self.wg_stream
 
         # How a weight gradient joins the side stream matters in the captured graph: this stack's graph executor keeps a
-        # node's FIRST captured successor on the node's queue and hands later ones to other queues (~11 us per
-        # hand-over).  So the dependency is taken (event on the main stream) where dY is ready, but the launch itself is
-        # captured only after the main stream's next kernel - the critical chain ... -> dgrad -> next unit's
-        # coefficients -> ... then stays on one queue and only the off-path weight gradients pay the hand-over.
-        # KODHIP_WGRAD_FORK=legacy: wait_stream at the call site (round 1).  With collectives in the step the legacy form
-        # stays: a captured step that mixes these event edges with RCCL nodes crashed in hipGraphLaunch on this stack.
+        # node's FIRST captured successor on the node's queue and hands the later ones to other queues (~11 us per
+        # hand-over).  So a weight gradient takes its dependency where dY is ready (an event right after
+        # bn_silu_bwd_apply / head_bwd_prep - it then runs beside the same unit's data gradient, both reading dY) but
+        # is launched, i.e. captured, only after the main stream's next kernel (the data gradient): the critical chain
+        # apply -> dgrad -> next unit's coefficients -> ... stays on one queue and only the off-path weight gradients
+        # pay the hand-over.  KODHIP_WGRAD_FORK=legacy: wait_stream at the call site, behind the data gradient (round 1).
         deferred = []                  # [(event, name, nbytes, args)]
-        defer = wg is not None and self.wgrad_fork != "legacy" and not self.collectives
+        defer = wg is not None and self.wgrad_fork != "legacy"
 
-        def flush_wgrads(final=False):
-            while deferred and (final or deferred[0][0] is not None):
-                ev, name, nbytes, args = deferred.pop(0)
-                if ev is None:         # (its group never got an event: the end of backward)
-                    wg.wait_stream(main)
-                else:
-                    wg.wait_event(ev)
+        def fork_point():
+            """call right after the kernel that completes dY on the main stream"""
+            if defer:
+                self._fork_ev = torch.cuda.Event()
+                self._fork_ev.record(main)
+        self._fork_point = fork_point
+
+        def flush_wgrads():
+            """call after the main stream's next kernel has been launched"""
+            for ev, name, nbytes, args in deferred:
+                wg.wait_event(ev)
                 e0 = self._t0(wg)
                 chk(lib.kodhip_conv_wgrad(*args, wg.cuda_stream), name + ".wgrad")
                 self._t1(e0, "wgrad", nbytes, wg)
+            deferred.clear()
+        self._flush_wgrads = flush_wgrads
 
         def timed_wgrad(name, nbytes, *args):
             if defer:
-                ev = self._fork_ev          # KODHIP_WGRAD_FORK=apply: dependency taken right after bn_silu_bwd_apply
-                self._fork_ev = None
+                ev, self._fork_ev = self._fork_ev, None
                 if ev is None:
                     ev = torch.cuda.Event()
                     ev.record(main)
-                if ev == "group":           # this unit shares the event of a later unit of its group (KODHIP_WGRAD_GROUP)
-                    deferred.append([None, name, nbytes, args])
-                else:
-                    for d in deferred:
-                        if d[0] is None:
-                            d[0] = ev
-                    deferred.append([ev, name, nbytes, args])
+                deferred.append((ev, name, nbytes, args))
                 return
             ws = s
             if wg is not None:
@@ -728,7 +725,7 @@ class Engine:
             nonlocal unit_i
             unit_i -= 1
             if unit_i in buckets:
-                flush_wgrads(final=True)   # the bucket's last weight gradients must be on the side stream before the collective
+                flush_wgrads()         # the bucket's last weight gradients must be on the side stream before the collective
                 lo, hi = buckets[unit_i]
                 cs = self._comm_stream()
                 # overlapped buckets use their own communicator: SyncBN sums (main stream) and buckets (side stream)
@@ -769,7 +766,6 @@ class Engine:
                                                           aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off,
                                                           gp + 4 * st.b_off, st.coef.data_ptr(), C_, rawm, s), u.name)
             self._t1(e0, "bn_bwd_coeffs", sum(8.0 * u.cout * self.ustate[u.name].T2 for u in group))
-            flush_wgrads()             # (the previous unit's weight gradient: captured after this main-stream kernel)
 
         rops = list(reversed(self.g.ops))
         ri = 0
@@ -788,6 +784,7 @@ class Engine:
                                              gp + 4 * offs[0], gp + 4 * offs[1], gp + 4 * offs[2],
                                              B, hs["H"] * hs["W"], A, nc, self.head_npad, s), hu.name)
                 src = hu.src
+                fork_point()
                 e0 = self._t0()
                 chk(lib.kodhip_conv_dgrad(hs["dy"].data_ptr(), dp + 2 * hs["d_off"], self._ptr(src, True),
                                           B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
@@ -798,6 +795,7 @@ class Engine:
                             self._ptr(src), hs["dy"].data_ptr(), wgp, gp + 4 * hs["w_off"],
                             B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
                             self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kp"], self.head_npad, 0, A * (5 + nc), 0, 1.0)
+                flush_wgrads()
             elif op.kind == "up":
                 h, w = H // op.src.stride, W // op.src.stride
                 chk(lib.kodhip_upsample2x_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
@@ -829,7 +827,7 @@ class Engine:
             # gradient buckets complete from the arena's end toward its start
             if op.kind == "head":
                 bucket_tick()
-        flush_wgrads(final=True)
+        flush_wgrads()
         if wg is not None:
             main.wait_stream(wg)
         self._publish_grads()
@@ -852,13 +850,7 @@ class Engine:
                                          res.buf.C if res else 0, res.coff if res else 0,
                                          racc, st.M, C_, s), u.name)
         self._t1(e0, "bn_silu_bwd_apply", (6.0 + ((4.0 if racc else 2.0) if res else 0.0)) * st.M * C_)
-        if self.wgrad_fork == "apply" and self.wgrad_overlap and not self.collectives:
-            self._fork_n += 1
-            if self._fork_n % self.wgrad_group == 0:
-                self._fork_ev = torch.cuda.Event()
-                self._fork_ev.record()
-            else:
-                self._fork_ev = "group"
+        self._fork_point()
         # st.raw now holds dY
         if u.stem:
             geo = (B, st.H, st.W, 8, 0, 8, C_, 6, 3, 2, 1, 2, 1)
@@ -902,6 +894,7 @@ class Engine:
         timed_wgrad(u.name, 2.0 * (in_px_w * cin_true + st.M * C_),
                     self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
                     *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0)
+        self._flush_wgrads()           # this unit's - and a fused short_conv partner's - weight gradients: after the dgrad
 
 
     def _comm_stream(self):
