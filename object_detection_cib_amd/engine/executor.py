@@ -71,6 +71,7 @@ class Engine:
         self._eval_aff = None          # eval-mode BN constants of all units (flat), see _eval_affine_ptrs
         self._fork_ev = None
         self.br_stream = None         # side stream of the CSP short_conv branch in forward()
+        self.head_stream = None       # side stream of the P3 / P4 head convolutions in forward()
         self.aux_stream = None        # side stream of work that only depends on the step's inputs (label assignment)
         self.branch_overlap = os.environ.get("KODHIP_BRANCH_OVERLAP", "1") != "0"
         self.profile = None           # list of (family, start_event, end_event, algorithmic bytes), see _t0 / _t1
@@ -533,6 +534,10 @@ class Engine:
         # statistic exchanges travel as one grouped collective on the main stream - and not while timing families.)
         main_stream = torch.cuda.current_stream()
         branch = training and not sync and self.branch_overlap and self.profile is None
+        # the P3 / P4 head convolutions are leaves (only the loss reads them): they run on their own side stream as soon
+        # as their input exists, beside the bottom-up path, instead of after it.  head_src: buffer -> "ready" event
+        head_src = {op.src.buf.name: None for op in self.g.ops[:-1] if op.kind == "head"} if branch else {}
+        heads_on_aux = False
         joined_buf = None                # concat buffer whose short_conv half is being written on the side stream
         ops = self.g.ops
         i = 0
@@ -562,6 +567,14 @@ class Engine:
                 apply_stage(short, bs)
                 joined_buf = short.dst.buf.name
                 continue
+            if op.kind == "conv" and op.unit.dst.buf.name in head_src and not (branch and op.unit.sibling is not None):
+                conv_stage(op.unit)
+                stats_stage([op.unit])
+                apply_stage(op.unit)
+                ev = torch.cuda.Event()
+                ev.record(main_stream)
+                head_src[op.unit.dst.buf.name] = ev
+                continue
             if op.kind == "conv":
                 group = [op.unit]
                 # SyncBN: a unit and its sibling (same input, next in the program) share one statistic exchange
@@ -588,12 +601,21 @@ class Engine:
                 hu: HeadUnit = op.unit
                 hs = self.hstate[hu.name]
                 out = torch.empty((B, A, hs["H"], hs["W"], 5 + nc), dtype=torch.float32, device=self.device)
+                hstream = s
+                ev = head_src.get(hu.src.buf.name)
+                if ev is not None:
+                    if self.head_stream is None:
+                        self.head_stream = torch.cuda.Stream(device=self.device)
+                    self.head_stream.wait_event(ev)
+                    hstream, heads_on_aux = self.head_stream.cuda_stream, True
                 chk(lib.kodhip_conv_fwd_head(self._ptr(hu.src), fp + 2 * hs["f_off"], pa + 4 * hs["b_off"],
                                              out.data_ptr(), B, hs["H"], hs["W"], hu.src.buf.C, hu.src.coff,
-                                             hu.cin, A, nc, hs["Kp"], s), hu.name)
+                                             hu.cin, A, nc, hs["Kp"], hstream), hu.name)
                 outs.append(out)
         if joined_buf is not None:
             main_stream.wait_stream(self.br_stream)
+        if heads_on_aux:
+            main_stream.wait_stream(self.head_stream)
         if training:
             self.nbt_arena += 1
             self.stats_version += 1              # running statistics moved
