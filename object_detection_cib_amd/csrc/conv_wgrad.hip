@@ -563,7 +563,9 @@ int kodhip_conv_wgrad_splits(long M, int N, int Kp) {
   int tn, tk;
   tile_shape(N, Kp, &tn, &tk);
   int tiles = cdiv(N, tn) * cdiv(Kp, tk);
-  int s = 512 / tiles;
+  static int slots = 0;                  // resident-block target (KODHIP_WGRAD_SLOTS: A/B knob)
+  if (!slots) { const char* e = getenv("KODHIP_WGRAD_SLOTS"); slots = e ? atoi(e) : 512; if (slots < 8) slots = 512; }
+  int s = slots / tiles;
   if (s < 1) s = 1;
   long maxs = (M + 255) / 256;
   if (s > maxs) s = (int)maxs;

@@ -20,6 +20,30 @@ __global__ void nchw_to_nhwc4_kernel(const float* x, bf16_t* y, int B, int C, lo
   *reinterpret_cast<bf16x4*>(y + i * 4) = v;
 }
 
+// HW % 4 == 0 (every training geometry): 4 consecutive pixels per thread - one 16-byte load per plane, one 32-byte
+// store - so that each lane has 48 + 32 bytes in flight instead of 12 + 8 (the pass is the first kernel of the step
+// and nothing overlaps it: 3.9 -> 5 TB/s)
+__global__ void nchw_to_nhwc4_x4_kernel(const float* x, bf16_t* y, int B, int C, long HW) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;          // pixel quad
+  const long HWq = HW >> 2;
+  if (q >= (long)B * HWq) return;
+  const long b = q / HWq, pq = q - b * HWq;
+  float4 pl[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    pl[c] = c < C ? *reinterpret_cast<const float4*>(x + (b * C + c) * HW + pq * 4) : float4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 o0, o1;
+  const float* f0 = reinterpret_cast<const float*>(&pl[0]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    o0[c] = (bf16_t)f0[c * 4 + 0]; o0[4 + c] = (bf16_t)f0[c * 4 + 1];
+    o1[c] = (bf16_t)f0[c * 4 + 2]; o1[4 + c] = (bf16_t)f0[c * 4 + 3];
+  }
+  bf16_t* dst = y + (b * HW + pq * 4) * 4;
+  *reinterpret_cast<bf16x8*>(dst) = o0;
+  *reinterpret_cast<bf16x8*>(dst + 8) = o1;
+}
+
 struct PackDesc {          // all int64 so the host can fill it as a plain int64[13] row
   long w_off;              // offset (elements) of this weight in the fp32 master arena
   long f_off;              // offset of its first row in the bf16 forward pack arena ([N][Kp] rows)
@@ -374,7 +398,10 @@ extern "C" {
 int kodhip_nchw_to_nhwc4(const float* x, void* y, int B, int C, int H, int W, hipStream_t stream) {
   KOD_CHECK_ARG(x && y && B > 0 && C > 0 && C <= 4 && H > 0 && W > 0, "nchw_to_nhwc4: bad args");
   long n = (long)B * H * W;
-  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, (bf16_t*)y, B, C, (long)H * W);
+  if (((long)H * W) % 4 == 0 && ((uintptr_t)x % 16) == 0)
+    hipLaunchKernelGGL(nchw_to_nhwc4_x4_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, x, (bf16_t*)y, B, C, (long)H * W);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, (bf16_t*)y, B, C, (long)H * W);
   KOD_LAUNCH_CHECK("nchw_to_nhwc4");
   return KOD_OK;
 }
