@@ -688,11 +688,11 @@ class Engine:
         deferred = []                  # [(event, name, nbytes, args)]
         defer = wg is not None and self.wgrad_fork != "legacy"
 
-        def fork_point():
-            """call right after the kernel that completes dY on the main stream"""
+        def fork_point(stream=None):
+            """call right after the kernel that completes dY (on `stream`, default the main stream)"""
             if defer:
                 self._fork_ev = torch.cuda.Event()
-                self._fork_ev.record(main)
+                self._fork_ev.record(stream or main)
         self._fork_point = fork_point
 
         def flush_wgrads():
@@ -721,9 +721,20 @@ class Engine:
             chk(lib.kodhip_conv_wgrad(*args, ws), name + ".wgrad")
             self._t1(e0, "wgrad", nbytes, wg)
 
+        # gradient buffers last written on a side stream (the P3 / P4 heads' data gradients): buffer -> event the main
+        # stream must wait for before it reads or accumulates into the buffer
+        grad_events = {}
+
+        def sync_grad(name):
+            ev = grad_events.pop(name, None)
+            if ev is not None:
+                main.wait_event(ev)
+        self._sync_grad = sync_grad
+
         def acc_flag(v: View) -> int:
             """0 = first writer (overwrite), 1 = accumulate; zero-fills on a partial first touch."""
             name = v.buf.name
+            sync_grad(name)
             if name in touched:
                 return 1
             touched.add(name)
@@ -759,6 +770,8 @@ class Engine:
             """BatchNorm-backward sums -> coefficients.  Under SyncBN the [sum dz, sum dz*xhat] vectors of the group's
             units (a CSP layer's short + main convs) are exchanged as ONE grouped collective."""
             for u in group:
+                sync_grad(u.dst.buf.name)          # (a head's data gradient on the side stream may be its last writer)
+            for u in group:
                 st, C_ = self.ustate[u.name], u.cout
                 if not st.fused_red:
                     aff, dA = st.aff.data_ptr(), u.dst
@@ -789,6 +802,10 @@ class Engine:
                                                           gp + 4 * st.b_off, st.coef.data_ptr(), C_, rawm, s), u.name)
             self._t1(e0, "bn_bwd_coeffs", sum(8.0 * u.cout * self.ustate[u.name].T2 for u in group))
 
+        heads_side = wg is not None and defer and not self.collectives and self.branch_overlap and self.profile is None
+        bwd_start = torch.cuda.Event()
+        if heads_side:
+            bwd_start.record(main)
         rops = list(reversed(self.g.ops))
         ri = 0
         while ri < len(rops):
@@ -802,17 +819,33 @@ class Engine:
                 assert gten.shape == (B, A, hs["H"], hs["W"], 5 + nc) and gten.dtype == torch.float32
                 names = [f"{hu.name}.{k}_head.conv.bias" for k in ("box", "obj", "cls")]
                 offs = [self.layout[n][0] for n in names]
+                src = hu.src
+                # The three head chains (gradient re-layout -> data gradient) are independent until the neck: the P5
+                # chain, which the first backward layers wait for, stays on the main stream; the P4 and P3 chains
+                # run beside it on a side stream and the main stream joins each where that level's gradient buffer
+                # is next touched (acc_flag / the producing unit's apply).
+                side = (heads_side and head_i < len(self.g.heads) - 1 and src.C == src.buf.C and src.buf.name not in touched)
+                hstream, hs_ = main, s
+                if side:
+                    if self.head_stream is None:
+                        self.head_stream = torch.cuda.Stream(device=self.device)
+                    hstream, hs_ = self.head_stream, self.head_stream.cuda_stream
+                    hstream.wait_event(bwd_start)
                 chk(lib.kodhip_head_bwd_prep(gten.data_ptr(), hs["dy"].data_ptr(), hs["ws"].data_ptr(),
                                              gp + 4 * offs[0], gp + 4 * offs[1], gp + 4 * offs[2],
-                                             B, hs["H"] * hs["W"], A, nc, self.head_npad, s), hu.name)
-                src = hu.src
-                fork_point()
+                                             B, hs["H"] * hs["W"], A, nc, self.head_npad, hs_), hu.name)
+                fork_point(hstream)
+                acc = acc_flag(src)
                 e0 = self._t0()
                 chk(lib.kodhip_conv_dgrad(hs["dy"].data_ptr(), dp + 2 * hs["d_off"], self._ptr(src, True),
                                           B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
                                           self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kdp"], self.head_npad, 0,
-                                          acc_flag(src), s), hu.name + ".dgrad")
+                                          acc, hs_), hu.name + ".dgrad")
                 self._t1(e0, "dgrad", 2.0 * hs["M"] * (self.head_npad + hu.cin))
+                if side:
+                    ev = torch.cuda.Event()
+                    ev.record(hstream)
+                    grad_events[src.buf.name] = ev
                 timed_wgrad(hu.name, 2.0 * hs["M"] * (hu.cin + self.head_npad),
                             self._ptr(src), hs["dy"].data_ptr(), wgp, gp + 4 * hs["w_off"],
                             B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
@@ -850,6 +883,8 @@ class Engine:
             if op.kind == "head":
                 bucket_tick()
         flush_wgrads()
+        for name in list(grad_events):
+            sync_grad(name)
         if wg is not None:
             main.wait_stream(wg)
         self._publish_grads()
