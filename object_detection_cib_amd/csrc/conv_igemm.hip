@@ -92,7 +92,13 @@ __device__ __forceinline__ void wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0
 
 // launch bounds: 4 blocks per CU (one wave of each on every SIMD) => at most 128 VGPRs, so that one block's LDS /
 // global phases overlap another block's MFMA phase (measured: the phases of a single block do not overlap)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
+// ROW3 (FAST, 3x3 / stride 1 / pad 1, 128-pixel tiles): a K step is (kernel row kh, 32-channel chunk) and covers the
+// row's THREE taps - the source row segment [m0 - 1, m0 + BM] is staged once (BM + 16 rows with DMA granularity) and
+// the taps kw = 0, 1, 2 read it at row offsets 0, 1, 2 (their weight tiles are staged side by side); what the
+// zero-filling buffer load did per tap for the left / right image border becomes a per-lane mask on the pixel
+// fragments of taps 0 and 2.  Per unit of MFMA work the L2 -> LDS fill drops by 30-50 % (these layers are bound by it)
+// and there is one barrier per three taps.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST, bool ROW3 = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int NW = NT / 64;
@@ -106,13 +112,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   constexpr int TN = WN / 32;
   constexpr int B_CHUNKS = BN * 4;          // 16-byte chunks in the weight tile
   constexpr int B_PER_THREAD = (B_CHUNKS + NT - 1) / NT;
-  constexpr int STAGE_ELEMS = (BM + BN) * LDS_ROW;
+  static_assert(!ROW3 || (FAST && BM == 128), "ROW3 is a FAST-path form for 128-pixel tiles");
+  constexpr int A3_ROWS = BM + 16;                   // ROW3: staged source rows (BM + 2 used)
+  constexpr int STAGE_ELEMS = ROW3 ? (A3_ROWS + 3 * BN) * LDS_ROW : (BM + BN) * LDS_ROW;
   constexpr int CS_ROW = BN + 8;            // epilogue staging row (bf16)
   // LDS stages.  The fill of the wide tiles is latency-bound - a CU moves (bytes in flight) / (L2-or-HBM latency) -
   // so 256-row tiles (2 blocks per CU) run a 3-stage ring; 128-row tiles keep 2 stages and 4 blocks per CU (a third
   // stage costs 128x128 its 4th block, and measured nothing on the narrow tiles, whose 3x3 layers are bound by the
   // 9x im2col re-read through L2 instead).
-  constexpr int NST = (FAST && BM == 256) ? 3 : 2;
+  constexpr int NST = (FAST && BM == 256 && !ROW3) ? 3 : 2;
   constexpr int LDS_ELEMS = (NST * STAGE_ELEMS > BM * CS_ROW) ? NST * STAGE_ELEMS : BM * CS_ROW;
   __shared__ __attribute__((aligned(16))) bf16_t lds[LDS_ELEMS];
   float* sred = reinterpret_cast<float*>(lds);     // BN partial statistics reuse the staging area after the tile loop
@@ -142,7 +150,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
   float bn_run = 0.f;                        // MODE_PLAIN_BN: running sum of (channel tid>>1, statistic tid&1)
 
-  const int nk = a.nk1 ? 2 * a.nk1 : a.Kp / BK;
+  const int nk = ROW3 ? 3 * (a.cin_step / BK) : (a.nk1 ? 2 * a.nk1 : a.Kp / BK);
   // FAST path (Cin % 32 == 0, unit tap stride, no K tail): operands come through raw buffer loads - the tap of a
   // K step is wave-uniform (scalar registers), invalid (padding) elements are fetched from an out-of-range offset
   // that the buffer unit returns as zeros, so a step costs ~10 VALU instead of ~110 and has no branches.
@@ -202,7 +210,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     int f_tap = 0, f_kh = 0, f_kw = 0, f_ci = 0;      // wave-uniform K-step state
     if constexpr (FAST) {
 #pragma unroll
-      for (int i = 0; i < A_PER_WAVE; ++i) {
+      for (int i = 0; i < (ROW3 ? 0 : A_PER_WAVE); ++i) {
         int row = (uwave * A_PER_WAVE + i) * 16 + (lane >> 2);
         int m = m0 + row;
         bool valid = m < a.M;
@@ -262,6 +270,73 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         if (++f_kw == a.KW) { f_kw = 0; ++f_kh; }
         if (a.nk1 != 0) f_tap = f_kh = f_kw = 0;      // dual source: one tap, the channel counter restarts on the second source
       }
+    };
+
+    // ---- ROW3 staging state (see the header comment of this function)
+    constexpr int A3_INSTR = A3_ROWS / 16;
+    constexpr int A3_PW = (A3_INSTR + NW - 1) / NW;
+    uint32_t a3_voff[ROW3 ? A3_PW : 1], a3_mask[ROW3 ? A3_PW : 1];
+    uint32_t xmask = 0;                               // bit 2*jj: tap kw=0 valid, bit 2*jj+1: tap kw=2 valid (this lane's pixel)
+    if constexpr (ROW3) {
+#pragma unroll
+      for (int i = 0; i < A3_PW; ++i) {
+        const int blk = uwave + i * NW;               // DMA instruction = 16 staged rows
+        const int r = blk * 16 + (lane >> 2);
+        const long q = (long)m0 - 1 + r;              // source pixel of the centre tap (flattened b, y, x)
+        const bool valid = blk < A3_INSTR && r < BM + 2 && q >= 0 && q < a.M;
+        const int qq = valid ? (int)q : 0;
+        int b, rem, oy, ox;
+        fast_divmod(qq, HWo, a.rcp_hwo, b, rem);
+        fast_divmod(rem, a.Wo, a.rcp_wo, oy, ox);
+        const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+        a3_voff[i] = (uint32_t)(((long)qq * a.ldx + a.xcoff + chunk * 8) * 2);
+        uint32_t mk = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+          if ((unsigned)(oy + a.tap_sign * (kh - 1)) < (unsigned)a.Hs) mk |= 1u << kh;
+        a3_mask[i] = valid ? mk : 0u;
+      }
+#pragma unroll
+      for (int jj = 0; jj < TM; ++jj) {
+        const int p = m0 + wm * WM + jj * 32 + (lane & 31);
+        int b, rem, oy, ox;
+        fast_divmod(p < a.M ? p : 0, HWo, a.rcp_hwo, b, rem);
+        fast_divmod(rem, a.Wo, a.rcp_wo, oy, ox);
+        // tap kw reads source column ox + tap_sign * (kw - 1)
+        const bool ok0 = a.tap_sign > 0 ? ox != 0 : ox != a.Wo - 1;
+        const bool ok2 = a.tap_sign > 0 ? ox != a.Wo - 1 : ox != 0;
+        xmask |= (ok0 ? 1u : 0u) << (2 * jj) | (ok2 ? 1u : 0u) << (2 * jj + 1);
+      }
+    }
+    auto dma_tile3 = [&](int buf) {
+      // step state: f_kh = kernel row, f_ci = first channel of the chunk
+      const uint32_t soff = (uint32_t)((a.tap_sign * (f_kh - 1) * a.Ws * a.ldx + f_ci) * 2);
+      char* As = reinterpret_cast<char*>(lds + buf * STAGE_ELEMS);
+      char* Bs = As + A3_ROWS * LDS_ROW * 2;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KOD_ABL_NODMA)
+#pragma unroll
+      for (int i = 0; i < A3_PW; ++i) {
+        const int blk = uwave + i * NW;
+        if (blk < A3_INSTR) {
+          const uint32_t vo = ((a3_mask[i] >> f_kh) & 1u) ? a3_voff[i] + soff : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(As + blk * 16 * 64),
+                                                   16, vo, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int q = 0; q < B_PER_WAVE; ++q) {
+          const int blk = uwave * B_PER_WAVE + q;
+          if (blk < B_INSTR)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Bs + (kw * BN + blk * 16) * 64),
+                                                     16, dbvoff[q], ((f_kh * 3 + kw) * a.cin_step + f_ci) * 2, 0, 0);
+        }
+#else
+      (void)soff; (void)As; (void)Bs;
+#endif
+      f_ci += BK;
+      if (f_ci >= a.cin_step) { f_ci = 0; ++f_kh; }
     };
 
     u32x4 areg[2];
@@ -373,7 +448,50 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       }
     };
 
-    if constexpr (FAST) {
+    auto compute3 = [&](int stage) {
+      const bf16_t* As = lds + stage * STAGE_ELEMS;
+      const bf16_t* Bs = As + A3_ROWS * LDS_ROW;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        // output row `local` reads staged row local + 1 + tap_sign * (kw - 1)   (staged row 0 = pixel m0 - 1)
+        const int roff = a.tap_sign > 0 ? kw : 2 - kw;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 wf[TN], xf[TM];
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            const int row = wn * WN + i * 32 + fr;
+            const int ch = (ks * 2 + fh) ^ ((row >> 2) & 3);
+            wf[i] = *reinterpret_cast<const bf16x8*>(Bs + (kw * BN + row) * LDS_ROW + ch * 8);
+          }
+#pragma unroll
+          for (int jj = 0; jj < TM; ++jj) {
+            const int row = wm * WM + jj * 32 + fr + roff;
+            const int ch = (ks * 2 + fh) ^ ((row >> 2) & 3);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(As + row * LDS_ROW + ch * 8);
+            if (kw == 0 && !((xmask >> (2 * jj)) & 1u)) v = bf16x8{};
+            if (kw == 2 && !((xmask >> (2 * jj + 1)) & 1u)) v = bf16x8{};
+            xf[jj] = v;
+          }
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TM; ++jj)
+              acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[jj], acc[i][jj], 0, 0, 0);
+        }
+      }
+    };
+
+    if constexpr (ROW3) {
+      dma_tile3(0);
+      for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) dma_tile3((kt + 1) & 1);
+        compute3(kt & 1);
+      }
+      __syncthreads();
+    } else if constexpr (FAST) {
       // LDS ring fed by LDS-DMA: while tile kt is multiplied, tiles kt+1 .. kt+NST-2 are in flight.  A wave's DMAs
       // retire in order, so "all but the newer tiles' instructions" is a counted vmcnt; the raw s_barrier then
       // publishes every wave's share of tile kt (and fences the stage that tile kt+NST-1 overwrites: it was last
@@ -632,6 +750,12 @@ void conv_igemm_kernel(ConvArgs a) {
   conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(a, blockIdx.x);
 }
 
+template <int BN, int WAVES_M, int WAVES_N, int MODE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BN == 128 ? 2 : (BN == 64 ? 3 : 4)))    /* = what the LDS stages allow */
+void conv_igemm_row3_kernel(ConvArgs a) {
+  conv_igemm_body<128, BN, WAVES_M, WAVES_N, MODE, true, true>(a, blockIdx.x);
+}
+
 // Four problems of identical tiling in one launch (the parity classes of a stride-2 dgrad).  The classes have 4, 2, 2
 // and 1 taps - reductions of very different length - and the launch is a few rounds of resident blocks at most, so
 // blocks are dispatched longest class first (class 3, then 1 and 2, then 0): a long block never starts in the last
@@ -671,13 +795,13 @@ constexpr int MAX_STATS_SLOTS = 1024;
 // Tile shape: the widest channel tile that fits N (or the next narrower one when that removes a badly quantised
 // last round).  256-pixel tiles (8 waves, 3-stage ring) when the reduction is long enough to amortise their deeper
 // pipeline fill (measured on gfx950: 3x3 layers with N >= 128 gain 15-25 %, short-K 1x1 layers lose ~5 %).
-Plan make_plan(long M, int N, int K, bool fast) {
+Plan make_plan(long M, int N, int K, bool fast, bool row3 = false) {
   static int force_bn = -1, force_bm = -1;
   if (force_bn < 0) { const char* e = getenv("KODHIP_FORCE_BN"); force_bn = e ? atoi(e) : 0; }
   if (force_bm < 0) { const char* e = getenv("KODHIP_FORCE_BM"); force_bm = e ? atoi(e) : 0; }
   const int widest = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
   const bool can256 = fast && widest >= 64 && M >= 256 * 64;       // 256 x 128 and 256 x 64 tiles
-  const int bm = can256 && (force_bm ? force_bm == 256 : K >= 512) ? 256 : 128;
+  const int bm = !row3 && can256 && (force_bm ? force_bm == 256 : K >= 512) ? 256 : 128;
   Plan best = {};
   double best_cost = 1e30;
   for (int bn = widest; bn >= 32 && bn >= widest / 2; bn >>= 1) {
@@ -685,6 +809,7 @@ Plan make_plan(long M, int N, int K, bool fast) {
     if (force_bn && force_bn <= widest && bn != force_bn) continue;
     long tiles_m = (M + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
     int slots = slots_for(bm, bn, fast);
+    if (row3) slots = bn == 128 ? 512 : (bn == 64 ? 768 : 1024);       // ROW3 stages are larger: 2 / 3 / 4 blocks per CU
     long rounds = (tiles_m * tiles_n + slots - 1) / slots;
     double cost = (double)rounds * (bm + bn);       // per-round time ~ operand bytes staged per tile
     if (cost < best_cost * 0.97) {
@@ -701,6 +826,27 @@ Plan make_plan(long M, int N, int K, bool fast) {
 
 bool fast_eligible(const ConvArgs& a);
 
+// ROW3 form (conv_igemm_body): 3x3 / stride 1 / pad 1 gathers of same-size images on the FAST path.
+// KODHIP_ROW3: 0 = off, 1 = only where the plan would use 128-pixel tiles anyway, 2 (default) = every eligible layer.
+bool row3_eligible(const ConvArgs& a, bool fast) {
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("KODHIP_ROW3"); mode = e ? atoi(e) : 2; }
+  if (!mode || !fast) return false;
+  const bool shape = a.KH == 3 && a.KW == 3 && a.mul_h == 1 && a.mul_w == 1 && a.Ho == a.Hs && a.Wo == a.Ws &&
+                     a.add_h == -a.tap_sign && a.add_w == -a.tap_sign && a.wide_px == 1 && a.nk1 == 0 && a.d2s_C == 0 &&
+                     a.out_mul == 1 && a.head_out == nullptr;
+  if (!shape) return false;
+  if (mode == 1 && make_plan(a.M, a.N, a.K, fast).bm != 128) return false;
+  return true;
+}
+
+Plan plan_conv(const ConvArgs& a, bool fast, bool& row3, int mode) {
+  static int modes = -1;                 // KODHIP_ROW3_MODES: bit per MODE (debug: 1 = forward, 2 = dgrad, 8 = dgrad + BN reduction)
+  if (modes < 0) { const char* e = getenv("KODHIP_ROW3_MODES"); modes = e ? atoi(e) : 0xF; }
+  row3 = row3_eligible(a, fast) && ((modes >> mode) & 1);
+  return make_plan(a.M, a.N, a.nk1 ? 2 * a.K : a.K, fast, row3);
+}
+
 template <int MODE>
 int launch(const ConvArgs& a, hipStream_t stream) {
   ConvArgs args = a;
@@ -708,7 +854,8 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   const bool fast = fast_eligible(a);
   KOD_CHECK_ARG(fast || a.wide_px == 1, "conv: wide-pixel taps need the FAST path");
   args.x_bytes = (uint32_t)xb; args.w_bytes = (uint32_t)wb;
-  const Plan p = make_plan(a.M, a.N, a.nk1 ? 2 * a.K : a.K, fast);
+  bool row3;
+  const Plan p = plan_conv(a, fast, row3, MODE);
   args.tiles_n = p.tiles_n; args.tiles_m = p.tiles_m; args.groups_m = p.groups_m;
   if (MODE == MODE_RAW) {
     KOD_CHECK_ARG(a.stats_slots >= p.groups_m, "conv: stats buffer has %d slots, launch needs %d", a.stats_slots, p.groups_m);
@@ -719,6 +866,15 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     args.slot_base = 0; args.slot_used = need;
   }
   dim3 g(p.grid);
+  if constexpr (MODE != MODE_HEAD) {
+    if (row3) {
+      if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_row3_kernel<128, 2, 2, MODE>), g, dim3(256), 0, stream, args);
+      else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_row3_kernel<64, 2, 2, MODE>), g, dim3(256), 0, stream, args);
+      else hipLaunchKernelGGL((conv_igemm_row3_kernel<32, 4, 1, MODE>), g, dim3(256), 0, stream, args);
+      KOD_LAUNCH_CHECK("conv_igemm_row3");
+      return KOD_OK;
+    }
+  }
   if (fast) {
     if (p.bm == 256 && p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
     else if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
@@ -1016,7 +1172,8 @@ int kodhip_conv_dgrad_bnred_slots(int B, int H, int W, int Cin, int N, int KH, i
   ConvArgs a;
   const int Kp = KH * KW * ((N + 31) / 32 * 32);
   if (prep_dgrad(a, fake, fake, (void*)fake, B, H, W, Cin, 0, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, 0, 0) || !fast_eligible(a)) return 0;
-  return make_plan(a.M, a.N, a.K, true).groups_m;
+  bool row3;
+  return plan_conv(a, true, row3, MODE_PLAIN_BN).groups_m;
 }
 
 int kodhip_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* dx,
