@@ -49,9 +49,9 @@ def algorithmic_work(widen, deepen, nc, S):
     stem_dgrad = 2 * (S // 2) ** 2 * g.units[0].cout * 3 * 36
     return 3.0 * (sin + sout) * 2, 3.0 * fl - stem_dgrad
 FAMILY_KERNELS = {
-    "conv_fwd": "conv_igemm_kernel<MODE_RAW> (forward conv + BN statistics, 57 layers)",
-    "dgrad": "conv_igemm[_x4]_kernel<MODE_PLAIN> (data gradient)",
-    "dgrad+bn_reduce": "conv_igemm[_x4]_kernel<MODE_PLAIN_BN> (data gradient + fused BatchNorm-backward reduction)",
+    "conv_fwd": "conv_igemm_kernel / conv_igemm_row3_kernel <MODE_RAW> (forward conv + BN statistics, 57 layers)",
+    "dgrad": "conv_igemm[_x4|_row3]_kernel<MODE_PLAIN> (data gradient)",
+    "dgrad+bn_reduce": "conv_igemm[_x4|_row3]_kernel<MODE_PLAIN_BN> (data gradient + fused BatchNorm-backward reduction)",
     "wgrad": "conv_wgrad_dma_kernel + wgrad_reduce_kernel (weight gradient)",
     "bn_silu_apply": "bn_silu_apply_kernel (BatchNorm + SiLU forward, residual add)",
     "bn_silu_bwd_apply": "bn_silu_bwd_apply_kernel (BatchNorm + SiLU backward)",

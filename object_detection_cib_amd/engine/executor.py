@@ -536,7 +536,8 @@ class Engine:
         branch = training and not sync and self.branch_overlap and self.profile is None
         # the P3 / P4 head convolutions are leaves (only the loss reads them): they run on their own side stream as soon
         # as their input exists, beside the bottom-up path, instead of after it.  head_src: buffer -> "ready" event
-        head_src = {op.src.buf.name: None for op in self.g.ops[:-1] if op.kind == "head"} if branch else {}
+        heads_aside = training and self.branch_overlap and self.profile is None          # (also under SyncBN: no collective involved)
+        head_src = {op.src.buf.name: None for op in self.g.ops[:-1] if op.kind == "head"} if heads_aside else {}
         heads_on_aux = False
         joined_buf = None                # concat buffer whose short_conv half is being written on the side stream
         ops = self.g.ops
