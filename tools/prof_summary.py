@@ -13,10 +13,15 @@ for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:22]:
 tr = list(csv.DictReader(open((glob.glob(d + '/*/*kernel_trace.csv') + glob.glob(d + '/*kernel_trace.csv'))[0])))
 tr.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(tr) if 'nchw_to_nhwc4' in r['Kernel_Name']]
-step = tr[idx[-2]:idx[-1]] if len(idx) > 1 else tr[idx[-1]:]
+# step windows are delimited by the input re-layout kernel; of `bench.py --steps K --warmup W` the last three windows
+# are the eager profiling steps (one stream, no overlap), the K + 1 before them are hipGraph replays: take a replay
+k = len(idx) - 6 if len(idx) >= 8 else max(len(idx) - 2, 0)
+step = tr[idx[k]:idx[k + 1]] if len(idx) > 1 else tr[idx[-1]:]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-print("== last full step: %d dispatches, sum of kernel time %.2f ms, span %.2f ms" % (
-    len(step), sum(dur(r) for r in step) / 1e3, (int(step[-1]['End_Timestamp']) - int(step[0]['Start_Timestamp'])) / 1e6))
+span = (int(tr[idx[k + 1]]['Start_Timestamp']) - int(step[0]['Start_Timestamp'])) / 1e6 if len(idx) > 1 else 0.0
+print("== one replayed step (window %d of %d; under the profiler): %d dispatches on queues %s, sum of kernel time %.2f ms "
+      "(kernels of different queues overlap), span %.2f ms" % (
+          k, len(idx) - 1, len(step), sorted(set(r['Queue_Id'] for r in step)), sum(dur(r) for r in step) / 1e3, span))
 fam = {}
 for r in step:
     n = r['Kernel_Name']
