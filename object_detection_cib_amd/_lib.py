@@ -105,6 +105,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -m object_detection_cib_amd.build` "
                 "(hipcc, gfx950).  There is no CPU fallback for the HIP hot path.")
+        # torch first: the process must hold ONE HIP runtime - the one PyTorch-ROCm ships and has loaded - and
+        # libkodhip.so binds to it by soname.  Loaded the other way round the system runtime comes in first and torch's
+        # device discovery then fails ("no ROCm-capable device") in the same process.
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
