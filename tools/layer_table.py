@@ -15,6 +15,9 @@ isk = lambda r, s: s in r['Kernel_Name']
 import re
 def mode(r):
     m = re.search(r'conv_igemm(?:_x4)?_kernel<\d+, \d+, \d+, \d+, (\d), ', r['Kernel_Name'])
+    if m:
+        return int(m.group(1))
+    m = re.search(r'conv_igemm_row3_kernel<\d+, \d+, \d+, (\d)>', r['Kernel_Name'])
     return int(m.group(1)) if m else -1
 fw = [r for r in step if mode(r) == 0]
 dg = [r for r in step if mode(r) in (1, 3)]
