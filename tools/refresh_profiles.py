@@ -40,7 +40,15 @@ def per_family(rows, counter):
     return out
 
 
+def timeline():
+    """idle gaps / queue hand-overs of one replayed step (tools/step_timeline.py) -> profiles/<tag>_step_timeline.txt"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_timeline.py"), os.path.join(EV, "trace"), "6"],
+                         capture_output=True, text=True).stdout
+    open(os.path.join(PR, f"{tag}_step_timeline.txt"), "w").write(out)
+
+
 def main():
+    timeline()
     from object_detection_cib_amd import build as kb
     dig = kb.source_digest()
     bench = json.loads(open(os.path.join(EV, "bench.json")).read().strip().splitlines()[-1])
