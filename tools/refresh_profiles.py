@@ -47,12 +47,43 @@ def timeline():
     open(os.path.join(PR, f"{tag}_step_timeline.txt"), "w").write(out)
 
 
+def family_durations(bench):
+    """rocprofv3 durations per family in two windows of the SAME trace: the last eager one-stream step (what bench.py's
+    event timing measures: must agree with its avg_launch_us up to ~3 us of dispatch latency per launch) and one
+    replayed step (kernels of two queues overlap and slow each other down)."""
+    f = glob.glob(os.path.join(EV, "trace", "*kernel_trace.csv")) + glob.glob(os.path.join(EV, "trace", "*", "*kernel_trace.csv"))
+    if not f:
+        return
+    tr = list(csv.DictReader(open(f[0]))); tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(tr) if "nchw_to_nhwc4" in r["Kernel_Name"]]
+    if len(idx) < 8:
+        return
+    wins = {"eager": tr[idx[-2]:idx[-1]], "replay": tr[idx[len(idx) - 6]:idx[len(idx) - 5]]}
+    fams = dict(FAMILIES); fams["wgrad"] = r"conv_wgrad(_dma)?_kernel<|wgrad_reduce_kernel"
+    bt = {r["family"]: r for r in bench.get("families", [])}
+    lines = ["family                 launches(bench)  bench event-timed us/launch | rocprof eager step: us/launch (kernels) | rocprof replayed step: us/launch"]
+    for fam, pat in fams.items():
+        rx = re.compile(pat)
+        if fam not in bt:
+            continue
+        n = bt[fam]["launches"]
+        row = f"{fam:22s} {n:15d} {1e3 * bt[fam]['ms'] / n:28.2f}"
+        for w in ("eager", "replay"):
+            rs = [r for r in wins[w] if rx.search(r["Kernel_Name"])]
+            tot = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / 1e3
+            row += f" | {tot / n:22.2f} ({len(rs)})"
+        lines.append(row)
+    open(os.path.join(PR, f"{tag}_family_durations.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
 def main():
     timeline()
     from object_detection_cib_amd import build as kb
     dig = kb.source_digest()
     bench = json.loads(open(os.path.join(EV, "bench.json")).read().strip().splitlines()[-1])
     fam_alg = {r["family"]: r for r in bench.get("families", [])}
+    family_durations(bench)
     fr, wr = counter_rows(os.path.join(EV, "pmc_FETCH_SIZE")), counter_rows(os.path.join(EV, "pmc_WRITE_SIZE"))
     F, W = per_family(fr, "FETCH_SIZE"), per_family(wr, "WRITE_SIZE")
     fams, lines = {}, ["family                 launches   read MB/launch  write MB/launch  total MB/launch  algorithmic MB/launch  traffic/algorithmic"]
