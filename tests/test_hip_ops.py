@@ -485,3 +485,40 @@ def test_conv_dgrad_dual_source(case):
                 for got_, want_, what in zip(outs[0], outs[1], ("dgamma", "dbeta", "coef")):
                     assert torch.isfinite(got_).all(), what
                     _close(got_.cpu(), want_.cpu(), 2e-4, 2e-4 * want_.abs().max().item(), what)
+
+
+@pytest.mark.parametrize("case", [(4, 16, 32, 32, 16), (4, 64, 8, 8, 128), (6, 32, 16, 16, 32), (4, 128, 4, 4, 128), (2, 48, 9, 7, 96)])
+def test_conv3x3_result_independent_of_tile_position(case):
+    """The 3x3 / stride-1 kernels (ROW3: a staged row segment shared by the three taps of a kernel row, border taps masked
+    per lane) must give every pixel the same reduction whatever tile and tile row it lands in: a batch and its two halves
+    agree bit for bit, forward (with BatchNorm statistics vs torch) and data gradient."""
+    B, C, H, W, N = case
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(sum(case))
+    x = bf(torch.randn(B, C, H, W, generator=g))
+    w = bf(torch.randn(N, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    dy = bf(torch.randn(B, N, H, W, generator=g))
+    pk = pack([w])
+    xb, dyb = nhwc(x), nhwc(dy)
+
+    def fwd(xs):
+        y, st = conv_fwd_raw(xs, (0, C), pk, 1, 1)
+        return y, st.sum(-1)
+
+    def dgrad(ds):
+        b = ds.shape[0]
+        dx = torch.zeros(b, H, W, C, device="cuda", dtype=torch.bfloat16)
+        _lib.check(lib.kodhip_conv_dgrad(ds.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), b, H, W, C, 0, C, N, 3, 3, 1, 1,
+                                         1, 1, pk["Kdp"], N, 0, 0, stream()), "dgrad")
+        return dx
+    y, st = fwd(xb)
+    ref = F.conv2d(x, w, None, 1, 1)
+    _close(nchw(y), ref, 1e-2, 3e-2, "forward")
+    want = torch.stack([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))])
+    _close(st.cpu(), want, 5e-3, 5e-3 * want.abs().max().item(), "batch statistics")
+    h = B // 2
+    y0, _ = fwd(xb[:h].contiguous())
+    y1, _ = fwd(xb[h:].contiguous())
+    assert torch.equal(torch.cat([y0, y1]), y), "forward: a pixel's result depends on its tile position"
+    dx = dgrad(dyb)
+    assert torch.equal(torch.cat([dgrad(dyb[:h].contiguous()), dgrad(dyb[h:].contiguous())]), dx), "dgrad: tile position"
