@@ -510,6 +510,27 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         }
         __builtin_amdgcn_s_barrier();
         if (kt + NST - 1 < nk) dma_tile(kt + NST - 1, (kt + NST - 1) % NST);
+#ifdef KOD_ABL_FIXUP
+        // ablation only (tools/build_ablate.sh fixup -DKOD_ABL_FIXUP): what it would cost to apply the PRODUCER's BatchNorm +
+        // SiLU in this consumer instead of in a separate pass - an in-LDS pass over the landed pixel tile (constant
+        // scale / shift: the arithmetic, LDS traffic and extra barrier without even the parameter loads)
+        {
+          bf16_t* Af = lds + (kt % NST) * STAGE_ELEMS;
+          for (int q = tid; q < BM * 4; q += NT) {
+            bf16x8 v = *reinterpret_cast<bf16x8*>(Af + q * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float z = (float)v[e] * 1.001f + 0.01f;
+              const float d = 1.0f + __expf(-z);
+              float r = __builtin_amdgcn_rcpf(d);
+              r = r * (2.0f - d * r);
+              v[e] = (bf16_t)(z * r);
+            }
+            *reinterpret_cast<bf16x8*>(Af + q * 8) = v;
+          }
+          __builtin_amdgcn_s_barrier();
+        }
+#endif
         compute(kt % NST);
       }
       __syncthreads();
