@@ -125,6 +125,12 @@ int kodhip_bn_finalize_partials(const float* partials, int T, double count, cons
                                 float* running_mean, float* running_var, float momentum, float eps,
                                 float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
                                 kodStream_t stream);
+/* kodhip_bn_bwd_coeffs_partials for two units in one launch (a CSP layer's short_conv + main_conv) */
+int kodhip_bn_bwd_coeffs_partials2(const float* partials0, int T0, double count0, const float* gamma0, const float* mean0,
+                                   const float* rstd0, float* dgamma0, float* dbeta0, float* coef0, int C0, int raw_moment0,
+                                   const float* partials1, int T1, double count1, const float* gamma1, const float* mean1,
+                                   const float* rstd1, float* dgamma1, float* dbeta1, float* coef1, int C1, int raw_moment1,
+                                   kodStream_t stream);
 int kodhip_bn_bwd_coeffs_partials(const float* partials, int T, double count, const float* gamma, const float* mean,
                                   const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
                                   int raw_moment /* 1: partials[1] = sum dz*y (kodhip_conv_dgrad_bnred) */,
@@ -180,6 +186,8 @@ typedef struct KodLossLevel {
   int fh, fw;
   float balance;
 } KodLossLevel;
+/* out: 16 floats - [0..2] localization / objectness / classification, [3..11] per-level raw means, [12] (with upstream)
+ * upstream[0] * ((loc + cls) + obj): the training-step scalar of exp.py:104-121 when the three upstreams are one scale */
 int kodhip_yolo_loss(const KodLossLevel* levels /* host[3] */, int B, int A, int nc, int cap,
                      float lam_box, float lam_obj, float lam_cls, const float* pos_weight,
                      const float* upstream, float* partials, int nslots, float* out, int compute_grad,

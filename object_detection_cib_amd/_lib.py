@@ -59,6 +59,7 @@ SIGNATURES = {
     "kodhip_bn_finalize": (i32, [vp, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_finalize_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_bwd_coeffs_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "kodhip_bn_bwd_coeffs_partials2": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, i32] * 2 + [vp]),
     "kodhip_bn_silu_apply": (i32, [vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, vp]),
     "kodhip_bn_bwd_slots": (i32, [i64, i32]),
     "kodhip_bn_silu_bwd_reduce": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, i64, i32, vp]),

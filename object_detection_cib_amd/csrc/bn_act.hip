@@ -88,12 +88,9 @@ __global__ void bn_finalize_fused_kernel(const float* part, int T, double count,
 
 // raw_moment: the second partial is sum dz*y (produced by the data-gradient epilogue, conv_igemm.hip MODE_PLAIN_BN)
 // instead of sum dz*xhat; xhat = (y - mean)*rstd  =>  sum dz*xhat = rstd * (sum dz*y - mean * sum dz), in fp64.
-__global__ void bn_bwd_coeffs_fused_kernel(const float* part, int T, double count, const float* gamma,
-                                           const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                                           float* coef, int C, int raw_moment) {
-  int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (c >= C) return;
-  int lane = threadIdx.x & 63;
+__device__ __forceinline__ void bn_bwd_coeffs_channel(const float* part, int T, double count, const float* gamma,
+                                                      const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                                      float* coef, int C, int raw_moment, int c, int lane) {
   const float* p0 = part + (size_t)c * T;
   const float* p1 = part + (size_t)(C + c) * T;
   double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
@@ -106,6 +103,26 @@ __global__ void bn_bwd_coeffs_fused_kernel(const float* part, int T, double coun
   coef[c] = (float)(g * rs);
   coef[C + c] = (float)(-g * rs * rs * S1);
   coef[2 * C + c] = (float)(-g * rs * S0 + g * rs * rs * mu * S1);
+}
+
+__global__ void bn_bwd_coeffs_fused_kernel(const float* part, int T, double count, const float* gamma,
+                                           const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                           float* coef, int C, int raw_moment) {
+  int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  bn_bwd_coeffs_channel(part, T, count, gamma, mean, rstd, dgamma, dbeta, coef, C, raw_moment, c, threadIdx.x & 63);
+}
+
+// the same for TWO units in one launch (blockIdx.y = unit): a CSP layer's short_conv and main_conv reach this point of
+// the backward pass together, and on the critical chain a launch costs more than the arithmetic
+struct CoefJob { const float* part; int T; double count; const float* gamma; const float* mean; const float* rstd;
+                 float* dgamma; float* dbeta; float* coef; int C; int raw_moment; };
+__global__ void bn_bwd_coeffs_fused2_kernel(CoefJob j0, CoefJob j1) {
+  const CoefJob& j = blockIdx.y == 0 ? j0 : j1;
+  int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= j.C) return;
+  bn_bwd_coeffs_channel(j.part, j.T, j.count, j.gamma, j.mean, j.rstd, j.dgamma, j.dbeta, j.coef, j.C, j.raw_moment, c,
+                        threadIdx.x & 63);
 }
 
 // The elementwise passes are pure HBM streams: each thread keeps U rows (U x 16 B per operand) in flight before it
@@ -360,6 +377,21 @@ int kodhip_bn_bwd_coeffs_partials(const float* partials, int T, double count, co
   hipLaunchKernelGGL(bn_bwd_coeffs_fused_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, T, count, gamma,
                      mean, rstd, dgamma, dbeta, coef, C, raw_moment);
   KOD_LAUNCH_CHECK("bn_bwd_coeffs_partials");
+  return KOD_OK;
+}
+
+int kodhip_bn_bwd_coeffs_partials2(const float* partials0, int T0, double count0, const float* gamma0, const float* mean0,
+                                   const float* rstd0, float* dgamma0, float* dbeta0, float* coef0, int C0, int raw_moment0,
+                                   const float* partials1, int T1, double count1, const float* gamma1, const float* mean1,
+                                   const float* rstd1, float* dgamma1, float* dbeta1, float* coef1, int C1, int raw_moment1,
+                                   hipStream_t stream) {
+  KOD_CHECK_ARG(partials0 && gamma0 && mean0 && rstd0 && dgamma0 && dbeta0 && coef0 && C0 > 0 && T0 > 0 && count0 > 0 &&
+                partials1 && gamma1 && mean1 && rstd1 && dgamma1 && dbeta1 && coef1 && C1 > 0 && T1 > 0 && count1 > 0,
+                "bn_bwd_coeffs_partials2: bad args");
+  CoefJob j0 = {partials0, T0, count0, gamma0, mean0, rstd0, dgamma0, dbeta0, coef0, C0, raw_moment0};
+  CoefJob j1 = {partials1, T1, count1, gamma1, mean1, rstd1, dgamma1, dbeta1, coef1, C1, raw_moment1};
+  hipLaunchKernelGGL(bn_bwd_coeffs_fused2_kernel, dim3(cdiv(C0 > C1 ? C0 : C1, 4), 2), dim3(256), 0, stream, j0, j1);
+  KOD_LAUNCH_CHECK("bn_bwd_coeffs_partials2");
   return KOD_OK;
 }
 

@@ -425,9 +425,13 @@ __global__ void loss_finalize_kernel(LossArgs a, int nblk_rows, int nblk_cells) 
     box += lb; obj += lo; cls += lc;
   }
   if (lane == 0) {
-    a.out[0] = a.lam_box * (float)box;
-    a.out[1] = a.lam_obj * (float)obj;
-    a.out[2] = a.lam_cls * (float)cls;
+    const float o0 = a.lam_box * (float)box, o1 = a.lam_obj * (float)obj, o2 = a.lam_cls * (float)cls;
+    a.out[0] = o0;
+    a.out[1] = o1;
+    a.out[2] = o2;
+    // the training-step scalar scale * ((localization + classification) + objectness) (exp.py:104-121) in the order and
+    // precision torch evaluates it, for callers whose three upstream gradients are the same scale
+    if (a.upstream) a.out[12] = a.upstream[0] * ((o0 + o2) + o1);
   }
 }
 
@@ -475,7 +479,8 @@ struct KodLossLevel {
   float balance;
 };
 
-// partials: 9 * nslots floats with nslots >= max(ceil(cap/256), 1024); out: 12 floats.
+// partials: 9 * nslots floats with nslots >= max(ceil(cap/256), 1024) (need not be initialised); out: 16 floats
+// ([0..2] losses, [3..11] per-level raw means, [12] upstream[0] * ((loc + cls) + obj) when upstream is given).
 int kodhip_yolo_loss(const KodLossLevel* levels /*[3], host*/, int B, int A, int nc, int cap,
                      float lam_box, float lam_obj, float lam_cls, const float* pos_weight,
                      const float* upstream, float* partials, int nslots, float* out, int compute_grad,

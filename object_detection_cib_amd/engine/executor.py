@@ -460,8 +460,10 @@ class Engine:
                 torch.distributed.all_reduce(t, group=self.process_group)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor, training: bool = True):
-        """x: [B,3,H,W] fp32 NCHW on this device.  Returns 3 tensors [B,A,h,w,5+nc] fp32 (ll, ml, hl)."""
+    def forward(self, x: torch.Tensor, training: bool = True, after_first_layer=None):
+        """x: [B,3,H,W] fp32 NCHW on this device.  Returns 3 tensors [B,A,h,w,5+nc] fp32 (ll, ml, hl).
+        after_first_layer: called once after the first layer's kernels are launched (a hook for side-stream work that only
+        depends on the step's inputs: it is then captured behind the forward chain's head, see Yolov5Network.train_step)."""
         lib, chk = self.lib, _lib.check
         B, Cimg, H, W = x.shape
         assert Cimg == 3 and x.dtype == torch.float32 and x.is_contiguous() and x.device == self.device
@@ -576,6 +578,9 @@ class Engine:
                 ev.record(main_stream)
                 head_src[op.unit.dst.buf.name] = ev
                 continue
+            if op.kind == "conv" and after_first_layer is not None and i > 1:
+                after_first_layer()
+                after_first_layer = None
             if op.kind == "conv":
                 group = [op.unit]
                 # SyncBN: a unit and its sibling (same input, next in the program) share one statistic exchange
@@ -613,6 +618,8 @@ class Engine:
                                              out.data_ptr(), B, hs["H"], hs["W"], hu.src.buf.C, hu.src.coff,
                                              hu.cin, A, nc, hs["Kp"], hstream), hu.name)
                 outs.append(out)
+        if after_first_layer is not None:
+            after_first_layer()
         if joined_buf is not None:
             main_stream.wait_stream(self.br_stream)
         if heads_on_aux:
@@ -788,7 +795,18 @@ class Engine:
                     chk(lib.kodhip_bn_reduce_partials(st.bpart.data_ptr(), st.bsums.data_ptr(), u.cout, st.T2, s), u.name)
                 # out of place: the local sums stay for dgamma / dbeta
                 self._allreduce_group([self.ustate[u.name].bsums for u in group], [self.ustate[u.name].bsums_g for u in group])
-            for u in group:
+            if not sync and len(group) == 2:           # short_conv + main_conv: one launch for both coefficient sets
+                args = []
+                for u in group:
+                    st, C_ = self.ustate[u.name], u.cout
+                    aff = st.aff.data_ptr()
+                    args += [st.bpart.data_ptr(), st.T2, float(st.M), pa + 4 * st.g_off, aff + 8 * C_, aff + 12 * C_,
+                             gp + 4 * st.g_off, gp + 4 * st.b_off, st.coef.data_ptr(), C_, 1 if st.fused_red else 0]
+                chk(lib.kodhip_bn_bwd_coeffs_partials2(*args, s), group[0].name + "+" + group[1].name)
+                group_done = True
+            else:
+                group_done = False
+            for u in ([] if group_done else group):
                 st, C_ = self.ustate[u.name], u.cout
                 aff = st.aff.data_ptr()
                 rawm = 1 if st.fused_red else 0        # partials came from the last dgrad into this tensor

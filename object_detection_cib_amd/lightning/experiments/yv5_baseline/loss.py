@@ -72,8 +72,8 @@ class _LossFn(torch.autograd.Function):
             prev=[torch.empty(cap, dtype=torch.int32, device=dev) for _ in raws],
             rowgrad=[torch.empty(cap * (P - 1), dtype=torch.float32, device=dev) for _ in raws],
             tobj=[torch.empty(cap, dtype=torch.float32, device=dev) for _ in raws],
-            partials=torch.zeros(9 * nslots, dtype=torch.float32, device=dev), nslots=nslots,
-            out=torch.empty(12, dtype=torch.float32, device=dev))
+            partials=torch.empty(9 * nslots, dtype=torch.float32, device=dev), nslots=nslots,
+            out=torch.empty(16, dtype=torch.float32, device=dev))
         _run(mod, shape, raws, asg, cap, None, None, work)
         ctx.state = (mod, shape, raws, asg, cap, work)
         out = work["out"]
@@ -85,7 +85,7 @@ class _LossFn(torch.autograd.Function):
         upstream = torch.stack([g_box, g_obj, g_cls]).to(torch.float32).contiguous()
         grads = [torch.empty_like(t) for t in raws]
         work = dict(work)
-        work["out"] = torch.empty(12, dtype=torch.float32, device=raws[0].device)
+        work["out"] = torch.empty(16, dtype=torch.float32, device=raws[0].device)
         _run(mod, shape, raws, asg, cap, grads, upstream, work)
         return (None, None, None, *grads)
 
@@ -147,9 +147,12 @@ class Yolov5Loss(nn.Module):
             prev=[torch.empty(cap, dtype=torch.int32, device=dev) for _ in raws],
             rowgrad=[torch.empty(cap * (P - 1), dtype=torch.float32, device=dev) for _ in raws],
             tobj=[torch.empty(cap, dtype=torch.float32, device=dev) for _ in raws],
-            partials=torch.zeros(9 * nslots, dtype=torch.float32, device=dev), nslots=nslots,
-            out=torch.empty(12, dtype=torch.float32, device=dev))
+            partials=torch.empty(9 * nslots, dtype=torch.float32, device=dev), nslots=nslots,
+            out=torch.empty(16, dtype=torch.float32, device=dev))
         grads = [torch.empty_like(t) for t in raws]
         _run(self, image_feature_shape, raws, asg, cap, grads, cache[key], work)
         out = work["out"]
+        # out[12] = upstream[0] * ((localization + classification) + objectness), written by the loss kernel: the step's
+        # scalar when the three upstreams are one scale (Yolov5Network.train_step)
+        self._scaled_total = out[12] if key[0][0] == key[0][1] == key[0][2] else None
         return LossResult(localization=out[0], objectness=out[1], classification=out[2]), grads

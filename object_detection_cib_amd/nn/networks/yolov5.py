@@ -177,18 +177,29 @@ class Yolov5Network(nn.Module):
             # beside the forward pass instead of between the heads and the loss
             cur = torch.cuda.current_stream()
             if eng.aux_stream is None:
-                eng.aux_stream = torch.cuda.Stream(device=eng.device)
+                # the CSP branches' stream: side-stream work of one captured stream runs in launch order
+                if eng.br_stream is None:
+                    eng.br_stream = torch.cuda.Stream(device=eng.device)
+                eng.aux_stream = eng.br_stream
             fork = torch.cuda.Event()
             fork.record(cur)
-            outs = eng.forward(x.contiguous(), training=True)
-            # (launched - and captured - after the forward pass, dependent only on the step's start: the graph executor
-            # keeps a node's first captured successor on its queue, and that must be the forward chain)
-            eng.aux_stream.wait_event(fork)
-            asg = loss.assigner.assign_device(image_feature_shape, targets, eng.device, stream=eng.aux_stream)
+            asg = []
+
+            def launch_assignment():
+                # Launched - and captured - right after the forward chain's first layer, dependent only on the step's
+                # start: the graph executor keeps a node's first captured successor on its queue (that must be the forward
+                # chain) and runs the side streams' work in capture order on one queue (so this must come before the CSP
+                # branches, or the loss would wait for it at the end of the forward pass).
+                eng.aux_stream.wait_event(fork)
+                asg.append(loss.assigner.assign_device(image_feature_shape, targets, eng.device, stream=eng.aux_stream))
+            outs = eng.forward(x.contiguous(), training=True, after_first_layer=launch_assignment)
             cur.wait_stream(eng.aux_stream)
+            asg = asg[0]
             lr, grads = loss.value_and_grad(image_feature_shape, outs, targets, (scale, scale, scale), assignment=asg)
             eng.backward(grads)
-            total = scale * (lr.localization + lr.classification + lr.objectness)
+            total = loss._scaled_total          # scale * ((loc + cls) + obj), computed by the loss kernel in torch's order
+            if total is None:
+                total = scale * (lr.localization + lr.classification + lr.objectness)
         return total, lr
 
     def forward(self, x: torch.Tensor) -> Yolov5NetworkResult:
