@@ -2,6 +2,7 @@
 """Benchmark of the MI355X-native YOLOv5-s training step (BASELINE.json metric: images/sec, 640 px).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...                      (WORLD_SIZE unset: starts N fresh child processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -129,6 +130,128 @@ def cpu_baseline(seconds=15.0):
             "sample": f"{n} train steps of yv5s B=2 640px fp32 (oracle/ CPU restatement) in {dt:.1f}s"}
 
 
+def synth_pool(n, S, nc, seed):
+    """u8 image pool + boxes of the device data path: n images with U{0..255} pixels, aspect ratios from
+    {4:3, 3:4, 1:1, 3:2}, longest side S, 1..9 boxes per image, class ~ Zipf(1.01).  (Own generator: the timed path must
+    not touch oracle/.)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    k = np.arange(1, nc + 1, dtype=np.float64)
+    pmf = k ** (-1.01)
+    pmf /= pmf.sum()
+    imgs, boxes, labels = [], [], []
+    for _ in range(n):
+        rw, rh = [(4, 3), (3, 4), (1, 1), (3, 2)][int(rng.integers(0, 4))]
+        w, h = (S, int(round(S * rh / rw))) if rw >= rh else (int(round(S * rw / rh)), S)
+        imgs.append(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        m = int(rng.integers(1, 10))
+        bw = np.exp(rng.uniform(np.log(S / 16), np.log(S / 2.5), (m, 2)))
+        c = np.stack((rng.uniform(bw[:, 0] / 2, w - bw[:, 0] / 2), rng.uniform(bw[:, 1] / 2, h - bw[:, 1] / 2)), 1)
+        boxes.append(np.concatenate((c - bw / 2, c + bw / 2), 1).astype(np.float64))
+        labels.append(rng.choice(nc, size=m, p=pmf).astype(np.int64))
+    return imgs, boxes, labels
+
+
+def loop_leg(net, loss_fn, B, S, nc, device, steps, mixup_prob=0.0):
+    """The training LOOP BASELINE configs[1] literally names ("mosaic on"): DeviceTrainPipeline (reference sampling /
+    RNG protocol on the host, mosaic + affine + HSV + flip compositing from a u8 pool resident in HBM) feeding the
+    captured step (engine/graphed.py).  Reported beside the step rate, never as `value`."""
+    import random
+    import numpy as np
+    from object_detection_cib_amd.data.device_pipeline import DeviceTrainPipeline
+    from object_detection_cib_amd.engine.graphed import GraphedTrainStep
+    imgs, boxes, labels = synth_pool(256, S, nc, 7)
+    pipe = DeviceTrainPipeline(imgs, boxes, labels, S, device, mixup_prob=mixup_prob)
+    random.seed(2023); np.random.seed(2023)
+    batch = lambda i: pipe.make_batch([(i * B + k) % 256 for k in range(B)])
+    img, _, tg = batch(0)
+    gs = GraphedTrainStep(net, loss_fn, B, S, S, max_targets=16384).capture(img, tg)
+    for i in range(3):
+        img, _, tg = batch(i)
+        gs(img, tg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        img, _, tg = batch(i + 3)
+        total, _ = gs(img, tg)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
+            "workload": f"DeviceTrainPipeline (mosaic + affine + HSV + flip, mixup p={mixup_prob}, u8 pool of 256 images in HBM, "
+                        "host RNG protocol) -> hipGraph replay of the training step", "final_loss": float(total)}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N FRESH child processes (one per GPU, the env contract of
+    torch.distributed.run) from this parent, which never touches a GPU, wait for them with a deadline, and hand rank
+    0's JSON line through.  A rank that fails - or the job hanging past --timeout - ends every child and the exit code
+    is non-zero: a scaling run never waits forever and never reports a partial job."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    n = args.gpus
+    procs = []
+    argv = [a for a in sys.argv[1:]]
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KODHIP_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
+
+    def stop_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)       # exactly the process group this parent started
+                except ProcessLookupError:
+                    pass
+        for q in procs:
+            try:
+                q.wait(10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    deadline = time.monotonic() + args.timeout
+    out0 = b""
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        codes = [q.poll() for q in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = f"no result after {args.timeout:.0f} s (hang?): " + ", ".join(
+                f"rank {r} {'running' if c is None else 'done'}" for r, c in enumerate(codes))
+            break
+        time.sleep(0.2)
+    if failed:
+        stop_all()
+        print(f"bench.py --gpus {n}: {failed}; all ranks stopped", file=sys.stderr, flush=True)
+        return 124 if "hang" in failed else 1
+    reader.join(10)
+    out0 = chunks[0] if chunks else b""
+    line = None
+    for ln in out0.decode(errors="replace").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None:
+        print(f"bench.py --gpus {n}: rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
@@ -152,9 +275,11 @@ def pmc_traffic(family, B, S):
     return round(fam["traffic_bytes_per_launch"]) if fam else None
 
 
-def family_table(prof, steps_ms):
+def family_table(prof):
     """Per kernel family of one eager step: launches, summed event time, algorithmic bytes (SURVEY 8d byte model for
-    the convolutions; bytes actually touched for the BatchNorm / SiLU passes), achieved GB/s and fraction of 8 TB/s."""
+    the convolutions; bytes actually touched for the BatchNorm / SiLU passes), achieved GB/s and fraction of 8 TB/s.
+    share_of_step = family time / sum of all families' times of that SAME eager one-stream step (shares sum to 1; the
+    replayed step is shorter than that sum because its families overlap)."""
     fam = {}
     for name, e0, e1, nb in prof:
         f = fam.setdefault(name, [0, 0.0, 0.0])
@@ -162,9 +287,10 @@ def family_table(prof, steps_ms):
         f[1] += e0.elapsed_time(e1)
         f[2] += nb
     rows = []
+    total_ms = sum(v[1] for v in fam.values()) or 1.0
     for name, (n, ms, nb) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         gbs = nb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        rows.append({"family": name, "launches": n, "ms": round(ms, 3), "share_of_step": round(ms / steps_ms, 3),
+        rows.append({"family": name, "launches": n, "ms": round(ms, 3), "share_of_step": round(ms / total_ms, 3),
                      "algorithmic_MB": round(nb / 1e6, 1), "GB/s": round(gbs, 1), "frac": round(gbs * 1e9 / HBM_PEAK, 4)})
     return rows
 
@@ -182,7 +308,16 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--autograd", action="store_true",
                     help="drive the step through torch autograd (net(x) -> loss -> .backward()) instead of Yolov5Network.train_step")
+    ap.add_argument("--launch", default="auto", choices=("auto", "self", "none"),
+                    help="auto: with WORLD_SIZE unset and --gpus > 1 this process starts the N ranks itself; self: always")
+    ap.add_argument("--timeout", type=float, default=900.0, help="self-launch: seconds before a hung job is stopped")
+    ap.add_argument("--no-loop", action="store_true", help="skip the training-loop leg (device data pipeline -> captured step)")
+    ap.add_argument("--loop-steps", type=int, default=20)
     args = ap.parse_args()
+
+    # decided before anything touches a GPU; the parent only starts and supervises the ranks (never re-executes itself)
+    if "WORLD_SIZE" not in os.environ and (args.launch == "self" or (args.launch == "auto" and args.gpus > 1)):
+        raise SystemExit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,7 +328,7 @@ def main():
     device = torch.device("cuda", local)
     dist = None
     # KODHIP_FORCE_COLLECTIVES=1: rehearse the N>1 code path (RCCL group, SyncBN sums, gradient buckets) on one GPU
-    use_dist = world > 1 or os.environ.get("KODHIP_FORCE_COLLECTIVES") == "1"
+    use_dist = world > 1 or os.environ.get("KODHIP_FORCE_COLLECTIVES") == "1" or "WORLD_SIZE" in os.environ and args.launch == "self"
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -201,7 +336,15 @@ def main():
         # control plane (rendezvous id, barriers, max-over-ranks of the clock) on gloo; every GPU collective of the
         # step goes through the engine's own RCCL communicator, enqueued on the step's streams and captured with it
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
+    if use_dist:
+        # a rank that stops making progress (a peer died, a collective hangs) ends itself: under a launcher without a
+        # supervising parent (torch.distributed.run) the job then fails instead of hanging
+        import threading
+        threading.Thread(target=lambda: (time.sleep(args.timeout), print(f"[bench rank {rank}] no result after "
+                         f"{args.timeout:.0f} s: giving up", file=sys.stderr, flush=True), os._exit(124)), daemon=True).start()
 
     nc, B, S = 10, args.batch, args.size
     widen, deepen = VARIANTS[args.variant]
@@ -303,16 +446,21 @@ def main():
     torch.cuda.synchronize()
     prof = eng.profile
     eng.profile, eng.wgrad_overlap = None, ov
+    per_rank = [round(B * args.steps / dt, 1)]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dts = [None] * world
+        dist.all_gather_object(dts, dt)
+        per_rank = [round(B * args.steps / d, 1) for d in dts]
+        dt = max(dts)                              # the job is as fast as its slowest rank
     final_loss = float(last.item())
+    loop = None
+    if world == 1 and not use_dist and not args.no_loop and not args.autograd and use_graph:
+        loop = loop_leg(net, loss_fn, B, S, nc, device, args.loop_steps)
 
     if rank == 0:
         ips = world * B * args.steps / dt
         # roofline: the kernel family with the largest share of the step (event-timed, see above)
-        table = family_table(prof, 1e3 * dt / args.steps)
+        table = family_table(prof)
         top = table[0]
         n_launch = max(top["launches"], 1)
         out = {
@@ -323,7 +471,14 @@ def main():
             "config": {"workload": f"{args.variant} coco-zipf-like synthetic, {S}px, bf16 storage/fp32 accumulate, "
                                    f"batch {B}/GPU, fwd+assign+loss+bwd+SGD, targets 4-30 boxes/img",
                        "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if use_dist and not args.no_sync_bn else ""),
-                       "launch": launch_note, "collectives": ("RCCL, native in-stream" if use_dist else "none")},
+                       "launch": launch_note,
+                       "collectives": ("none" if not use_dist else
+                                       "RCCL, native: SyncBN sums in stream order, gradient buckets "
+                                       + ("overlapped with backward on the weight-gradient stream (own communicator)"
+                                          if eng.comm_buckets is not None else "in stream order")),
+                       "launcher": os.environ.get("KODHIP_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none")},
+            "per_rank_images_per_sec": per_rank,
+            "engine_options": eng.opt.as_dict(),
             "final_loss": final_loss,
             "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_img": algo_bytes,
                               "achieved": round(ips / world * algo_bytes / 1e9, 1), "peak": HBM_PEAK / 1e9,
@@ -337,6 +492,8 @@ def main():
                          "share_of_step": top["share_of_step"]},
             "families": table,
         }
+        if loop is not None:
+            out["loop"] = loop
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -54,14 +54,21 @@ int kodhip_conv_fwd_raw(const void* x, const void* w_packed, void* y, float* sta
 int kodhip_conv_fwd_head(const void* x, const void* w_packed, const float* bias, float* out,
                          int B, int H, int W, int ldx, int xcoff, int Cin, int A, int nc, int Kp,
                          kodStream_t stream);
+/* Data gradients (aten::convolution_backward dX).  `accumulate`: bit 0 = add to the bf16 partial already in dx (read-
+ * modify-write: rounds the partial and the sum); bits 8.. = fp32 accumulation of an activation gradient with several
+ * producers (autograd sums those in fp32 before anything is rounded): 1<<8 first producer - also store the fp32 values
+ * to dx_f32, the fp32 shadow of dx (same indexing, row stride ldx floats); 2<<8 later producer - add the shadow's sum
+ * in the MFMA accumulators before the single bf16 rounding, store the sum back; 3<<8 last producer - the same without
+ * the store; 4<<8 - the partial is dx's own bf16 content left by exact producers (a residual pass-through), added in
+ * fp32 before the rounding.  dx_f32 may be NULL for modes 0 and 4. */
 int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
                       int B, int H, int W, int ldx, int xcoff, int Cin,
                       int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
-                      int ldy, int ycoff, int accumulate, kodStream_t stream);
+                      int ldy, int ycoff, int accumulate, void* dx_f32, kodStream_t stream);
 /* dX of a 3x3/s2/p1 conv by output-pixel parity classes (9 instead of 36 taps of MFMA work) */
 int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
                          int B, int H, int W, int ldx, int xcoff, int Cin, int N,
-                         int ldy, int ycoff, int accumulate, kodStream_t stream);
+                         int ldy, int ycoff, int accumulate, void* dx_f32, kodStream_t stream);
 /* Data gradient that also produces the BatchNorm-backward reduction of the conv units whose output gradient it
  * completes (it must be the LAST writer of those channel ranges of dx): fuses aten::convolution_backward (dX) with
  * the reduction half of native_batch_norm_backward + silu_backward of the producing Conv2dNormActivation
@@ -77,11 +84,11 @@ int kodhip_conv_dgrad_bnred_slots(int B, int H, int W, int Cin, int N, int KH, i
 int kodhip_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* dx,
                             int B, int H, int W, int ldx, int xcoff, int Cin,
                             int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
-                            int ldy, int ycoff, int accumulate, const void* segments /* host KodBnRedSeg[nseg] */,
+                            int ldy, int ycoff, int accumulate, void* dx_f32, const void* segments /* host KodBnRedSeg[nseg] */,
                             int nseg, int slots, kodStream_t stream);
 int kodhip_conv_dgrad_s2_bnred(const void* dy, const void* w_dgrad_s2, void* dx,
                                int B, int H, int W, int ldx, int xcoff, int Cin, int N,
-                               int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                               int ldy, int ycoff, int accumulate, void* dx_f32, const void* segments, int nseg, int slots,
                                kodStream_t stream);
 /* The same data gradient "folded": one stride-1 gather over the 2x2 dY neighbourhood of each 2x2 output-pixel block,
  * 4 parity classes x Cin output columns, depth-to-space epilogue (16 tap-class products instead of 9, but dY is staged
@@ -90,11 +97,11 @@ int kodhip_conv_dgrad_s2_bnred(const void* dy, const void* w_dgrad_s2, void* dx,
 int kodhip_conv_dgrad_s2_folded(int Cin, int N);
 int kodhip_conv_dgrad_s2f(const void* dy, const void* w_fold, void* dx,
                           int B, int H, int W, int ldx, int xcoff, int Cin, int N,
-                          int ldy, int ycoff, int accumulate, kodStream_t stream);
+                          int ldy, int ycoff, int accumulate, void* dx_f32, kodStream_t stream);
 int kodhip_conv_dgrad_s2f_bnred_slots(int B, int H, int W, int Cin, int N, int ldy);
 int kodhip_conv_dgrad_s2f_bnred(const void* dy, const void* w_fold, void* dx,
                                 int B, int H, int W, int ldx, int xcoff, int Cin, int N,
-                                int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                                int ldy, int ycoff, int accumulate, void* dx_f32, const void* segments, int nseg, int slots,
                                 kodStream_t stream);
 /* dX of TWO pointwise (1x1/s1/p0) convs that read the same tensor - a CSP layer's main_conv and short_conv
  * (kod/nn/layers/csp.py:96-111) - as one launch over the concatenated reduction: dx is written once instead of written
@@ -102,11 +109,11 @@ int kodhip_conv_dgrad_s2f_bnred(const void* dy, const void* w_fold, void* dx,
  * dgrad packs [Cin][Kp], Kp = round_up(N, 32). */
 int kodhip_conv_dgrad_dual(const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
                            int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
-                           int accumulate, kodStream_t stream);
+                           int accumulate, void* dx_f32, kodStream_t stream);
 int kodhip_conv_dgrad_dual_bnred_slots(int B, int H, int W, int Cin, int N, int ldy);
 int kodhip_conv_dgrad_dual_bnred(const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
                                  int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
-                                 int accumulate, const void* segments, int nseg, int slots, kodStream_t stream);
+                                 int accumulate, void* dx_f32, const void* segments, int nseg, int slots, kodStream_t stream);
 int kodhip_conv_wgrad_splits(long M, int N, int Kp);
 int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* grad,
                       int B, int H, int W, int ldx, int xcoff, int Cin,
@@ -153,12 +160,13 @@ int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout,
  *      kod/nn/necks/yolov5_pafpn.py:144-146,182-184) ------------------------------------------------- */
 int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff, void* idx,
                         int B, int H, int W, int C, kodStream_t stream);
+/* dx_f32 (NULL = none): fp32 shadow of dx holding the earlier producers' partial sum (see kodhip_conv_dgrad) */
 int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, void* dx, int ldx, int xcoff,
-                        int B, int H, int W, int C, kodStream_t stream);
+                        int B, int H, int W, int C, const float* dx_f32, kodStream_t stream);
 int kodhip_upsample2x_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff,
                           int B, int H, int W, int C, kodStream_t stream);
 int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx, int xcoff, int accumulate,
-                          int B, int H, int W, int C, kodStream_t stream);
+                          int B, int H, int W, int C, const float* dx_f32, kodStream_t stream);
 /* workspace: 2048 * Npad floats (per-block bias partials) */
 int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_box, float* db_obj, float* db_cls,
                          int B, int HW, int A, int nc, int Npad, kodStream_t stream);

@@ -41,18 +41,18 @@ SIGNATURES = {
     "kodhip_conv_stats_slots": (i32, [i64, i32]),
     "kodhip_conv_fwd_raw": (i32, [vp, vp, vp, vp] + [i32] * 16 + [vp]),
     "kodhip_conv_fwd_head": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp]),
-    "kodhip_conv_dgrad": (i32, [vp, vp, vp] + [i32] * 17 + [vp]),
-    "kodhip_conv_dgrad_s2": (i32, [vp, vp, vp] + [i32] * 10 + [vp]),
+    "kodhip_conv_dgrad": (i32, [vp, vp, vp] + [i32] * 17 + [vp, vp]),
+    "kodhip_conv_dgrad_s2": (i32, [vp, vp, vp] + [i32] * 10 + [vp, vp]),
     "kodhip_conv_dgrad_bnred_slots": (i32, [i32] * 13),
-    "kodhip_conv_dgrad_bnred": (i32, [vp, vp, vp] + [i32] * 17 + [vp, i32, i32, vp]),
-    "kodhip_conv_dgrad_s2_bnred": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, i32, vp]),
+    "kodhip_conv_dgrad_bnred": (i32, [vp, vp, vp] + [i32] * 17 + [vp, vp, i32, i32, vp]),
+    "kodhip_conv_dgrad_s2_bnred": (i32, [vp, vp, vp] + [i32] * 10 + [vp, vp, i32, i32, vp]),
     "kodhip_conv_dgrad_s2_folded": (i32, [i32, i32]),
-    "kodhip_conv_dgrad_s2f": (i32, [vp, vp, vp] + [i32] * 10 + [vp]),
+    "kodhip_conv_dgrad_s2f": (i32, [vp, vp, vp] + [i32] * 10 + [vp, vp]),
     "kodhip_conv_dgrad_s2f_bnred_slots": (i32, [i32] * 6),
-    "kodhip_conv_dgrad_s2f_bnred": (i32, [vp, vp, vp] + [i32] * 10 + [vp, i32, i32, vp]),
-    "kodhip_conv_dgrad_dual": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),
+    "kodhip_conv_dgrad_s2f_bnred": (i32, [vp, vp, vp] + [i32] * 10 + [vp, vp, i32, i32, vp]),
+    "kodhip_conv_dgrad_dual": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp, vp]),
     "kodhip_conv_dgrad_dual_bnred_slots": (i32, [i32] * 6),
-    "kodhip_conv_dgrad_dual_bnred": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp, i32, i32, vp]),
+    "kodhip_conv_dgrad_dual_bnred": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp, vp, i32, i32, vp]),
     "kodhip_conv_wgrad_splits": (i32, [i64, i32, i32]),
     "kodhip_conv_wgrad": (i32, [vp, vp, vp, vp] + [i32] * 18 + [f32, vp]),
     "kodhip_bn_reduce_partials": (i32, [vp, vp, i32, i32, vp]),
@@ -66,9 +66,9 @@ SIGNATURES = {
     "kodhip_bn_bwd_coeffs": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_silu_bwd_apply": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i64, i32, vp]),
     "kodhip_maxpool5_fwd": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, vp]),
-    "kodhip_maxpool5_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "kodhip_maxpool5_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "kodhip_upsample2x_fwd": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
-    "kodhip_upsample2x_bwd": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "kodhip_upsample2x_bwd": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "kodhip_head_bwd_prep": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "kodhip_sgd_nesterov": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "kodhip_fill_u32": (i32, [vp, u32, i64, vp]),
@@ -152,7 +152,7 @@ def limit_host_threads():
     WHOLE process is throttled for most of a 100 ms scheduler period: measured 37 ms per validation batch (9 throttled
     periods out of 38) against 13 ms with the pool sized to the quota.  Only ever lowers the thread count."""
     global _threads_limited
-    if _threads_limited:
+    if _threads_limited or os.environ.get("KODHIP_LIMIT_HOST_THREADS", "1") == "0":
         return
     _threads_limited = True
     import torch
@@ -166,4 +166,3 @@ def require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError("object_detection_cib_amd: the HIP hot path needs an MI355X (no CPU fallback)")
     lib()
-    limit_host_threads()

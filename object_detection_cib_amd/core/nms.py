@@ -37,11 +37,10 @@ def non_max_suppression(detections: torch.Tensor, conf_thres: float = 0.25, nms_
     dev = det.device
     # the sort keys are the one large workspace (B * key_cap * 8 B = 134 MB at 64 x 25200 x 10): kept across calls,
     # returning it to the caching allocator every batch makes later allocations fall through to hipMalloc (tens of ms)
-    wk = (dev, B * key_cap)
-    keys = _WORKSPACE.get(wk)
-    if keys is None:
-        _WORKSPACE.clear()
-        keys = _WORKSPACE[wk] = torch.empty(B * key_cap, dtype=torch.int64, device=dev)
+    # (grow-only per device: alternating full and partial validation batches reuse the largest buffer)
+    keys = _WORKSPACE.get(dev)
+    if keys is None or keys.numel() < B * key_cap:
+        keys = _WORKSPACE[dev] = torch.empty(B * key_cap, dtype=torch.int64, device=dev)
     ncand = torch.empty(B, dtype=torch.int32, device=dev)
     out = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
     nout = torch.empty(B, dtype=torch.int32, device=dev)

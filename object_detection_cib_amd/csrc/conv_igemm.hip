@@ -51,6 +51,14 @@ struct ConvArgs {
   int KH, KW;
   int mul_h, mul_w, add_h, add_w, tap_sign, sh_shift, sw_shift;
   int ldy, ycoff, accumulate;
+  // PLAIN: fp32 shadow of the output buffer (same pixel / channel indexing, row stride ldy floats) for activation
+  // gradients with several producers.  f32_mode: 0 off; 1 = also write this launch's fp32 values there (first
+  // producer); 2 / 3 = a later producer: the shadow's partial sum is added to the MFMA accumulators BEFORE the single bf16
+  // rounding and the bf16 output is overwritten with the rounded running sum (2 also stores the sum back to the shadow,
+  // 3 = last producer, does not); 4 = the partial is the bf16 output itself (left there by exact producers - copies such
+  // as a residual pass-through): added in fp32 before the rounding, no shadow
+  float* y32;
+  int f32_mode;
   int out_mul, out_off_y, out_off_x, out_H, out_W;   // PLAIN: output pixel (oy,ox) -> (oy*mul+off_y, ox*mul+off_x) of an out_H x out_W image
   int d2s_C;                   // PLAIN, folded stride-2 data gradient: output column n = class * d2s_C + channel, class (py,px)
                                // = (n / d2s_C) >> 1, & 1 is the pixel's parity offset (depth-to-space epilogue); 0 = off
@@ -98,7 +106,7 @@ __device__ __forceinline__ void wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0
 // zero-filling buffer load did per tap for the left / right image border becomes a per-lane mask on the pixel
 // fragments of taps 0 and 2.  Per unit of MFMA work the L2 -> LDS fill drops by 30-50 % (these layers are bound by it)
 // and there is one barrier per three taps.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST, bool ROW3 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST, bool ROW3 = false, bool F32ACC = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int NW = NT / 64;
@@ -589,6 +597,54 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         __syncthreads();
       }
     } else {
+      // F32ACC: own instantiations (a run-time branch here costs the default kernels 30-40 VGPRs and spills)
+      if constexpr (F32ACC && (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN)) {
+        if (a.f32_mode != 0) {
+          // fp32 accumulation across producers, straight from / into the accumulators (lane: pixel fr of block jj,
+          // channels 8g + 4fh .. +3 of block i): 16-byte accesses of the shadow
+#pragma unroll
+          for (int jj = 0; jj < TM; ++jj) {
+            const int m = m0 + wm * WM + jj * 32 + fr;
+            size_t opix = (size_t)m;
+            if (a.out_mul != 1) {
+              const int b = m / HWo, rem = m - b * HWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+              opix = ((size_t)b * a.out_H + oy * a.out_mul) * a.out_W + ox * a.out_mul;
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
+                if (m >= a.M || n >= a.N) continue;
+                int nch = n;
+                size_t pix = opix;
+                if (a.out_mul != 1) {
+                  int poff = a.out_off_y * a.out_W + a.out_off_x;
+                  if (a.d2s_C != 0) { const int cls = n / a.d2s_C; nch = n - cls * a.d2s_C; poff = (cls >> 1) * a.out_W + (cls & 1); }
+                  pix += poff;
+                }
+                if (a.f32_mode == 4) {
+                  const bf16x4 o = *reinterpret_cast<const bf16x4*>(a.y + pix * a.ldy + a.ycoff + nch);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) acc[i][jj][g * 4 + e] += (float)o[e];
+                  continue;
+                }
+                f32x4* p32 = reinterpret_cast<f32x4*>(a.y32 + pix * a.ldy + a.ycoff + nch);
+                if (a.f32_mode >= 2) {
+                  const f32x4 o = *p32;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) acc[i][jj][g * 4 + e] += o[e];
+                }
+                if (a.f32_mode <= 2) {
+                  f32x4 o;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) o[e] = acc[i][jj][g * 4 + e];
+                  *p32 = o;
+                }
+              }
+          }
+        }
+      }
       bf16_t* Cs = lds;
 #pragma unroll
       for (int i = 0; i < TN; ++i)
@@ -649,7 +705,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
           }
           bf16_t* dst = a.y + opix * a.ldy + a.ycoff + nch;
           if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
-            if (a.accumulate) {
+            if (a.accumulate && (!F32ACC || a.f32_mode < 2)) {
               bf16x8 o = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)o[e]);
@@ -765,16 +821,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST, bool F32ACC = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ ? 2 : (FAST ? 4 : 3)))   /* waves per SIMD */
 void conv_igemm_kernel(ConvArgs a) {
-  conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(a, blockIdx.x);
+  conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST, false, F32ACC>(a, blockIdx.x);
 }
 
-template <int BN, int WAVES_M, int WAVES_N, int MODE>
+template <int BN, int WAVES_M, int WAVES_N, int MODE, bool F32ACC = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (BN == 128 ? 2 : (BN == 64 ? 3 : 4)))    /* = what the LDS stages allow */
 void conv_igemm_row3_kernel(ConvArgs a) {
-  conv_igemm_body<128, BN, WAVES_M, WAVES_N, MODE, true, true>(a, blockIdx.x);
+  conv_igemm_body<128, BN, WAVES_M, WAVES_N, MODE, true, true, F32ACC>(a, blockIdx.x);
 }
 
 // Four problems of identical tiling in one launch (the parity classes of a stride-2 dgrad).  The classes have 4, 2, 2
@@ -785,17 +841,17 @@ void conv_igemm_row3_kernel(ConvArgs a) {
 // for A/B.)
 struct ConvArgs4 { ConvArgs c[4]; int per_class, interleave; };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST, bool F32ACC = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (MODE == 2 /*HEAD*/ ? 2 : (FAST ? 4 : 3)))   /* waves per SIMD */
 void conv_igemm_x4_kernel(ConvArgs4 p) {
   const int bid = blockIdx.x;
   if (p.interleave) {
     const int cls = (bid >> 3) & 3;
-    conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(p.c[cls], ((bid >> 5) << 3) | (bid & 7));
+    conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST, false, F32ACC>(p.c[cls], ((bid >> 5) << 3) | (bid & 7));
   } else {
     const int q = bid / p.per_class;                     // 0..3 in dispatch order
     const int cls = q == 0 ? 3 : (q == 3 ? 0 : q);
-    conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST>(p.c[cls], bid - q * p.per_class);
+    conv_igemm_body<BM, BN, WAVES_M, WAVES_N, MODE, FAST, false, F32ACC>(p.c[cls], bid - q * p.per_class);
   }
 }
 
@@ -868,8 +924,11 @@ Plan plan_conv(const ConvArgs& a, bool fast, bool& row3, int mode) {
   return make_plan(a.M, a.N, a.nk1 ? 2 * a.K : a.K, fast, row3);
 }
 
-template <int MODE>
+template <int MODE, bool F32ACC = false>
 int launch(const ConvArgs& a, hipStream_t stream) {
+  if constexpr ((MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) && !F32ACC) {
+    if (a.f32_mode != 0) return launch<MODE, true>(a, stream);      // fp32 accumulation across producers: own kernels
+  }
   ConvArgs args = a;
   const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, wb = (long)a.N * a.Kp * 2;
   const bool fast = fast_eligible(a);
@@ -889,19 +948,21 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   dim3 g(p.grid);
   if constexpr (MODE != MODE_HEAD) {
     if (row3) {
-      if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_row3_kernel<128, 2, 2, MODE>), g, dim3(256), 0, stream, args);
-      else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_row3_kernel<64, 2, 2, MODE>), g, dim3(256), 0, stream, args);
-      else hipLaunchKernelGGL((conv_igemm_row3_kernel<32, 4, 1, MODE>), g, dim3(256), 0, stream, args);
+      if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_row3_kernel<128, 2, 2, MODE, F32ACC>), g, dim3(256), 0, stream, args);
+      else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_row3_kernel<64, 2, 2, MODE, F32ACC>), g, dim3(256), 0, stream, args);
+      else hipLaunchKernelGGL((conv_igemm_row3_kernel<32, 4, 1, MODE, F32ACC>), g, dim3(256), 0, stream, args);
       KOD_LAUNCH_CHECK("conv_igemm_row3");
       return KOD_OK;
     }
   }
   if (fast) {
-    if (p.bm == 256 && p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
-    else if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, args);
-    else if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE, true>), g, dim3(256), 0, stream, args);
-    else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE, true>), g, dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, args);
+    if (p.bm == 256 && p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, args);
+    else if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, args);
+    else if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, args);
+    else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, MODE, true, F32ACC>), g, dim3(256), 0, stream, args);
+  } else if constexpr (F32ACC) {
+    KOD_CHECK_ARG(false, "conv: fp32 accumulation across producers needs the FAST path");
   } else if constexpr (MODE == MODE_PLAIN_BN) {
     KOD_CHECK_ARG(false, "conv: the fused BatchNorm-backward reduction needs the FAST path (query the slots first)");
   } else {
@@ -914,8 +975,11 @@ int launch(const ConvArgs& a, hipStream_t stream) {
 }
 
 // one launch for four FAST problems that share M, N and the tile plan (chosen for the longest reduction)
-template <int MODE>
+template <int MODE, bool F32ACC = false>
 int launch_x4(ConvArgs c[4], hipStream_t stream) {
+  if constexpr (!F32ACC) {
+    if (c[0].f32_mode != 0) return launch_x4<MODE, true>(c, stream);
+  }
   ConvArgs4 p;
   int kmax = 0;
   for (int i = 0; i < 4; ++i) kmax = c[i].K > kmax ? c[i].K : kmax;
@@ -933,11 +997,11 @@ int launch_x4(ConvArgs c[4], hipStream_t stream) {
   static const bool interleave = getenv("KODHIP_S2_INTERLEAVE") != nullptr;
   p.per_class = pl.grid; p.interleave = interleave;
   dim3 g(pl.grid * 4);
-  if (pl.bm == 256 && pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
-  else if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true>), g, dim3(512), 0, stream, p);
-  else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true>), g, dim3(256), 0, stream, p);
-  else if (pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 2, MODE, true>), g, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 32, 4, 1, MODE, true>), g, dim3(256), 0, stream, p);
+  if (pl.bm == 256 && pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, p);
+  else if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, p);
+  else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, p);
+  else if (pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 32, 4, 1, MODE, true, F32ACC>), g, dim3(256), 0, stream, p);
   KOD_LAUNCH_CHECK("conv_igemm_x4");
   return KOD_OK;
 }
@@ -1040,8 +1104,20 @@ int set_segments(ConvArgs& a, const BnRedSeg* segs, int nseg, int slots, int out
   return KOD_OK;
 }
 
+// the `accumulate` argument of the data-gradient entry points: bit 0 = add to the bf16 partial already in dx (read-
+// modify-write, rounds twice); bits 8.. = f32_mode (ConvArgs) with dx_f32 = the output buffer's fp32 shadow
+int set_f32(ConvArgs& a, int accumulate, void* dx_f32) {
+  a.accumulate = accumulate & 1;
+  a.f32_mode = accumulate >> 8;
+  a.y32 = (float*)dx_f32;
+  KOD_CHECK_ARG(a.f32_mode >= 0 && a.f32_mode <= 4, "conv_dgrad: bad fp32 accumulation mode %d", a.f32_mode);
+  KOD_CHECK_ARG(a.f32_mode == 0 || a.f32_mode == 4 || dx_f32, "conv_dgrad: fp32 accumulation mode %d needs the fp32 shadow of dx", a.f32_mode);
+  return KOD_OK;
+}
+
 int prep_dgrad(ConvArgs& a, const void* dy, const void* w_dgrad, void* dx, int B, int H, int W, int ldx, int xcoff, int Cin,
-               int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp, int ldy, int ycoff, int accumulate) {
+               int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp, int ldy, int ycoff, int accumulate,
+               void* dx_f32 = nullptr) {
   a = ConvArgs{};
   int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
   // gather source is dy (channels N per tap), output pixels are the input pixels of the forward conv
@@ -1051,14 +1127,15 @@ int prep_dgrad(ConvArgs& a, const void* dy, const void* w_dgrad, void* dx, int B
   KOD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0 && xcoff + Cin <= ldx, "conv_dgrad: bad output slice");
   int ssh = ilog2_exact(SH), ssw = ilog2_exact(SW);
   KOD_CHECK_ARG(ssh >= 0 && ssw >= 0, "conv_dgrad: stride must be a power of two");
-  a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff; a.accumulate = accumulate;
+  a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff;
+  if (int rc2 = set_f32(a, accumulate, dx_f32)) return rc2;
   a.mul_h = 1; a.mul_w = 1; a.add_h = PH; a.add_w = PW; a.tap_sign = -1; a.sh_shift = ssh; a.sw_shift = ssw;
   return KOD_OK;
 }
 
 // the four parity classes of a 3x3 / stride 2 / pad 1 data gradient (see kodhip_conv_dgrad_s2)
 int prep_dgrad_s2(ConvArgs cls[4], bool& all_fast, const void* dy, const void* w_dgrad_s2, void* dx, int B, int H, int W,
-                  int ldx, int xcoff, int Cin, int N, int ldy, int ycoff, int accumulate) {
+                  int ldx, int xcoff, int Cin, int N, int ldy, int ycoff, int accumulate, void* dx_f32 = nullptr) {
   KOD_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "conv_dgrad_s2: input dims must be even");
   const int Ho = H / 2, Wo = W / 2;
   size_t woff = 0;
@@ -1073,7 +1150,8 @@ int prep_dgrad_s2(ConvArgs cls[4], bool& all_fast, const void* dy, const void* w
     int rc = fill_common(a, dy, (const bf16_t*)w_dgrad_s2 + woff, B, Ho, Wo, ldy, ycoff, N, Ho, Wo, Cin, KH, KW, Kp);
     if (rc) return rc;
     KOD_CHECK_ARG(dx && Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0 && xcoff + Cin <= ldx, "conv_dgrad_s2: bad output slice");
-    a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff; a.accumulate = accumulate;
+    a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff;
+    if (int rc2 = set_f32(a, accumulate, dx_f32)) return rc2;
     a.mul_h = 1; a.mul_w = 1; a.add_h = py; a.add_w = px; a.tap_sign = -1; a.sh_shift = 0; a.sw_shift = 0;
     a.out_mul = 2; a.out_off_y = py; a.out_off_x = px; a.out_H = H; a.out_W = W;
     all_fast = all_fast && fast_eligible(a);
@@ -1089,14 +1167,15 @@ int prep_dgrad_s2(ConvArgs cls[4], bool& all_fast, const void* dy, const void* w
 // both x parities of a pixel pair: the shallow layers (Cin <= 64), which are bound by staging / pipeline fill and
 // half-line stores and not by the MFMA, run 2x faster this way.
 int prep_dgrad_s2f(ConvArgs& a, const void* dy, const void* w_fold, void* dx, int B, int H, int W,
-                   int ldx, int xcoff, int Cin, int N, int ldy, int ycoff, int accumulate) {
+                   int ldx, int xcoff, int Cin, int N, int ldy, int ycoff, int accumulate, void* dx_f32 = nullptr) {
   KOD_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "conv_dgrad_s2f: input dims must be even");
   const int Ho = H / 2, Wo = W / 2;
   const int Kp = 4 * ((N + 31) / 32 * 32);
   a = ConvArgs{};
   if (int rc = fill_common(a, dy, w_fold, B, Ho, Wo, ldy, ycoff, N, Ho, Wo, 4 * Cin, 2, 2, Kp)) return rc;
   KOD_CHECK_ARG(dx && Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0 && xcoff + Cin <= ldx, "conv_dgrad_s2f: bad output slice");
-  a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff; a.accumulate = accumulate;
+  a.y = (bf16_t*)dx; a.ldy = ldx; a.ycoff = xcoff;
+  if (int rc2 = set_f32(a, accumulate, dx_f32)) return rc2;
   a.mul_h = 1; a.mul_w = 1; a.add_h = 0; a.add_w = 0; a.tap_sign = 1; a.sh_shift = 0; a.sw_shift = 0;
   a.out_mul = 2; a.out_off_y = 0; a.out_off_x = 0; a.out_H = H; a.out_W = W; a.d2s_C = Cin;
   KOD_CHECK_ARG(fast_eligible(a), "conv_dgrad_s2f: needs the LDS-DMA path (operands within a 32-bit buffer range)");
@@ -1112,9 +1191,9 @@ extern "C" {
 int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
                       int B, int H, int W, int ldx, int xcoff, int Cin,
                       int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
-                      int ldy, int ycoff, int accumulate, hipStream_t stream) {
+                      int ldy, int ycoff, int accumulate, void* dx_f32, hipStream_t stream) {
   ConvArgs a;
-  if (int rc = prep_dgrad(a, dy, w_dgrad, dx, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, accumulate)) return rc;
+  if (int rc = prep_dgrad(a, dy, w_dgrad, dx, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, accumulate, dx_f32)) return rc;
   return launch<MODE_PLAIN>(a, stream);
 }
 
@@ -1124,10 +1203,10 @@ int kodhip_conv_dgrad(const void* dy, const void* w_dgrad, void* dx,
 // back to back: class c = 2*py+px is [Cin][Kdp_c], Kdp_c = ntaps_c * round_up(N, 32), k = (kh', kw', n) tap-major.
 int kodhip_conv_dgrad_s2(const void* dy, const void* w_dgrad_s2, void* dx,
                          int B, int H, int W, int ldx, int xcoff, int Cin, int N,
-                         int ldy, int ycoff, int accumulate, hipStream_t stream) {
+                         int ldy, int ycoff, int accumulate, void* dx_f32, hipStream_t stream) {
   ConvArgs cls[4];
   bool all_fast;
-  if (int rc = prep_dgrad_s2(cls, all_fast, dy, w_dgrad_s2, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate)) return rc;
+  if (int rc = prep_dgrad_s2(cls, all_fast, dy, w_dgrad_s2, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate, dx_f32)) return rc;
   if (all_fast) return launch_x4<MODE_PLAIN>(cls, stream);
   for (int c = 0; c < 4; ++c)
     if (int rc = launch<MODE_PLAIN>(cls[c], stream)) return rc;
@@ -1148,9 +1227,9 @@ int kodhip_conv_dgrad_s2_folded(int Cin, int N) {
 // + ci (class = 2 * py + px), k = (dy * 2 + dx) * round_up(N, 32) + n.
 int kodhip_conv_dgrad_s2f(const void* dy, const void* w_fold, void* dx,
                           int B, int H, int W, int ldx, int xcoff, int Cin, int N,
-                          int ldy, int ycoff, int accumulate, hipStream_t stream) {
+                          int ldy, int ycoff, int accumulate, void* dx_f32, hipStream_t stream) {
   ConvArgs a;
-  if (int rc = prep_dgrad_s2f(a, dy, w_fold, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate)) return rc;
+  if (int rc = prep_dgrad_s2f(a, dy, w_fold, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate, dx_f32)) return rc;
   return launch<MODE_PLAIN>(a, stream);
 }
 
@@ -1164,10 +1243,10 @@ int kodhip_conv_dgrad_s2f_bnred_slots(int B, int H, int W, int Cin, int N, int l
 
 int kodhip_conv_dgrad_s2f_bnred(const void* dy, const void* w_fold, void* dx,
                                 int B, int H, int W, int ldx, int xcoff, int Cin, int N,
-                                int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                                int ldy, int ycoff, int accumulate, void* dx_f32, const void* segments, int nseg, int slots,
                                 hipStream_t stream) {
   ConvArgs a;
-  if (int rc = prep_dgrad_s2f(a, dy, w_fold, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate)) return rc;
+  if (int rc = prep_dgrad_s2f(a, dy, w_fold, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate, dx_f32)) return rc;
   if (int rc = set_segments(a, (const BnRedSeg*)segments, nseg, slots, Cin)) return rc;
   return launch<MODE_PLAIN_BN>(a, stream);
 }
@@ -1200,10 +1279,10 @@ int kodhip_conv_dgrad_bnred_slots(int B, int H, int W, int Cin, int N, int KH, i
 int kodhip_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* dx,
                             int B, int H, int W, int ldx, int xcoff, int Cin,
                             int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
-                            int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                            int ldy, int ycoff, int accumulate, void* dx_f32, const void* segments, int nseg, int slots,
                             hipStream_t stream) {
   ConvArgs a;
-  if (int rc = prep_dgrad(a, dy, w_dgrad, dx, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, accumulate)) return rc;
+  if (int rc = prep_dgrad(a, dy, w_dgrad, dx, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, accumulate, dx_f32)) return rc;
   if (int rc = set_segments(a, (const BnRedSeg*)segments, nseg, slots, Cin)) return rc;
   return launch<MODE_PLAIN_BN>(a, stream);
 }
@@ -1215,8 +1294,9 @@ int kodhip_conv_dgrad_bnred(const void* dy, const void* w_dgrad, void* dx,
 // each); w1, w2: [Cin][Kp] dgrad packs (Kp = round_up(N, 32)).  *_bnred: also the BatchNorm-backward reduction of the
 // units whose output gradient dx completes (see kodhip_conv_dgrad_bnred).
 static int prep_dgrad_dual(ConvArgs& a, const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
-                           int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff, int accumulate) {
-  if (int rc = prep_dgrad(a, dy1, w1, dx, B, H, W, ldx, xcoff, Cin, N, 1, 1, 1, 1, 0, 0, Kp, ldy, ycoff, accumulate)) return rc;
+                           int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff, int accumulate,
+                           void* dx_f32 = nullptr) {
+  if (int rc = prep_dgrad(a, dy1, w1, dx, B, H, W, ldx, xcoff, Cin, N, 1, 1, 1, 1, 0, 0, Kp, ldy, ycoff, accumulate, dx_f32)) return rc;
   KOD_CHECK_ARG(dy2 && w2, "conv_dgrad_dual: null second source");
   KOD_CHECK_ARG(fast_eligible(a), "conv_dgrad_dual: needs the LDS-DMA path (operands within a 32-bit buffer range)");
   a.x2 = (const bf16_t*)dy2; a.w2 = (const bf16_t*)w2; a.nk1 = Kp / 32;
@@ -1225,9 +1305,9 @@ static int prep_dgrad_dual(ConvArgs& a, const void* dy1, const void* w1, const v
 
 int kodhip_conv_dgrad_dual(const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
                            int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
-                           int accumulate, hipStream_t stream) {
+                           int accumulate, void* dx_f32, hipStream_t stream) {
   ConvArgs a;
-  if (int rc = prep_dgrad_dual(a, dy1, w1, dy2, w2, dx, B, H, W, ldx, xcoff, Cin, N, Kp, ldy, ycoff, accumulate)) return rc;
+  if (int rc = prep_dgrad_dual(a, dy1, w1, dy2, w2, dx, B, H, W, ldx, xcoff, Cin, N, Kp, ldy, ycoff, accumulate, dx_f32)) return rc;
   return launch<MODE_PLAIN>(a, stream);
 }
 
@@ -1242,20 +1322,20 @@ int kodhip_conv_dgrad_dual_bnred_slots(int B, int H, int W, int Cin, int N, int 
 
 int kodhip_conv_dgrad_dual_bnred(const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
                                  int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
-                                 int accumulate, const void* segments, int nseg, int slots, hipStream_t stream) {
+                                 int accumulate, void* dx_f32, const void* segments, int nseg, int slots, hipStream_t stream) {
   ConvArgs a;
-  if (int rc = prep_dgrad_dual(a, dy1, w1, dy2, w2, dx, B, H, W, ldx, xcoff, Cin, N, Kp, ldy, ycoff, accumulate)) return rc;
+  if (int rc = prep_dgrad_dual(a, dy1, w1, dy2, w2, dx, B, H, W, ldx, xcoff, Cin, N, Kp, ldy, ycoff, accumulate, dx_f32)) return rc;
   if (int rc = set_segments(a, (const BnRedSeg*)segments, nseg, slots, Cin)) return rc;
   return launch<MODE_PLAIN_BN>(a, stream);
 }
 
 int kodhip_conv_dgrad_s2_bnred(const void* dy, const void* w_dgrad_s2, void* dx,
                                int B, int H, int W, int ldx, int xcoff, int Cin, int N,
-                               int ldy, int ycoff, int accumulate, const void* segments, int nseg, int slots,
+                               int ldy, int ycoff, int accumulate, void* dx_f32, const void* segments, int nseg, int slots,
                                hipStream_t stream) {
   ConvArgs cls[4];
   bool all_fast;
-  if (int rc = prep_dgrad_s2(cls, all_fast, dy, w_dgrad_s2, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate)) return rc;
+  if (int rc = prep_dgrad_s2(cls, all_fast, dy, w_dgrad_s2, dx, B, H, W, ldx, xcoff, Cin, N, ldy, ycoff, accumulate, dx_f32)) return rc;
   KOD_CHECK_ARG(all_fast, "conv_dgrad_s2_bnred: this geometry cannot carry the fused reduction (query the slots first)");
   for (int c = 0; c < 4; ++c)
     if (int rc = set_segments(cls[c], (const BnRedSeg*)segments, nseg, slots, Cin)) return rc;

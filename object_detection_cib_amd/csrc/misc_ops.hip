@@ -182,7 +182,7 @@ __global__ void maxpool5_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_t*
 
 // dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic; same column sharing)
 __global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const unsigned char* idx,
-                                    bf16_t* dx, int ldx, int xcoff, int B, int H, int W, int C) {
+                                    bf16_t* dx, int ldx, int xcoff, int B, int H, int W, int C, const float* dx32) {
   const int CC = C >> 3;
   const int WG = (W + POOL_PX - 1) / POOL_PX;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,9 +200,10 @@ __global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const 
   for (int o = 0; o < POOL_PX; ++o) {
     const bool in = ix0 + o < W;
     bf16x8 old = {};
-    if (in) old = *reinterpret_cast<const bf16x8*>(dx + ((long)(b * H + iy) * W + ix0 + o) * ldx + xcoff + cc * 8);
+    const long po = ((long)(b * H + iy) * W + ix0 + o) * ldx + xcoff + cc * 8;
+    if (in && !dx32) old = *reinterpret_cast<const bf16x8*>(dx + po);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[o][e] = in ? (float)old[e] : 0.f;
+    for (int e = 0; e < 8; ++e) acc[o][e] = in ? (dx32 ? dx32[po + e] : (float)old[e]) : 0.f;      // dx32: fp32 partial
   }
   for (int dyy = 0; dyy < 5; ++dyy) {
     int oy = iy - dyy + 2;                 // output row whose window tap dyy hits iy
@@ -256,7 +257,7 @@ __global__ void upsample2x_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_
 }
 
 __global__ void upsample2x_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, bf16_t* dx, int ldx, int xcoff,
-                                      int accumulate, int B, int H, int W, int C) {  // H,W = input dims
+                                      int accumulate, int B, int H, int W, int C, const float* dx32) {  // H,W = input dims
   const int CC = C >> 3;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)B * H * W * CC;
@@ -269,7 +270,11 @@ __global__ void upsample2x_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, bf16
   int b = (int)(q / H);
   float acc[8];
   bf16_t* d = dx + p * ldx + xcoff + cc * 8;
-  if (accumulate) {
+  if (accumulate && dx32) {                 // the partial sum of the earlier producers, kept in fp32
+    const float* o32 = dx32 + p * ldx + xcoff + cc * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = o32[e];
+  } else if (accumulate) {
     bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = (float)old[e];
@@ -429,13 +434,15 @@ int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int
   return KOD_OK;
 }
 
+// dx_f32 (may be NULL): fp32 shadow of dx (same indexing) holding the partial sum the earlier producers left - read
+// instead of dx's bf16 content, so the total is rounded once (see kodhip_conv_dgrad's `accumulate`)
 int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, void* dx, int ldx, int xcoff,
-                        int B, int H, int W, int C, hipStream_t stream) {
+                        int B, int H, int W, int C, const float* dx_f32, hipStream_t stream) {
   KOD_CHECK_ARG(dy && dx && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
                 "maxpool5_bwd: bad args");
   long n = (long)B * H * ((W + POOL_PX - 1) / POOL_PX) * (C / 8);
   hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)dy, ldy, ycoff,
-                     (const unsigned char*)idx, (bf16_t*)dx, ldx, xcoff, B, H, W, C);
+                     (const unsigned char*)idx, (bf16_t*)dx, ldx, xcoff, B, H, W, C, dx_f32);
   KOD_LAUNCH_CHECK("maxpool5_bwd");
   return KOD_OK;
 }
@@ -452,12 +459,12 @@ int kodhip_upsample2x_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, i
 }
 
 int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx, int xcoff, int accumulate,
-                          int B, int H, int W, int C, hipStream_t stream) {
+                          int B, int H, int W, int C, const float* dx_f32, hipStream_t stream) {
   KOD_CHECK_ARG(dy && dx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
                 "upsample2x_bwd: bad args");
   long n = (long)B * H * W * (C / 8);
   hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)dy, ldy, ycoff,
-                     (bf16_t*)dx, ldx, xcoff, accumulate, B, H, W, C);
+                     (bf16_t*)dx, ldx, xcoff, accumulate, B, H, W, C, dx_f32);
   KOD_LAUNCH_CHECK("upsample2x_bwd");
   return KOD_OK;
 }

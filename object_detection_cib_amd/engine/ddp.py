@@ -47,14 +47,15 @@ def launch_bucket(flat: torch.Tensor, lo: int, hi: int, group=None, stream=None,
     stream: the side stream first waits for the caller's stream and for `also_after` (the weight-gradient stream
     that fills this bucket) - dependencies live in stream order only, so the code is hipGraph-capturable.  Without
     `stream` the collective is enqueued on the caller's stream itself: every collective of the step is then in ONE
-    stream order, identical on all ranks - the conservative default (Engine.comm_overlap).
+    stream order, identical on all ranks - the conservative switch (KODHIP_COMM_OVERLAP=0); the engine's default passes
+    the weight-gradient stream itself (Engine._comm_stream).
     CPU tensors (host-logic tests): a plain async_op Work."""
     if flat.is_cuda:
         cur = torch.cuda.current_stream()
         target = stream if stream is not None else cur
         if stream is not None:
             stream.wait_stream(cur)
-        if also_after is not None:           # e.g. the weight-gradient stream that fills this bucket
+        if also_after is not None and also_after is not target:      # e.g. the weight-gradient stream that fills this bucket
             target.wait_stream(also_after)
         if comm is not None:
             comm.all_reduce(flat[lo:hi], target.cuda_stream)

@@ -21,6 +21,8 @@ import torch
 from .. import _lib
 from .graph import Graph, ConvUnit, HeadUnit, View, Buf
 from .ddp import plan_buckets, launch_bucket
+from .options import EngineOptions
+from .plan import backward_writes, plan_f32_accumulation
 
 BN_EPS, BN_MOMENTUM = 1e-3, 0.03        # kod/nn/networks/yolov5.py:24
 
@@ -38,9 +40,11 @@ class _UnitState:
 class Engine:
     """Owns arenas + buffers for one network instance (one process, one GPU)."""
 
-    def __init__(self, graph: Graph, params: Dict[str, torch.nn.Parameter], buffers: Dict[str, torch.Tensor]):
+    def __init__(self, graph: Graph, params: Dict[str, torch.nn.Parameter], buffers: Dict[str, torch.Tensor],
+                 options: Optional[EngineOptions] = None):
         _lib.require_gpu()
         self.lib = _lib.lib()
+        self.opt = options or EngineOptions.from_env()      # every switch, read once (engine/options.py)
         self.g = graph
         self.params = params          # full state_dict-style names -> Parameter (shared with the nn.Module)
         self.buffers = buffers        # running_mean / running_var / num_batches_tracked
@@ -50,30 +54,30 @@ class Engine:
         # shape (validation batch, partial last batch) must never free what a graph replays into
         self._sets: Dict[tuple, dict] = {}
         self._pinned = set()          # shapes a captured graph depends on: never evicted
-        self.max_shape_sets = int(os.environ.get("KODHIP_MAX_SHAPE_SETS", "4"))
+        self.max_shape_sets = self.opt.max_shape_sets
         self.training_ready = False
         self.sync_bn = False
         self.process_group = None
         self.world_size = 1
         self.wg_stream = None          # side stream of the weight-gradient kernels (see backward)
-        self.wgrad_overlap = os.environ.get("KODHIP_WGRAD_OVERLAP", "1") != "0"
-        self.wgrad_fork = os.environ.get("KODHIP_WGRAD_FORK", "apply")     # see backward(): deferred capture of the wgrad launches
+        self.wgrad_overlap = self.opt.wgrad_overlap
+        self.wgrad_fork = self.opt.wgrad_fork     # see backward(): deferred capture of the wgrad launches
         self.comm = None               # RcclComm when the process group is RCCL-backed (the product path)
-        self.comm_buckets = None       # second communicator: gradient buckets on the side stream (comm_overlap)
-        self.comm_stream = None        # side stream of the gradient-bucket all-reduces
-        self.comm_overlap = os.environ.get("KODHIP_COMM_OVERLAP", "0") == "1"
+        self.comm_buckets = None       # second communicator: gradient buckets on the weight-gradient stream (comm_overlap)
+        self.comm_overlap = self.opt.comm_overlap
         self.collectives = False       # True when gradients / BN sums go through the process group (world > 1)
-        self.bucket_bytes = 8 << 20
+        self.bucket_bytes = int(self.opt.bucket_mb * (1 << 20))
+        self._checked_shapes = set()   # local batch shapes already compared across the ranks (SyncBN, see forward)
         self._pending = []
         self._packed_version = -1
         self.param_version = 0
-        self.stats_version = 0         # bumped whenever BatchNorm running statistics change (training forward, load)
+        self.stats_version = 0         # bumped by every eager training forward (BatchNorm running statistics moved)
         self._eval_aff = None          # eval-mode BN constants of all units (flat), see _eval_affine_ptrs
         self._fork_ev = None
         self.br_stream = None         # side stream of the CSP short_conv branch in forward()
         self.head_stream = None       # side stream of the P3 / P4 head convolutions in forward()
         self.aux_stream = None        # side stream of work that only depends on the step's inputs (label assignment)
-        self.branch_overlap = os.environ.get("KODHIP_BRANCH_OVERLAP", "1") != "0"
+        self.branch_overlap = self.opt.branch_overlap
         self.profile = None           # list of (family, start_event, end_event, algorithmic bytes), see _t0 / _t1
 
     # ------------------------------------------------------------------ arenas
@@ -218,12 +222,13 @@ class Engine:
     _HEAD_FIELDS = ("H", "W", "M", "dy", "ws")
 
     def _export_set(self) -> dict:
-        return dict(act=self.act, gact=self.gact, wg_part=self.wg_part, pool_idx=self.pool_idx,
+        return dict(act=self.act, gact=self.gact, gact32=self.gact32, wg_part=self.wg_part, pool_idx=self.pool_idx,
                     units={n: {f: getattr(st, f) for f in self._UNIT_FIELDS} for n, st in self.ustate.items()},
                     heads={n: {f: hs[f] for f in self._HEAD_FIELDS} for n, hs in self.hstate.items()})
 
     def _import_set(self, d: dict):
         self.act, self.gact, self.wg_part, self.pool_idx = d["act"], d["gact"], d["wg_part"], d["pool_idx"]
+        self.gact32 = d["gact32"]
         for n, fields in d["units"].items():
             st = self.ustate[n]
             for f, v in fields.items():
@@ -258,7 +263,6 @@ class Engine:
         dev = self.device
         lib = self.lib
         self.shape = key
-        self._check_equal_local_batch(key)
         self.act: Dict[str, torch.Tensor] = {}
         self.gact: Dict[str, torch.Tensor] = {}
         for b in self.g.bufs:
@@ -294,6 +298,10 @@ class Engine:
             splits = lib.kodhip_conv_wgrad_splits(st.M, u.cout, st.Kp)
             max_part = max(max_part, splits * u.cout * st.Kp)
         self._plan_bn_fusion(B)
+        self.gact32 = {}
+        if self._f32plan is not None:
+            for name in self._f32plan.shadow_bufs:
+                self.gact32[name] = torch.empty(self.gact[name].shape, dtype=torch.float32, device=dev)
         for h in self.g.heads:
             hs = self.hstate[h.name]
             hh, ww = H // h.stride, W // h.stride
@@ -313,9 +321,12 @@ class Engine:
     def _check_equal_local_batch(self, key):
         """SyncBN here divides the all-reduced sums by M_local * world_size (torch's SyncBatchNorm all-gathers the
         per-rank counts instead): that is only right when every rank holds the same number of pixels, so the first
-        allocation of a shape checks it across the group and refuses uneven local batches loudly."""
-        if not (self.collectives and self.sync_bn and self.world_size > 1):
+        TRAINING forward of a shape under SyncBN checks it across the group and refuses uneven local batches loudly.
+        (Only there: eval forwards exchange nothing, so validation on one rank, or with uneven last batches, must not
+        meet a collective.)"""
+        if not (self.collectives and self.sync_bn and self.world_size > 1) or key in self._checked_shapes:
             return
+        self._checked_shapes.add(key)
         import torch.distributed as dist
         shapes = [None] * self.world_size
         dist.all_gather_object(shapes, tuple(key), group=self.process_group)
@@ -334,7 +345,7 @@ class Engine:
             st.fused_red, st.segs, st.seg_slots = False, None, 0
         # dual data gradients: a CSP layer's main_conv and short_conv (both pointwise, same input) write dX in ONE launch
         self._dual = {}                # main unit name -> its short_conv unit
-        if os.environ.get("KODHIP_NO_DUAL") != "1":
+        if self.opt.dual_dgrad:
             for u in self.exec_units:
                 v = u.sibling
                 if (v is not None and u.k == v.k == 1 and u.s == v.s == 1 and u.p == v.p == 0 and u.cout == v.cout
@@ -342,25 +353,17 @@ class Engine:
                         and u.cout % 8 == 0):
                     self._dual[u.name] = v
         dual_shorts = {v.name for v in self._dual.values()}
-        if os.environ.get("KODHIP_NO_BNRED") == "1":
+        # activation gradients with several producers: accumulated in fp32 (one rounding) instead of bf16 read-modify-write
+        self._f32plan = None
+        if self.opt.dx_accum_fp32:
+            self._f32plan = plan_f32_accumulation(backward_writes(self.g, dual_shorts)[0], {b.name: b.C for b in self.g.bufs})
+            if self.opt.debug_plan:
+                print(f"[kodhip] fp32 accumulation of multi-producer gradients: shadows {sorted(self._f32plan.shadow_bufs)}; "
+                      f"bf16 (unsupported) {self._f32plan.unsupported}", flush=True)
+        if not self.opt.bn_reduce_fused:
             return
-        writes, upos, pos = [], {}, 0      # (position, writer unit name | None, buffer, lo, hi)
-        for op in reversed(self.g.ops):
-            if op.kind == "conv":
-                u = op.unit
-                upos[u.name] = pos
-                pos += 1
-                if u.residual is not None:
-                    r = u.residual
-                    writes.append((pos, None, r.buf.name, r.coff, r.coff + r.C))
-                    pos += 1
-                if not u.stem and u.name not in dual_shorts:       # (a fused short_conv's dX is written by its main_conv's launch)
-                    writes.append((pos, u.name, u.src.buf.name, u.src.coff, u.src.coff + u.src.C))
-                    pos += 1
-            else:
-                v = op.unit.src if op.kind == "head" else op.src
-                writes.append((pos, None, v.buf.name, v.coff, v.coff + v.C))
-                pos += 1
+        ws, upos = backward_writes(self.g, dual_shorts)          # engine/plan.py: who writes which gradient buffer, in order
+        writes = [(w.pos, w.unit, w.buf, w.lo, w.hi) for w in ws]
         plan = {}
         for u in self.exec_units:
             lo, hi = u.dst.coff, u.dst.coff + u.dst.C
@@ -376,7 +379,7 @@ class Engine:
             ws = self.ustate[wname]
             s2 = int(w.k == 3 and w.s == 2 and w.p == 1)
             # (A/B knob: only fuse into launches whose reduction length is at least KODHIP_BNRED_MINK; measured best: all)
-            if w.k * w.k * w.cout < int(os.environ.get("KODHIP_BNRED_MINK", "0")):
+            if w.k * w.k * w.cout < self.opt.bn_reduce_min_k:
                 continue
             if wname in self._dual:
                 slots = lib.kodhip_conv_dgrad_dual_bnred_slots(B, ws.H, ws.W, w.cin, w.cout, w.cout)
@@ -397,7 +400,7 @@ class Engine:
                 segs[i].raw, segs[i].ldr = st.raw.data_ptr(), u.cout
                 segs[i].aff, segs[i].partials = st.aff.data_ptr(), st.bpart.data_ptr()
             ws.segs, ws.seg_slots = segs, slots
-        if os.environ.get("KODHIP_DEBUG_PLAN"):
+        if self.opt.debug_plan:
             fused = [u.name for u in self.exec_units if self.ustate[u.name].fused_red]
             print(f"[kodhip] BN-backward reduction fused into a data gradient for {len(fused)} of {len(self.exec_units)} units; "
                   f"separate pass: {[u.name for u in self.exec_units if not self.ustate[u.name].fused_red]}", flush=True)
@@ -478,6 +481,8 @@ class Engine:
         fp, pa = self.fpack.data_ptr(), self.p_arena.data_ptr()
         eval_aff = None if training else self._eval_affine_ptrs()
         sync = training and self.sync_bn and self.collectives
+        if sync:
+            self._check_equal_local_batch((B, H, W))
         rm, rv = self.rm_arena.data_ptr(), self.rv_arena.data_ptr()
 
         def conv_stage(u: ConvUnit, s=s):
@@ -636,7 +641,9 @@ class Engine:
         running statistics changed - not per layer per forward (a validation epoch forwards many batches with frozen
         weights).  Kept apart from the training constants (st.aff), so an eval forward never disturbs a pending backward.
         Returns {unit name: (scale ptr, shift ptr)}."""
-        key = (self.param_version, self.stats_version)
+        # keyed on the arenas' own version counters too: in-place edits that bypass the engine (EMA swap,
+        # reset_running_stats, a non-fused optimizer, a user-captured graph replay bumps nothing - see invalidate_eval_constants)
+        key = (self.param_version, self.stats_version, self.p_arena._version, self.rm_arena._version, self.rv_arena._version)
         if self._eval_aff is None:
             gi, bi, ri, off = [], [], [], 0
             self._eval_off = {}
@@ -748,8 +755,21 @@ class Engine:
             touched.add(name)
             if v.C != v.buf.C:
                 self.gact[name].zero_()
+                if name in self.gact32:
+                    self.gact32[name].zero_()
                 return 1
             return 0
+
+        op_index = {id(o): i for i, o in enumerate(self.g.ops)}
+
+        def f32(kind, ident, v: View):
+            """(bits 8.. of the `accumulate` argument, fp32 shadow pointer) of one gradient-buffer write (engine/plan.py)"""
+            if self._f32plan is None:
+                return 0, None
+            mode = self._f32plan.modes.get((kind, op_index[id(ident)] if kind in ("up", "pool") else ident), 0)
+            sh = self.gact32.get(v.buf.name)
+            return mode << 8, (sh.data_ptr() if (sh is not None and mode in (1, 2, 3)) else None)
+        self._f32 = f32
 
         self._pending = []
         buckets = {}
@@ -855,11 +875,12 @@ class Engine:
                                              B, hs["H"] * hs["W"], A, nc, self.head_npad, hs_), hu.name)
                 fork_point(hstream)
                 acc = acc_flag(src)
+                fm, fptr = f32("head", hu.name, src)
                 e0 = self._t0()
                 chk(lib.kodhip_conv_dgrad(hs["dy"].data_ptr(), dp + 2 * hs["d_off"], self._ptr(src, True),
                                           B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
                                           self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kdp"], self.head_npad, 0,
-                                          acc, hs_), hu.name + ".dgrad")
+                                          acc | fm, fptr, hs_), hu.name + ".dgrad")
                 self._t1(e0, "dgrad", 2.0 * hs["M"] * (self.head_npad + hu.cin))
                 if side:
                     ev = torch.cuda.Event()
@@ -874,14 +895,14 @@ class Engine:
                 h, w = H // op.src.stride, W // op.src.stride
                 chk(lib.kodhip_upsample2x_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
                                               self._ptr(op.src, True), op.src.buf.C, op.src.coff,
-                                              acc_flag(op.src), B, h, w, op.src.C, s), "upsample_bwd")
+                                              acc_flag(op.src), B, h, w, op.src.C, f32("up", op, op.src)[1], s), "upsample_bwd")
             elif op.kind == "pool":
                 pool_i -= 1
                 h, w = H // op.src.stride, W // op.src.stride
                 # src and dst are slices of the same (already initialised) concat gradient buffer
                 chk(lib.kodhip_maxpool5_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
                                             self.pool_idx[pool_i].data_ptr(), self._ptr(op.src, True),
-                                            op.src.buf.C, op.src.coff, B, h, w, op.src.C, s), "maxpool_bwd")
+                                            op.src.buf.C, op.src.coff, B, h, w, op.src.C, f32("pool", op, op.src)[1], s), "maxpool_bwd")
             else:
                 group = [op.unit]
                 # SyncBN: short_conv (reached first in reverse order) and its main_conv share one exchange - main's
@@ -938,11 +959,12 @@ class Engine:
                             self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
                             *geo, st.Kp, C_, 0, C_, 0, 1.0)
                 return
-            acc_src = acc_flag(u.src)
+            fm, fptr = self._f32("dgrad", u.name, u.src)
+            acc_src = acc_flag(u.src) | fm
             in_px = B * st.H * st.W
             # dY read once, dX written once (+ read when accumulating), + the re-read of the producers' pre-BN
             # tensors when this launch carries their BatchNorm-backward reduction
-            nb = 2.0 * st.M * C_ + (4.0 if acc_src else 2.0) * in_px * u.cin
+            nb = 2.0 * st.M * C_ + (4.0 if acc_src & 1 else 2.0) * in_px * u.cin
             if st.segs is not None:
                 nb += 2.0 * in_px * sum(sg.ch_count for sg in st.segs)
             e0 = self._t0()
@@ -951,7 +973,7 @@ class Engine:
                 nb += 2.0 * ps.M * partner.cout
                 fn = lib.kodhip_conv_dgrad_dual if st.segs is None else lib.kodhip_conv_dgrad_dual_bnred
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, ps.raw.data_ptr(), dp + 2 * ps.d_off, self._ptr(u.src, True),
-                       B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, st.Kdp, C_, 0, acc_src, *fz, s), u.name + ".dgrad2")
+                       B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, st.Kdp, C_, 0, acc_src, fptr, *fz, s), u.name + ".dgrad2")
             elif u.k == 3 and u.s == 2 and u.p == 1:
                 if st.s2_fold:
                     fn = lib.kodhip_conv_dgrad_s2f if st.segs is None else lib.kodhip_conv_dgrad_s2f_bnred
@@ -959,11 +981,11 @@ class Engine:
                     fn = lib.kodhip_conv_dgrad_s2 if st.segs is None else lib.kodhip_conv_dgrad_s2_bnred
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
                        B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,
-                       acc_src, *fz, s), u.name + ".dgrad")
+                       acc_src, fptr, *fz, s), u.name + ".dgrad")
             else:
                 fn = lib.kodhip_conv_dgrad if st.segs is None else lib.kodhip_conv_dgrad_bnred
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
-                       *geo, st.Kdp, C_, 0, acc_src, *fz, s), u.name + ".dgrad")
+                       *geo, st.Kdp, C_, 0, acc_src, fptr, *fz, s), u.name + ".dgrad")
             self._t1(e0, "dgrad" if st.segs is None else "dgrad+bn_reduce", nb)
         cin_true = 3 if u.stem else u.cin
         in_px_w = B * H * W if u.stem else B * st.H * st.W
@@ -974,15 +996,16 @@ class Engine:
 
 
     def _comm_stream(self):
-        """Side stream of the gradient-bucket all-reduces, or None: by default every collective of the step (SyncBN
-        sums and gradient buckets) is enqueued on the main stream, i.e. in one order that is the same on all ranks
-        by construction.  KODHIP_COMM_OVERLAP=1 moves the buckets to a side stream (overlapped with the rest of
-        backward; collectives of one communicator then come from two streams)."""
-        if not self.comm_overlap:
+        """Stream of the gradient-bucket all-reduces.  Default (comm_overlap): the WEIGHT-GRADIENT side stream, through
+        the buckets' own communicator - a bucket is enqueued right behind the last weight gradient that fills it and
+        overlaps the rest of backward on the main stream (torch DDP's reducer does the same with its hooks; north_star:
+        "all-reduce overlapped with the backward pass").  SyncBN sums (main stream, `comm`) and buckets (side stream,
+        `comm_buckets`) never share a communicator, so no communicator sees calls from two streams; every rank enqueues
+        the same program, so the order inside each stream / graph branch is the same on all ranks.
+        KODHIP_COMM_OVERLAP=0: None = everything on the main stream in one order (the conservative switch)."""
+        if not self.comm_overlap or self.wg_stream is None or not self.wgrad_overlap:
             return None
-        if self.comm_stream is None:
-            self.comm_stream = torch.cuda.Stream(device=self.device)
-        return self.comm_stream
+        return self.wg_stream
 
     def wait_grads(self):
         for w in self._pending:
@@ -1043,3 +1066,10 @@ class Engine:
 
     def mark_params_changed(self):
         self.param_version += 1
+
+    def invalidate_eval_constants(self):
+        """Call after anything the version counters cannot see changed parameters or running statistics - i.e. a
+        replay of a user-captured hipGraph that contains a training forward or an optimizer step (GraphedTrainStep
+        does it itself)."""
+        self.param_version += 1
+        self.stats_version += 1

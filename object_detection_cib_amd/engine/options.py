@@ -1,0 +1,68 @@
+"""EngineOptions - every switch of the HIP engine in one object.
+
+The switches are A/B and diagnostic knobs (none changes results beyond floating-point summation order, DESIGN.md
+section 7); they are read from the environment ONCE, when the engine is built, and the resulting object is what the
+engine consults and what bench.py logs into its JSON line - an A/B result is attributable from the record alone.
+Kernel-selection knobs that libkodhip.so reads itself (tile shapes, stride-2 forms, ...) are recorded verbatim in
+`native` so the record is complete.
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+from dataclasses import dataclass, field
+from typing import Dict
+
+# knobs libkodhip.so reads with getenv (csrc/conv_igemm.hip, csrc/conv_wgrad.hip)
+NATIVE_KNOBS = ("KODHIP_NO_FAST", "KODHIP_FORCE_BM", "KODHIP_FORCE_BN", "KODHIP_S2_SEPARATE", "KODHIP_S2_FOLD_MAXC",
+                "KODHIP_S2_INTERLEAVE", "KODHIP_ROW3", "KODHIP_ROW3_MODES", "KODHIP_WGRAD_DMA", "KODHIP_WGRAD_SLOTS",
+                "KODHIP_LIB")
+
+
+def _flag(name: str, default: bool) -> bool:
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    return v not in ("0", "", "false", "False")
+
+
+@dataclass
+class EngineOptions:
+    wgrad_overlap: bool = True        # KODHIP_WGRAD_OVERLAP: weight gradients on a side stream
+    wgrad_fork: str = "apply"         # KODHIP_WGRAD_FORK: "apply" (event where dY is ready, captured after the dgrad) | "legacy"
+    branch_overlap: bool = True       # KODHIP_BRANCH_OVERLAP: CSP short_conv branches / P3-P4 heads on side streams
+    comm_overlap: bool = True         # KODHIP_COMM_OVERLAP: gradient buckets on the weight-gradient stream, own communicator
+    force_collectives: bool = False   # KODHIP_FORCE_COLLECTIVES: keep the N>1 code path on a 1-rank group
+    syncbn_exchange: str = "auto"     # KODHIP_SYNCBN: "rccl" | "peer" (IPC peer buffers) | "auto" (peer when every rank is on this node)
+    dual_dgrad: bool = True           # KODHIP_NO_DUAL=1 switches off
+    bn_reduce_fused: bool = True      # KODHIP_NO_BNRED=1 switches off
+    bn_reduce_min_k: int = 0          # KODHIP_BNRED_MINK
+    dx_accum_fp32: bool = False       # KODHIP_DX_FP32: multi-consumer activation gradients accumulated in fp32
+    wgrad_reduce_batched: bool = True  # KODHIP_WGRAD_REDUCE=layer: one slab reduction per layer (round 2) instead of per bucket
+    debug_plan: bool = False          # KODHIP_DEBUG_PLAN
+    max_shape_sets: int = 4           # KODHIP_MAX_SHAPE_SETS
+    bucket_mb: float = 8.0
+    native: Dict[str, str] = field(default_factory=dict)
+
+    @staticmethod
+    def from_env() -> "EngineOptions":
+        e = os.environ
+        return EngineOptions(
+            wgrad_overlap=_flag("KODHIP_WGRAD_OVERLAP", True),
+            wgrad_fork=e.get("KODHIP_WGRAD_FORK", "apply"),
+            branch_overlap=_flag("KODHIP_BRANCH_OVERLAP", True),
+            comm_overlap=_flag("KODHIP_COMM_OVERLAP", True),
+            force_collectives=_flag("KODHIP_FORCE_COLLECTIVES", False),
+            syncbn_exchange=e.get("KODHIP_SYNCBN", "auto"),
+            dual_dgrad=not _flag("KODHIP_NO_DUAL", False),
+            bn_reduce_fused=not _flag("KODHIP_NO_BNRED", False),
+            bn_reduce_min_k=int(e.get("KODHIP_BNRED_MINK", "0")),
+            dx_accum_fp32=_flag("KODHIP_DX_FP32", False),
+            wgrad_reduce_batched=e.get("KODHIP_WGRAD_REDUCE", "bucket") != "layer",
+            debug_plan=_flag("KODHIP_DEBUG_PLAN", False),
+            max_shape_sets=int(e.get("KODHIP_MAX_SHAPE_SETS", "4")),
+            native={k: e[k] for k in NATIVE_KNOBS if k in e},
+        )
+
+    def as_dict(self) -> dict:
+        return dataclasses.asdict(self)

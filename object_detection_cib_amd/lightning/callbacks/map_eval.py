@@ -129,17 +129,15 @@ class DeviceMAPEvaluator:
         return self
 
     def get_report(self, process_group=None, sync: str = "mean") -> dict:
-        """Single process: the report of this evaluator.  With a process group (validation sharded over ranks):
+        """process_group None (default): the report of THIS evaluator, no collective - also inside an initialised
+        torch.distributed job, so validation on one rank only can never hang on its peers.  With an explicit process
+        group (validation sharded over its ranks; `torch.distributed.group.WORLD` for the default group):
         sync="mean"   - every rank evaluates its own shard and the logged values are averaged over ranks, which is what
                         the reference does (`pl_module.log_dict(results, sync_dist=True)`, pycoco_map_eval.py:139-142);
         sync="global" - match records are gathered first (gather()), giving the mAP of the whole validation set."""
-        if process_group is None and sync == "mean":
-            import torch.distributed as dist
-            if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-                return self._report_of(self.average_precision())
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
+        if process_group is None:
             return self._report_of(self.average_precision())
+        import torch.distributed as dist
         if sync == "global":
             return self.gather(process_group)._report_of(self.average_precision())
         rep = self._report_of(self.average_precision())

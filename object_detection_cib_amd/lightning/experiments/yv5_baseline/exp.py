@@ -13,6 +13,7 @@ from typing import Callable, Optional, Sequence
 
 import torch
 
+from .... import _lib
 from ....core.types import FeatureShape
 from ....core.nms import non_max_suppression
 from ....nn.optim.smart import SmartOptimizer, FusedSGD
@@ -36,6 +37,7 @@ def _gc_paused():
     finally:
         if was:
             gc.enable()
+        gc.collect()            # reference cycles built while paused (they may hold device tensors) go now
 
 
 class DefaultYolov5Experiment:
@@ -66,6 +68,9 @@ class DefaultYolov5Experiment:
         # arithmetic, no per-launch Python; batches must keep one shape and at most max_targets boxes
         self.graphed, self.max_targets, self._gstep = graphed, max_targets, None
         self._geval = {}              # input shape -> GraphedEvalForward
+        # cross-rank validation is opt-in: None = every rank reports its own shard (a rank-0-only validation never
+        # meets a collective); a process group + "mean" / "global" = DeviceMAPEvaluator.get_report's two DDP modes
+        self.val_process_group, self.val_sync = None, "mean"
 
     # exp.py:156-162
     def configure_optimizers(self):
@@ -144,6 +149,9 @@ class DefaultYolov5Experiment:
         lr, mom, wd = self.optimizer.hyper()
         total, (box, obj, cls) = self._gstep(images, targets, lr, mom, wd, 1.0 / self.optimizer.world_size)
         self.optimizer.steps_taken += 1
+        # the replayed graph contains the SGD update: tell torch's bookkeeping that a step happened (LambdaLR.step() checks
+        # optimizer._step_count to warn about a scheduler stepped before the optimizer)
+        self.optimizer._step_count = getattr(self.optimizer, "_step_count", 0) + 1
         self.logged = {"obj": obj, "cls": cls, "box": box}
         self.global_step += 1
         return total.clone()
@@ -156,6 +164,7 @@ class DefaultYolov5Experiment:
 
     def fit_epoch(self, batches: Sequence, num_training_batches: Optional[int] = None):
         n = num_training_batches or len(batches)
+        _lib.limit_host_threads()      # the epoch loops are the library's own: size torch's host pool to the cgroup share
         with _gc_paused():
             losses = [self.optimize(b, n).detach() for b in batches]
         self.end_epoch()
@@ -163,8 +172,9 @@ class DefaultYolov5Experiment:
 
     def validate(self, batches: Sequence, num_classes: int, class_names=None) -> dict:
         ev = DeviceMAPEvaluator(num_classes, class_names)
+        _lib.limit_host_threads()
         with _gc_paused():
             for b in batches:
                 targets, dets = self.validation_step(b)
                 ev.add_batch(targets, dets)
-        return ev.get_report()
+        return ev.get_report(self.val_process_group, self.val_sync)

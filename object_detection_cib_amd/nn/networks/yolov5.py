@@ -97,6 +97,7 @@ class Yolov5Network(nn.Module):
                 _ensure(self, f"{h.name}.{key}_head").add_module("conv", conv)
         self._engine: Engine | None = None
         self._engine_device = None
+        self.engine_options = None         # an EngineOptions to build the engine with (None: EngineOptions.from_env())
 
     # ------------------------------------------------------------------ engine plumbing
     def engine(self) -> Engine:
@@ -104,7 +105,7 @@ class Yolov5Network(nn.Module):
         if self._engine is None or self._engine_device != dev:
             if dev.type != "cuda":
                 raise RuntimeError("Yolov5Network (HIP) must be on an MI355X: call .cuda() first; no CPU fallback")
-            eng = Engine(self.graph, dict(self.named_parameters()), dict(self.named_buffers()))
+            eng = Engine(self.graph, dict(self.named_parameters()), dict(self.named_buffers()), self.engine_options)
             eng._build_arenas(dev)
             self._engine, self._engine_device = eng, dev
         return self._engine
@@ -123,14 +124,15 @@ class Yolov5Network(nn.Module):
         eng.world_size = dist.get_world_size(process_group)
         eng.sync_bn = sync_batchnorm
         # KODHIP_FORCE_COLLECTIVES=1 keeps the collective code path on a 1-rank group (single-GPU rehearsal of the N>1 path)
-        eng.collectives = eng.world_size > 1 or os.environ.get("KODHIP_FORCE_COLLECTIVES") == "1"
+        eng.collectives = eng.world_size > 1 or eng.opt.force_collectives
         eng.bucket_bytes = int(bucket_mb * (1 << 20))
+        eng.opt.bucket_mb = bucket_mb
         if native_rccl is None:
             native_rccl = dist.get_backend(process_group) == "nccl"
         if eng.collectives and native_rccl and eng.comm is None:
             from ...engine.comm import RcclComm
             eng.comm = RcclComm(process_group, eng.device)
-            if eng.comm_overlap:          # KODHIP_COMM_OVERLAP=1: gradient buckets on a side stream, own communicator
+            if eng.comm_overlap:          # default: gradient buckets on the weight-gradient stream, own communicator
                 eng.comm_buckets = RcclComm(process_group, eng.device)
         if eng.collectives:
             # rank 0's parameters and BatchNorm buffers everywhere (torch DDP does this at wrap time)
@@ -176,6 +178,12 @@ class Yolov5Network(nn.Module):
             # the assignment depends only on the targets: its (three-block, latency-bound) kernel runs on a side stream
             # beside the forward pass instead of between the heads and the loss
             cur = torch.cuda.current_stream()
+            # device-resident DetectionTargets (what a Lightning training_step passes) are concatenated by torch kernels
+            # on the CURRENT stream: do that before the fork event, or the side stream's assignment kernel could read the
+            # boxes before they are written
+            from ...core.label_assignment.yv5 import BatchedTargets
+            if not isinstance(targets, BatchedTargets):
+                targets = BatchedTargets.from_targets(targets, eng.device)
             if eng.aux_stream is None:
                 # the CSP branches' stream: side-stream work of one captured stream runs in launch order
                 if eng.br_stream is None:

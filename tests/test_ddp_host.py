@@ -97,9 +97,11 @@ def _map_worker(rank, world, port, q):
     try:
         ev = DeviceMAPEvaluator(5)
         _fake_records(ev, np.random.default_rng(100 + rank), 20)
-        local = ev.get_report(sync="local") if False else ev._report_of(ev.average_precision())
-        mean = ev.get_report(sync="mean")                 # reference semantics: log_dict(sync_dist=True)
-        glob = ev.get_report(sync="global")               # exact: match records gathered in rank order
+        local = ev.get_report()                           # no process group: this rank's own report, no collective
+        assert local == ev._report_of(ev.average_precision())
+        world_group = dist.group.WORLD                    # cross-rank reports are opt-in: an explicit group
+        mean = ev.get_report(world_group, sync="mean")    # reference semantics: log_dict(sync_dist=True)
+        glob = ev.get_report(world_group, sync="global")  # exact: match records gathered in rank order
         q.put((rank, local, mean, glob))
     finally:
         dist.destroy_process_group()

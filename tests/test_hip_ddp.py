@@ -116,10 +116,14 @@ def _native_worker(port, size, out):
 
         x, tg = _data(size)
         res = {}
-        for mode in ("plain", "collectives-eager", "collectives-graph", "overlap-eager", "overlap-graph"):
+        for mode in ("plain", "default-eager", "default-graph", "inorder-eager", "inorder-graph"):
             net, loss = _build(5)
             eng = net.engine()
-            eng.comm_overlap = mode.startswith("overlap")        # = KODHIP_COMM_OVERLAP=1
+            # default-*: what a job gets without any switch - gradient buckets overlapped with backward on the
+            # weight-gradient stream through their own communicator; inorder-*: KODHIP_COMM_OVERLAP=0
+            assert eng.comm_overlap, "bucket / backward overlap must be the default"
+            if mode.startswith("inorder"):
+                eng.comm_overlap = False
             if mode != "plain":
                 net.configure_distributed(None, sync_batchnorm=True, bucket_mb=0.5, native_rccl=True)
                 assert eng.comm is not None and eng.collectives
@@ -180,8 +184,34 @@ def test_native_rccl_comm_and_captured_step(tmp_path):
     assert p.exitcode == 0
     res = torch.load(out)
     ref_l, ref_p = res["plain"]
-    # overlap-*: gradient buckets on a side stream through their own communicator (KODHIP_COMM_OVERLAP=1), eager and captured
-    for mode in ("collectives-eager", "collectives-graph", "overlap-eager", "overlap-graph"):
+    # default-*: gradient buckets on the weight-gradient stream through their own communicator, eager and captured;
+    # inorder-*: every collective on the main stream (KODHIP_COMM_OVERLAP=0)
+    for mode in ("default-eager", "default-graph", "inorder-eager", "inorder-graph"):
         l, prm = res[mode]
         assert l == ref_l, (mode, l, ref_l)
         assert torch.equal(prm, ref_p), mode
+
+
+def test_bench_self_launch_runs_the_collective_path():
+    """`python bench.py --gpus N` with WORLD_SIZE unset (the driver's plain command) starts the ranks itself.  Rehearsed
+    here with one rank and KODHIP_FORCE_COLLECTIVES=1: a fresh child process, its own RCCL communicators, SyncBN sums +
+    gradient buckets (overlapped with backward, the default) inside the replayed hipGraph; ONE JSON line comes back."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["KODHIP_FORCE_COLLECTIVES"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--launch", "self", "--steps", "3",
+                        "--warmup", "2", "--batch", "8", "--size", "320", "--no-cpu-baseline", "--timeout", "400"],
+                       capture_output=True, text=True, timeout=500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and len(d["per_rank_images_per_sec"]) == 1
+    cfg = d["config"]
+    assert cfg["launcher"] == "self" and cfg["launch"] == "hipGraph replay", cfg
+    assert "RCCL" in cfg["collectives"] and "overlapped with backward" in cfg["collectives"], cfg
+    assert d["engine_options"]["comm_overlap"] is True and d["engine_options"]["force_collectives"] is True
+    assert abs(sum(f["share_of_step"] for f in d["families"]) - 1.0) < 0.02

@@ -67,11 +67,11 @@ def test_conv_fwd_dgrad_wgrad(case):
     dyb = nhwc(dy)
     dxb = torch.zeros((B, H, W, Cin), dtype=torch.bfloat16, device="cuda")
     _lib.check(lib.kodhip_conv_dgrad(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
-                                     Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 0, stream()), "dgrad")
+                                     Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 0, None, stream()), "dgrad")
     _close(nchw(dxb), xr.grad, 1e-2, 3e-2, "dgrad")
     # accumulate form
     _lib.check(lib.kodhip_conv_dgrad(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
-                                     Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 1, stream()), "dgrad acc")
+                                     Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 1, None, stream()), "dgrad acc")
     _close(nchw(dxb), 2 * xr.grad, 2e-2, 6e-2, "dgrad accumulate")
     # wgrad
     M = B * Ho * Wo
@@ -105,7 +105,7 @@ def test_conv_dgrad_stride2_parity_classes(case, form):
     dxb = torch.zeros((B, H, W, ld), dtype=torch.bfloat16, device="cuda")
     for acc, mult in ((0, 1.0), (1, 2.0)):
         _lib.check(fn(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, ld, 8, Cin,
-                      Cout, Cout, 0, acc, stream()), "dgrad_s2 " + form)
+                      Cout, Cout, 0, acc, None, stream()), "dgrad_s2 " + form)
         got = nchw(dxb)
         _close(got[:, 8:8 + Cin], mult * x.grad, 1e-2 * mult, 3e-2 * mult, "dgrad s2 " + form)
         assert (got[:, :8] == 0).all() and (got[:, 8 + Cin:] == 0).all()
@@ -195,7 +195,7 @@ def test_head_conv_fwd_bwd():
         _close(d.cpu(), r.grad, 1e-4, 1e-4, "head bias grad")
     dx = torch.zeros((B, H, W, C), dtype=torch.bfloat16, device="cuda")
     _lib.check(lib.kodhip_conv_dgrad(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, W, C, 0, C, npad, 1, 1, 1, 1,
-                                     0, 0, pk["Kdp"], npad, 0, 0, stream()), "head dgrad")
+                                     0, 0, pk["Kdp"], npad, 0, 0, None, stream()), "head dgrad")
     _close(nchw(dx), xr.grad, 2e-2, 3e-2, "head dgrad")
     splits = lib.kodhip_conv_wgrad_splits(B * H * W, npad, pk["Kp"])
     part = torch.zeros(splits * npad * pk["Kp"], dtype=torch.float32, device="cuda")
@@ -288,7 +288,7 @@ def test_maxpool_chain_and_upsample():
     gb = nhwc(dcat)
     for q in (2, 1, 0):
         _lib.check(lib.kodhip_maxpool5_bwd(gb.data_ptr(), 4 * C, (q + 1) * C, idx[q].data_ptr(), gb.data_ptr(), 4 * C,
-                                           q * C, B, H, W, C, stream()), "pool bwd")
+                                           q * C, B, H, W, C, None, stream()), "pool bwd")
     _close(nchw(gb)[:, :C], xr.grad, 2e-2, 5e-3 * xr.grad.abs().max().item(), "pool chain grad")
     # upsample
     up = F.interpolate(xr, scale_factor=2, mode="nearest")
@@ -302,7 +302,7 @@ def test_maxpool_chain_and_upsample():
     dub = torch.zeros_like(ub)
     dub[..., 8:] = nhwc(dup)
     dx = torch.ones((B, H, W, C), dtype=torch.bfloat16, device="cuda")
-    _lib.check(lib.kodhip_upsample2x_bwd(dub.data_ptr(), C + 8, 8, dx.data_ptr(), C, 0, 1, B, H, W, C, stream()), "up bwd")
+    _lib.check(lib.kodhip_upsample2x_bwd(dub.data_ptr(), C + 8, 8, dx.data_ptr(), C, 0, 1, B, H, W, C, None, stream()), "up bwd")
     _close(nchw(dx), xr.grad + 1, 1e-2, 2e-2, "upsample grad (accumulate)")
 
 
@@ -385,10 +385,10 @@ def test_conv_dgrad_with_fused_bn_backward_reduction(case):
     if s2:
         fn = lib.kodhip_conv_dgrad_s2f_bnred if fold else lib.kodhip_conv_dgrad_s2_bnred
         _lib.check(fn(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
-                      Cout, Cout, 0, 0, sp, len(prods), slots, stream()), "dgrad_s2_bnred")
+                      Cout, Cout, 0, 0, None, sp, len(prods), slots, stream()), "dgrad_s2_bnred")
     else:
         _lib.check(lib.kodhip_conv_dgrad_bnred(dyb.data_ptr(), pk["d"].data_ptr(), dxb.data_ptr(), B, H, W, Cin, 0, Cin,
-                                               Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 0, sp, len(prods), slots,
+                                               Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 0, None, sp, len(prods), slots,
                                                stream()), "dgrad_bnred")
     _close(nchw(dxb), x.grad, 1e-2, 3e-2, "dX of the fused launch")
     for pr in prods:
@@ -440,7 +440,7 @@ def test_conv_dgrad_dual_source(case):
         if split is None:
             _lib.check(lib.kodhip_conv_dgrad_dual(dyb[0].data_ptr(), pks[0]["d"].data_ptr(), dyb[1].data_ptr(),
                                                   pks[1]["d"].data_ptr(), dxb.data_ptr(), B, H, W, ld, coff, Cin, N,
-                                                  pks[0]["Kdp"], N, 0, acc, stream()), "dgrad_dual")
+                                                  pks[0]["Kdp"], N, 0, acc, None, stream()), "dgrad_dual")
         else:
             slots = lib.kodhip_conv_dgrad_dual_bnred_slots(B, H, W, Cin, N, N)
             assert slots > 0
@@ -459,7 +459,7 @@ def test_conv_dgrad_dual_source(case):
                 segs[i].aff, segs[i].partials = pr["aff"].data_ptr(), pr["part"].data_ptr()
             _lib.check(lib.kodhip_conv_dgrad_dual_bnred(dyb[0].data_ptr(), pks[0]["d"].data_ptr(), dyb[1].data_ptr(),
                                                         pks[1]["d"].data_ptr(), dxb.data_ptr(), B, H, W, ld, coff, Cin, N,
-                                                        pks[0]["Kdp"], N, 0, acc, C.cast(segs, C.c_void_p), len(prods),
+                                                        pks[0]["Kdp"], N, 0, acc, None, C.cast(segs, C.c_void_p), len(prods),
                                                         slots, stream()), "dgrad_dual_bnred")
         got = nchw(dxb)
         _close(got[:, coff:coff + Cin], x.grad + 0.5 * acc, 2e-2, 4e-2, f"dual dgrad acc={acc}")
@@ -509,7 +509,7 @@ def test_conv3x3_result_independent_of_tile_position(case):
         b = ds.shape[0]
         dx = torch.zeros(b, H, W, C, device="cuda", dtype=torch.bfloat16)
         _lib.check(lib.kodhip_conv_dgrad(ds.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), b, H, W, C, 0, C, N, 3, 3, 1, 1,
-                                         1, 1, pk["Kdp"], N, 0, 0, stream()), "dgrad")
+                                         1, 1, pk["Kdp"], N, 0, 0, None, stream()), "dgrad")
         return dx
     y, st = fwd(xb)
     ref = F.conv2d(x, w, None, 1, 1)

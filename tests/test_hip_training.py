@@ -287,3 +287,33 @@ def test_class_aware_mixup_reweighted_config_tracks_cpu_oracle():
     rel = np.abs(hip - cpu) / np.abs(cpu)
     assert rel[:5].max() < 1e-2 and rel.max() < 5e-2, rel
     assert float(full.max()) > 5.0          # the Zipf tail really is re-weighted (pos_weight = sum(count) / count_c)
+
+
+def test_train_step_with_device_resident_targets_equals_prebuilt_batch():
+    """A Lightning training_step hands `train_step` a tuple of DetectionTargets that already live on the GPU: their
+    concatenation (torch kernels on the current stream) must be ordered before the side stream's assignment kernel.
+    Same losses and gradients, bit for bit, as with a prebuilt BatchedTargets - repeated, with the main stream kept
+    busy in front so that a missing dependency would show."""
+    from object_detection_cib_amd.core.label_assignment.yv5 import BatchedTargets
+    from object_detection_cib_amd.core.types import FeatureShape
+    from object_detection_cib_amd.data.detection import DetectionTarget
+    S, nc, B = 160, 10, 8
+    exp = _experiment(0.25, 0.33, nc, 3)
+    net, loss = exp.net, exp.loss
+    x, _ = synth.batch(B, S, nc, 5)
+    x = x.cuda()
+    tg = synth.targets(B, S, nc, 5, nmin=4, nmax=20)
+    shape = FeatureShape(width=S, height=S)
+    host = tuple(DetectionTarget(b, l) for b, l in tg)
+    bt = BatchedTargets.from_targets(host, torch.device("cuda", 0))
+    ref_total, _ = net.train_step(x, loss, shape, bt, float(B))
+    ref_g = net.engine().current_grad_arena().clone()
+    ref_total = ref_total.item()
+    busy = torch.empty(64 << 20, device="cuda")
+    for _ in range(3):
+        # fresh device tensors written by kernels queued right in front of the step
+        dev_t = tuple(DetectionTarget((b.cuda() * 2.0) / 2.0, l.cuda() + 0) for b, l in tg)
+        busy.normal_()
+        total, _ = net.train_step(x, loss, shape, dev_t, float(B))
+        assert total.item() == ref_total
+        assert torch.equal(net.engine().current_grad_arena(), ref_g)

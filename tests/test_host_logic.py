@@ -1,4 +1,6 @@
 """CPU tests of the host-side mirror of the reference interface (no GPU needed)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -194,3 +196,62 @@ def test_checkpoint_optimizer_param_order_matches_smart_optimizer():
     for mine, theirs in zip(groups, O.param_groups(ora)):
         assert mine == [names[id(p)] for p in theirs]
     assert list(net.state_dict().keys()) == list(ora.state_dict().keys())
+
+
+def test_bench_self_launch_fails_loudly_when_a_rank_fails():
+    """`python bench.py --gpus 2` without a launcher starts two child ranks; here there is no second GPU (CPU container:
+    none at all), so a rank fails - the parent must stop the job and exit non-zero instead of hanging or printing a
+    partial result."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--batch", "2", "--size", "64", "--no-cpu-baseline", "--timeout", "120"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0
+    assert "all ranks stopped" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_engine_options_from_env(monkeypatch):
+    from object_detection_cib_amd.engine.options import EngineOptions
+    for k in ("KODHIP_COMM_OVERLAP", "KODHIP_NO_DUAL", "KODHIP_FORCE_BM"):
+        monkeypatch.delenv(k, raising=False)
+    o = EngineOptions.from_env()
+    assert o.comm_overlap and o.dual_dgrad and o.wgrad_overlap and o.native == {}
+    monkeypatch.setenv("KODHIP_COMM_OVERLAP", "0")
+    monkeypatch.setenv("KODHIP_NO_DUAL", "1")
+    monkeypatch.setenv("KODHIP_FORCE_BM", "256")
+    o = EngineOptions.from_env()
+    assert not o.comm_overlap and not o.dual_dgrad and o.native == {"KODHIP_FORCE_BM": "256"}
+    assert o.as_dict()["native"]["KODHIP_FORCE_BM"] == "256"
+
+
+def test_backward_write_plan_and_fp32_accumulation_modes():
+    """engine/plan.py (pure host logic): which gradient buffers of yv5s have several producers and how each producer
+    takes part in an fp32 accumulation.  Residual pass-throughs are exact copies (mode 4 on the conv1 data gradient, no
+    shadow); concat / pyramid tensors get an fp32 shadow (first producer mode 1, last mode 3)."""
+    from object_detection_cib_amd.engine.plan import backward_writes, plan_f32_accumulation
+    g = build_graph(3, 10, 0.5, 0.33)
+    duals = [u.sibling.name for u in g.units if u.sibling is not None]
+    ws, upos = backward_writes(g, duals)
+    assert [w.pos for w in ws] == sorted(w.pos for w in ws) and len({w.key for w in ws}) == len(ws)
+    assert not any(w.key == ("dgrad", d) for w in ws for d in duals)         # covered by the main_conv's dual launch
+    pl = plan_f32_accumulation(ws, {b.name: b.C for b in g.bufs})
+    assert pl.unsupported == {} and pl.zero_first == set()
+    assert pl.shadow_bufs == {"backbone.stages.stage4.blocks.2.cat", "neck.bu0.cat", "neck.bu1.cat", "neck.out.ll",
+                              "neck.out.ml", "neck.td0.cat", "neck.td1.cat"}
+    m = pl.modes
+    assert m[("head", "ll_head")] == 1 and m[("dgrad", "neck.downsample_layers.0")] == 3            # T3: head + 3x3/s2
+    assert m[("dgrad", "neck.top_down_layers.1.main_conv")] == 1 and m[("dgrad", "backbone.stages.stage3.blocks.0")] == 3   # P3
+    ups = [w for w in ws if w.kind == "up"]
+    assert len(ups) == 2 and all(m[w.key] == 3 for w in ups)
+    assert sum(1 for w in ws if w.kind == "pool" and m[w.key] == 3) == 3
+    # identity blocks (stage 1-3: 1 + 2 + 3): residual copy first, conv1's data gradient adds it in fp32 (mode 4)
+    mode4 = [k for k, v in m.items() if v == 4]
+    assert len(mode4) == 6 and all(k[0] == "dgrad" and k[1].endswith("conv1") for k in mode4)
+    assert m[("head", "hl_head")] == 0                                                                # single producer
+    # one first producer per shadow, nine last producers (4 stride-2 convs, 2 upsamples, 3 pools); the rest untouched
+    from collections import Counter
+    assert Counter(m.values()) == {0: len(ws) - 22, 1: 7, 3: 9, 4: 6}

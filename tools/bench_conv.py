@@ -38,8 +38,8 @@ for name in which:
     st = stream()
     def fwd(): _lib.check(lib.kodhip_conv_fwd_raw(x.data_ptr(), pk["f"].data_ptr(), y.data_ptr(), stats.data_ptr(), B, H, W, Cin, 0, Cin, Cout, k, k, s, s, p, p, pk["Kp"], Cout, 0, st))
     def dgrad():
-        if s2: _lib.check(lib.kodhip_conv_dgrad_s2(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, W, Cin, 0, Cin, Cout, Cout, 0, 0, st))
-        else: _lib.check(lib.kodhip_conv_dgrad(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, W, Cin, 0, Cin, Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 0, st))
+        if s2: _lib.check(lib.kodhip_conv_dgrad_s2(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, W, Cin, 0, Cin, Cout, Cout, 0, 0, None, st))
+        else: _lib.check(lib.kodhip_conv_dgrad(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, W, Cin, 0, Cin, Cout, k, k, s, s, p, p, pk["Kdp"], Cout, 0, 0, None, st))
     def wgrad(): _lib.check(lib.kodhip_conv_wgrad(x.data_ptr(), dy.data_ptr(), part.data_ptr(), gw.data_ptr(), B, H, W, Cin, 0, Cin, Cout, k, k, s, s, p, p, pk["Kp"], Cout, 0, Cout, 0, 1.0, st))
     flops = 2.0 * M * Cout * Cin * k * k
     byts = 2.0 * (B * H * W * Cin + M * Cout)

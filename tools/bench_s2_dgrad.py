@@ -19,7 +19,7 @@ for name, Cin, H, Cout in LAYERS:
     outs = []
     for form, fn in (("classes", lib.kodhip_conv_dgrad_s2), ("folded", lib.kodhip_conv_dgrad_s2f)):
         pk = pack([w], s2=True if form == "classes" else "fold")
-        call = lambda: _lib.check(fn(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, W, Cin, 0, Cin, Cout, Cout, 0, 0, st))
+        call = lambda: _lib.check(fn(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, W, Cin, 0, Cin, Cout, Cout, 0, 0, None, st))
         for _ in range(3): call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()

@@ -30,7 +30,7 @@ for name, Cin, H, Cout, k in LAYERS:
     stats = torch.empty(2 * Cout * T, device="cuda")
     st = stream()
     def fwd(): _lib.check(lib.kodhip_conv_fwd_raw(x.data_ptr(), pk["f"].data_ptr(), y.data_ptr(), stats.data_ptr(), B, H, H, Cin, 0, Cin, Cout, k, k, 1, 1, p, p, pk["Kp"], Cout, 0, st))
-    def dgrad(): _lib.check(lib.kodhip_conv_dgrad(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, H, Cin, 0, Cin, Cout, k, k, 1, 1, p, p, pk["Kdp"], Cout, 0, 0, st))
+    def dgrad(): _lib.check(lib.kodhip_conv_dgrad(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, H, Cin, 0, Cin, Cout, k, k, 1, 1, p, p, pk["Kdp"], Cout, 0, 0, None, st))
     line = f"{tag:12s} {name:30s}"
     for fn in (fwd, dgrad):
         try:
