@@ -160,6 +160,8 @@ def loop_leg(net, loss_fn, B, S, nc, device, steps, mixup_prob=0.0):
     import numpy as np
     from object_detection_cib_amd.data.device_pipeline import DeviceTrainPipeline
     from object_detection_cib_amd.engine.graphed import GraphedTrainStep
+    from object_detection_cib_amd import _lib
+    _lib.limit_host_threads()      # the host side of the data protocol: torch's pool sized to the cgroup's CPU share
     imgs, boxes, labels = synth_pool(256, S, nc, 7)
     pipe = DeviceTrainPipeline(imgs, boxes, labels, S, device, mixup_prob=mixup_prob)
     random.seed(2023); np.random.seed(2023)

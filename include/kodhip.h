@@ -119,6 +119,24 @@ int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* gra
                       int B, int H, int W, int ldx, int xcoff, int Cin,
                       int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
                       int ldy, int ycoff, int n_valid, int stem, float scale, kodStream_t stream);
+/* The two halves of kodhip_conv_wgrad apart: the split-K kernel alone (fp32 slabs partials[splits][N][Kp], a region of
+ * its own per layer), and ONE launch that sums the slabs of many layers into their gradients (same fixed-order
+ * arithmetic as the per-layer form: bit-identical) - a training step reduces a whole gradient bucket at a time instead
+ * of launching ~60 small reductions. */
+int kodhip_conv_wgrad_partial(const void* x, const void* dy, float* partials,
+                              int B, int H, int W, int ldx, int xcoff, int Cin,
+                              int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                              int ldy, int ycoff, kodStream_t stream);
+typedef struct KodWgradReduceDesc {
+  long part_off, grad_off;      /* floats, relative to the `partials` / `grads` arguments */
+  int splits, Nfull, N, K, Kp, Cin /* stem: 8 */, KK /* KH*KW */, stem;
+  float scale;
+  int block_start;              /* first block of the layer; it owns kodhip_wgrad_reduce_blocks(N, K) blocks */
+} KodWgradReduceDesc;
+int kodhip_wgrad_reduce_desc_bytes(void);
+int kodhip_wgrad_reduce_blocks(int n_valid, int K);
+int kodhip_wgrad_reduce_batched(const float* partials, float* grads, const void* descs /* device KodWgradReduceDesc[n] */,
+                                int n_desc, int total_blocks, kodStream_t stream);
 
 /* ---- BatchNorm2d(eps 1e-3, momentum .03) + SiLU (kod/nn/networks/yolov5.py:24,
  *      kod/nn/layers/activations.py:7; aten::native_batch_norm(+backward), silu(+backward)) ---------- */

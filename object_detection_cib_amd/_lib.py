@@ -55,6 +55,10 @@ SIGNATURES = {
     "kodhip_conv_dgrad_dual_bnred": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp, vp, i32, i32, vp]),
     "kodhip_conv_wgrad_splits": (i32, [i64, i32, i32]),
     "kodhip_conv_wgrad": (i32, [vp, vp, vp, vp] + [i32] * 18 + [f32, vp]),
+    "kodhip_conv_wgrad_partial": (i32, [vp, vp, vp] + [i32] * 16 + [vp]),
+    "kodhip_wgrad_reduce_desc_bytes": (i32, []),
+    "kodhip_wgrad_reduce_blocks": (i32, [i32, i32]),
+    "kodhip_wgrad_reduce_batched": (i32, [vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_reduce_partials": (i32, [vp, vp, i32, i32, vp]),
     "kodhip_bn_finalize": (i32, [vp, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_finalize_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),

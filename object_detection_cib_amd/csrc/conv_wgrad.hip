@@ -512,6 +512,69 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
   }
 }
 
+// ---- the same reduction for MANY layers in one launch.  A training step has ~60 weight gradients; their slab
+// reductions are 5-30 us kernels of a few hundred blocks each (1.0 ms per step as separate launches, mostly launch
+// ramps and tails).  Every layer keeps its own slab region, and ONE launch per gradient bucket reduces them all: block
+// -> layer by binary search over a small descriptor table, then exactly wgrad_reduce_kernel's arithmetic (same
+// fixed-order sums => bit-identical gradients).
+struct ReduceDesc {
+  long part_off, grad_off;      // in floats, relative to the partials / gradient arenas
+  int splits, Nfull, N, K, Kp, Cin, KK, stem;
+  float scale;
+  int block_start;              // first block of this layer; blocks = cdiv(N * K, RED_K)
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const float* parts, float* grads, const ReduceDesc* descs,
+                                                                   int n_desc) {
+  __shared__ float sm[RED_L][RED_K + 1];
+  int lo = 0, hi = n_desc - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {             // last descriptor whose block_start <= bid (block-uniform: scalar loads)
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block_start <= bid) lo = mid; else hi = mid - 1;
+  }
+  const ReduceDesc d = descs[lo];
+  const float* part = parts + d.part_off;
+  float* grad = grads + d.grad_off;
+  const int kx = threadIdx.x % RED_K, sl = threadIdx.x / RED_K;
+  const long idx = (long)(bid - d.block_start) * RED_K + kx;
+  const long total = (long)d.N * d.K;
+  float s = 0.f;
+  int n = 0, k = 0;
+  if (idx < total) {
+    n = (int)(idx / d.K);
+    k = (int)(idx - (long)n * d.K);
+    const float* p = part + (size_t)n * d.Kp + k;
+    const size_t slab = (size_t)d.Nfull * d.Kp;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = sl;
+    for (; i + 3 * RED_L < d.splits; i += 4 * RED_L) {
+      s0 += p[(size_t)i * slab];
+      s1 += p[(size_t)(i + RED_L) * slab];
+      s2 += p[(size_t)(i + 2 * RED_L) * slab];
+      s3 += p[(size_t)(i + 3 * RED_L) * slab];
+    }
+    for (; i < d.splits; i += RED_L) s0 += p[(size_t)i * slab];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  sm[sl][kx] = s;
+  __syncthreads();
+  if (sl == 0 && idx < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < RED_L; ++i) t += sm[i][kx];
+    if (d.stem) {
+      int c = k & 3, dx = (k >> 2) & 1, tt = k >> 3;
+      int kh = tt / 3, kwp = tt - kh * 3;
+      if (c < 3) grad[(size_t)n * 108 + c * 36 + kh * 6 + 2 * kwp + dx] = t * d.scale;
+    } else {
+      int tap = k / d.Cin;
+      int ci = k - tap * d.Cin;
+      grad[(size_t)n * d.Cin * d.KK + ci * d.KK + tap] = t * d.scale;
+    }
+  }
+}
+
 #ifndef WG_NST
 #define WG_NST 4
 #endif
@@ -558,8 +621,7 @@ void tile_shape(int N, int Kp, int* tn, int* tk) {
 
 extern "C" {
 
-// Number of reduction splits the launcher will use (partials buffer must hold splits*N*Kp floats).
-int kodhip_conv_wgrad_splits(long M, int N, int Kp) {
+static int wgrad_splits_target(long M, int N, int Kp) {
   int tn, tk;
   tile_shape(N, Kp, &tn, &tk);
   int tiles = cdiv(N, tn) * cdiv(Kp, tk);
@@ -573,16 +635,22 @@ int kodhip_conv_wgrad_splits(long M, int N, int Kp) {
   return s;
 }
 
-int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* grad,
-                      int B, int H, int W, int ldx, int xcoff, int Cin,
-                      int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
-                      int ldy, int ycoff, int n_valid, int stem, float scale, hipStream_t stream) {
-  KOD_CHECK_ARG(x && dy && partials && grad, "conv_wgrad: null pointer");
+static int wgrad_rows_per_split(long M, int N, int Kp) {
+  return cdiv(cdiv(M, wgrad_splits_target(M, N, Kp)), 32) * 32;
+}
+
+// Number of reduction splits the launcher uses (exact; the partials region must hold splits * N * Kp floats).
+int kodhip_conv_wgrad_splits(long M, int N, int Kp) { return (int)cdiv(M, (long)wgrad_rows_per_split(M, N, Kp)); }
+
+static int wgrad_partial(WgradArgs& a, const void* x, const void* dy, float* partials,
+                         int B, int H, int W, int ldx, int xcoff, int Cin,
+                         int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                         int ldy, int ycoff, hipStream_t stream) {
+  KOD_CHECK_ARG(x && dy && partials, "conv_wgrad: null pointer");
   KOD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0 && xcoff + Cin <= ldx, "conv_wgrad: bad input slice");
   KOD_CHECK_ARG(N % 8 == 0 && ldy % 8 == 0 && ycoff % 8 == 0 && ycoff + N <= ldy, "conv_wgrad: bad dy slice (N=%d ldy=%d)", N, ldy);
   KOD_CHECK_ARG(Kp % 32 == 0 && Kp >= KH * KW * Cin, "conv_wgrad: bad Kp");
-  KOD_CHECK_ARG(n_valid > 0 && n_valid <= N, "conv_wgrad: bad n_valid");
-  WgradArgs a = {};
+  a = WgradArgs{};
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.part = partials;
   a.B = B; a.Hs = H; a.Ws = W; a.ldx = ldx; a.xcoff = xcoff; a.Cin = Cin;
   a.Ho = (H + 2 * PH - KH) / SH + 1; a.Wo = (W + 2 * PW - KW) / SW + 1;
@@ -592,8 +660,7 @@ int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* gra
   a.KH = KH; a.KW = KW; a.SH = SH; a.SW = SW; a.PH = PH; a.PW = PW; a.ldy = ldy; a.ycoff = ycoff;
   a.magic_cin = magic_u32((uint32_t)Cin); a.magic_kw = magic_u32((uint32_t)KW);
   a.magic_hwo = magic_u32((uint32_t)(a.Ho * a.Wo)); a.magic_wo = magic_u32((uint32_t)a.Wo);
-  a.splits = kodhip_conv_wgrad_splits(M, N, Kp);
-  a.m_per_split = cdiv(cdiv(M, a.splits), 32) * 32;
+  a.m_per_split = wgrad_rows_per_split(M, N, Kp);
   a.splits = cdiv(M, a.m_per_split);
   int tn, tk, rc;
   tile_shape(N, Kp, &tn, &tk);
@@ -608,11 +675,45 @@ int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* gra
   else if (tn == 128 && tk == 32) rc = launch_cfg<4, 1, 1, 1>(a, stream);
   else if (tn == 64 && tk == 32) rc = launch_cfg<2, 1, 1, 1>(a, stream);
   else rc = launch_cfg<1, 1, 1, 1>(a, stream);
-  if (rc) return rc;
+  return rc;
+}
+
+int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* grad,
+                      int B, int H, int W, int ldx, int xcoff, int Cin,
+                      int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                      int ldy, int ycoff, int n_valid, int stem, float scale, hipStream_t stream) {
+  KOD_CHECK_ARG(grad, "conv_wgrad: null pointer");
+  KOD_CHECK_ARG(n_valid > 0 && n_valid <= N, "conv_wgrad: bad n_valid");
+  WgradArgs a;
+  if (int rc = wgrad_partial(a, x, dy, partials, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, stream)) return rc;
   int total = n_valid * a.K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, RED_K)), dim3(256), 0, stream,
                      (const float*)partials, grad, a.splits, N, n_valid, a.K, Kp, stem ? 8 : Cin, KH * KW, stem, scale);
   KOD_LAUNCH_CHECK("wgrad_reduce");
+  return KOD_OK;
+}
+
+// The split-K half alone: fp32 slabs partials[kodhip_conv_wgrad_splits(M, N, Kp)][N][Kp]; kodhip_wgrad_reduce_batched
+// turns the slabs of many layers into gradients with one launch.
+int kodhip_conv_wgrad_partial(const void* x, const void* dy, float* partials,
+                              int B, int H, int W, int ldx, int xcoff, int Cin,
+                              int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                              int ldy, int ycoff, hipStream_t stream) {
+  WgradArgs a;
+  return wgrad_partial(a, x, dy, partials, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, stream);
+}
+
+int kodhip_wgrad_reduce_desc_bytes(void) { return (int)sizeof(ReduceDesc); }
+int kodhip_wgrad_reduce_blocks(int n_valid, int K) { return cdiv(n_valid * K, RED_K); }
+
+// descs: DEVICE array of n_desc KodWgradReduceDesc sorted by block_start (block_start[0] = 0, each layer owning
+// kodhip_wgrad_reduce_blocks(N, K) consecutive blocks, total_blocks in all); offsets relative to partials / grads.
+int kodhip_wgrad_reduce_batched(const float* partials, float* grads, const void* descs, int n_desc, int total_blocks,
+                                hipStream_t stream) {
+  KOD_CHECK_ARG(partials && grads && descs && n_desc > 0 && total_blocks > 0, "wgrad_reduce_batched: bad args");
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, stream, partials, grads,
+                     (const ReduceDesc*)descs, n_desc);
+  KOD_LAUNCH_CHECK("wgrad_reduce_batched");
   return KOD_OK;
 }
 

@@ -34,7 +34,7 @@ def _pad(n: int, a: int = 64) -> int:
 class _UnitState:
     __slots__ = ("u", "w_off", "g_off", "b_off", "f_off", "d_off", "Kp", "Kdp", "rs_off", "stats", "T",
                  "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho", "Wo",
-                 "fused_red", "segs", "seg_slots", "Kp_f", "raw_ld", "s2_fold")
+                 "fused_red", "segs", "seg_slots", "Kp_f", "raw_ld", "s2_fold", "wg_splits", "wg_off")
 
 
 class Engine:
@@ -218,17 +218,18 @@ class Engine:
 
     # ------------------------------------------------------------------ activations
     _UNIT_FIELDS = ("stats", "T", "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho",
-                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld")
-    _HEAD_FIELDS = ("H", "W", "M", "dy", "ws")
+                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld", "wg_splits", "wg_off")
+    _HEAD_FIELDS = ("H", "W", "M", "dy", "ws", "wg_splits", "wg_off")
 
     def _export_set(self) -> dict:
         return dict(act=self.act, gact=self.gact, gact32=self.gact32, wg_part=self.wg_part, pool_idx=self.pool_idx,
+                    red_groups=self.red_groups,
                     units={n: {f: getattr(st, f) for f in self._UNIT_FIELDS} for n, st in self.ustate.items()},
                     heads={n: {f: hs[f] for f in self._HEAD_FIELDS} for n, hs in self.hstate.items()})
 
     def _import_set(self, d: dict):
         self.act, self.gact, self.wg_part, self.pool_idx = d["act"], d["gact"], d["wg_part"], d["pool_idx"]
-        self.gact32 = d["gact32"]
+        self.gact32, self.red_groups = d["gact32"], d["red_groups"]
         for n, fields in d["units"].items():
             st = self.ustate[n]
             for f, v in fields.items():
@@ -295,8 +296,9 @@ class Engine:
             st.bsums = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
             st.bsums_g = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
             st.coef = torch.empty(3 * u.cout, dtype=torch.float32, device=dev)
-            splits = lib.kodhip_conv_wgrad_splits(st.M, u.cout, st.Kp)
-            max_part = max(max_part, splits * u.cout * st.Kp)
+            st.wg_splits = lib.kodhip_conv_wgrad_splits(st.M, u.cout, st.Kp)
+            st.wg_off = max_part                       # this layer's own slab region [splits][cout][Kp] (floats)
+            max_part += _pad(st.wg_splits * u.cout * st.Kp)
         self._plan_bn_fusion(B)
         self.gact32 = {}
         if self._f32plan is not None:
@@ -308,15 +310,51 @@ class Engine:
             hs.update(H=hh, W=ww, M=B * hh * ww)
             hs["dy"] = torch.empty((B * hh * ww, self.head_npad), dtype=torch.bfloat16, device=dev)
             hs["ws"] = torch.empty(2048 * self.head_npad, dtype=torch.float32, device=dev)
-            splits = lib.kodhip_conv_wgrad_splits(hs["M"], self.head_npad, hs["Kp"])
-            max_part = max(max_part, splits * self.head_npad * hs["Kp"])
+            hs["wg_splits"] = lib.kodhip_conv_wgrad_splits(hs["M"], self.head_npad, hs["Kp"])
+            hs["wg_off"] = max_part
+            max_part += _pad(hs["wg_splits"] * self.head_npad * hs["Kp"])
         self.wg_part = torch.empty(max_part, dtype=torch.float32, device=dev)
+        self._plan_wgrad_reduce()
         # SPPF argmax indices
         self.pool_idx = []
         for op in self.g.ops:
             if op.kind == "pool":
                 h, w = H // op.src.stride, W // op.src.stride
                 self.pool_idx.append(torch.empty((B, h, w, op.src.C), dtype=torch.uint8, device=dev))
+
+    def _plan_wgrad_reduce(self):
+        """Weight-gradient slab reductions, one launch per gradient bucket (csrc/conv_wgrad.hip: wgrad_reduce_batched):
+        {trigger unit index: (device descriptor table, n, total blocks)} - the bucket's layers in arena order.  The
+        buckets are the all-reduce buckets of the data-parallel path (engine/ddp.py), planned the same way on one GPU."""
+        lib = self.lib
+        dt = np.dtype([("part_off", "<i8"), ("grad_off", "<i8"), ("splits", "<i4"), ("Nfull", "<i4"), ("N", "<i4"), ("K", "<i4"),
+                       ("Kp", "<i4"), ("Cin", "<i4"), ("KK", "<i4"), ("stem", "<i4"), ("scale", "<f4"), ("block_start", "<i4")])
+        assert dt.itemsize == lib.kodhip_wgrad_reduce_desc_bytes()
+        A, nc = self.g.num_anchors, self.g.num_classes
+        layers = []                   # arena order = forward execution order: (weight offset, descriptor fields)
+        for u in self.exec_units:
+            st = self.ustate[u.name]
+            K = 144 if u.stem else u.k * u.k * u.cin
+            layers.append((st.w_off, dict(part_off=st.wg_off, grad_off=st.w_off, splits=st.wg_splits, Nfull=u.cout, N=u.cout, K=K,
+                                          Kp=st.Kp, Cin=8 if u.stem else u.cin, KK=18 if u.stem else u.k * u.k,
+                                          stem=1 if u.stem else 0, scale=1.0)))
+        for h in self.g.heads:
+            hs = self.hstate[h.name]
+            layers.append((hs["w_off"], dict(part_off=hs["wg_off"], grad_off=hs["w_off"], splits=hs["wg_splits"], Nfull=self.head_npad,
+                                             N=A * (5 + nc), K=h.cin, Kp=hs["Kp"], Cin=h.cin, KK=1, stem=0, scale=1.0)))
+        self.red_groups = {}
+        self._red_bucket_bytes = self.bucket_bytes
+        for trig, lo, hi in plan_buckets(self.unit_starts, self.n_arena, max(self.bucket_bytes // 4, 1)):
+            rows, blk = [], 0
+            for off, d in layers:
+                if lo <= off < hi:
+                    d = dict(d, block_start=blk)
+                    blk += lib.kodhip_wgrad_reduce_blocks(d["N"], d["K"])
+                    rows.append(tuple(d[k] for k in dt.names))
+            if rows:
+                arr = np.array(rows, dtype=dt)
+                tab = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(self.device)
+                self.red_groups[trig] = (tab, len(rows), blk)
 
     def _check_equal_local_batch(self, key):
         """SyncBN here divides the all-reduced sums by M_local * world_size (torch's SyncBatchNorm all-gathers the
@@ -710,13 +748,23 @@ class Engine:
                 self._fork_ev.record(stream or main)
         self._fork_point = fork_point
 
+        batched = self.opt.wgrad_reduce_batched     # slab reductions: one launch per bucket (default) | per layer
+
+        def launch_wgrad(name, nbytes, args, stream_obj):
+            """args = kodhip_conv_wgrad's (x, dy, slab region, grad, geometry ..., n_valid, stem, scale)"""
+            e0 = self._t0(stream_obj)
+            sid = stream_obj.cuda_stream if stream_obj is not None else s
+            if batched:
+                chk(lib.kodhip_conv_wgrad_partial(*args[:3], *args[4:-3], sid), name + ".wgrad")
+            else:
+                chk(lib.kodhip_conv_wgrad(*args, sid), name + ".wgrad")
+            self._t1(e0, "wgrad", nbytes, stream_obj)
+
         def flush_wgrads():
             """call after the main stream's next kernel has been launched"""
             for ev, name, nbytes, args in deferred:
                 wg.wait_event(ev)
-                e0 = self._t0(wg)
-                chk(lib.kodhip_conv_wgrad(*args, wg.cuda_stream), name + ".wgrad")
-                self._t1(e0, "wgrad", nbytes, wg)
+                launch_wgrad(name, nbytes, args, wg)
             deferred.clear()
         self._flush_wgrads = flush_wgrads
 
@@ -728,13 +776,9 @@ class Engine:
                     ev.record(main)
                 deferred.append((ev, name, nbytes, args))
                 return
-            ws = s
             if wg is not None:
                 wg.wait_stream(main)
-                ws = wg.cuda_stream
-            e0 = self._t0(wg)
-            chk(lib.kodhip_conv_wgrad(*args, ws), name + ".wgrad")
-            self._t1(e0, "wgrad", nbytes, wg)
+            launch_wgrad(name, nbytes, args, wg)
 
         # gradient buffers last written on a side stream (the P3 / P4 heads' data gradients): buffer -> event the main
         # stream must wait for before it reads or accumulates into the buffer
@@ -772,6 +816,8 @@ class Engine:
         self._f32 = f32
 
         self._pending = []
+        if self._red_bucket_bytes != self.bucket_bytes:      # the reductions follow the all-reduce buckets
+            self._plan_wgrad_reduce()
         buckets = {}
         if self.collectives:
             buckets = {trig: (lo, hi) for trig, lo, hi in plan_buckets(self.unit_starts, self.n_arena,
@@ -785,6 +831,13 @@ class Engine:
             """one conv / head unit's gradients are complete: buckets finish from the arena's end toward its start"""
             nonlocal unit_i
             unit_i -= 1
+            if batched and unit_i in self.red_groups:
+                flush_wgrads()         # the bucket's last weight gradients are on their stream: reduce all its slabs at once
+                tab, n_desc, blocks = self.red_groups[unit_i]
+                e0 = self._t0(wg)
+                chk(lib.kodhip_wgrad_reduce_batched(wgp, gp, tab.data_ptr(), n_desc, blocks,
+                                                    wg.cuda_stream if wg is not None else s), "wgrad_reduce_batched")
+                self._t1(e0, "wgrad", 0.0, wg)
             if unit_i in buckets:
                 flush_wgrads()         # the bucket's last weight gradients must be on the side stream before the collective
                 lo, hi = buckets[unit_i]
@@ -887,7 +940,7 @@ class Engine:
                     ev.record(hstream)
                     grad_events[src.buf.name] = ev
                 timed_wgrad(hu.name, 2.0 * hs["M"] * (hu.cin + self.head_npad),
-                            self._ptr(src), hs["dy"].data_ptr(), wgp, gp + 4 * hs["w_off"],
+                            self._ptr(src), hs["dy"].data_ptr(), wgp + 4 * hs["wg_off"], gp + 4 * hs["w_off"],
                             B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
                             self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kp"], self.head_npad, 0, A * (5 + nc), 0, 1.0)
                 flush_wgrads()
@@ -956,7 +1009,7 @@ class Engine:
             fz = () if st.segs is None else (C.cast(st.segs, C.c_void_p), len(st.segs), st.seg_slots)
             if dgrad == "skip":
                 timed_wgrad(u.name, 2.0 * (B * st.H * st.W * u.cin + st.M * C_),
-                            self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
+                            self._ptr(u.src), st.raw.data_ptr(), wgp + 4 * st.wg_off, gp + 4 * st.w_off,
                             *geo, st.Kp, C_, 0, C_, 0, 1.0)
                 return
             fm, fptr = self._f32("dgrad", u.name, u.src)
@@ -990,7 +1043,7 @@ class Engine:
         cin_true = 3 if u.stem else u.cin
         in_px_w = B * H * W if u.stem else B * st.H * st.W
         timed_wgrad(u.name, 2.0 * (in_px_w * cin_true + st.M * C_),
-                    self._ptr(u.src), st.raw.data_ptr(), wgp, gp + 4 * st.w_off,
+                    self._ptr(u.src), st.raw.data_ptr(), wgp + 4 * st.wg_off, gp + 4 * st.w_off,
                     *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0)
         self._flush_wgrads()           # this unit's - and a fused short_conv partner's - weight gradients: after the dgrad
 

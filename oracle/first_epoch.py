@@ -127,5 +127,30 @@ def main():
     print(f"wrote {out}")
 
 
+def extra():
+    """`python -m oracle.first_epoch --extra`: more samples of the CPU trainer's run-to-run spread, appended to the
+    fixture (round 3: the HIP-vs-CPU mAP comparison wants a tighter estimate of the spread, and the bf16-storage
+    emulation - the HIP path's own perturbation - sampled more than once).  Thread counts not used by main()."""
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "first_epoch.npz")
+    log = lambda s: print(s, file=sys.stderr, flush=True)
+    keys = ("map", "map30", "map50", "map75", "map90")
+    res = dict(np.load(out))
+    tags = [str(t) for t in res.get("map_sample_tags", np.array(["fp32", "fp32_alt", "bf16emu", "fp32_t6", "fp32_t3", "fp32_t5"]))]
+    samples = [row for row in res["map_cpu_samples"]]
+    for tag, emu, threads in (("bf16emu_t4", True, 4), ("fp32_t7", False, 7), ("bf16emu_t6", True, 6), ("fp32_t2", False, 2),
+                              ("bf16emu_t3", True, 3), ("bf16emu_t5", True, 5)):
+        if tag in tags:
+            continue
+        torch.set_num_threads(threads)
+        r = run_cpu(CONFIG, emu, log)
+        log(f"{tag} ({threads} threads): { {k: round(r['report'][k], 4) for k in keys} }")
+        tags.append(tag)
+        samples.append(np.array([r["report"][k] for k in keys]))
+        res["map_cpu_samples"] = np.stack(samples)
+        res["map_sample_tags"] = np.array(tags)
+        np.savez_compressed(out, **res)               # after every run: a stopped job keeps what it has
+    print(f"wrote {out}: {len(samples)} samples")
+
+
 if __name__ == "__main__":
-    main()
+    extra() if "--extra" in sys.argv else main()

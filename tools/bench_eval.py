@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import synth
 import bench
+from object_detection_cib_amd import _lib as _kl; _kl.limit_host_threads()
 from object_detection_cib_amd.core.anchors.info import voc_anchor_info
 from object_detection_cib_amd.data.device_pipeline import DeviceValPipeline
 from object_detection_cib_amd.lightning.experiments.yv5_baseline.exp import DefaultYolov5Experiment

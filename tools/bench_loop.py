@@ -5,6 +5,7 @@ sys.path.insert(0, '.')
 import numpy as np, torch
 from oracle import synth
 import bench
+from object_detection_cib_amd import _lib as _kl; _kl.limit_host_threads()
 from object_detection_cib_amd.data.device_pipeline import DeviceTrainPipeline
 from object_detection_cib_amd.engine.graphed import GraphedTrainStep
 
