@@ -114,7 +114,12 @@ int kodhip_conv_dgrad_dual_bnred_slots(int B, int H, int W, int Cin, int N, int 
 int kodhip_conv_dgrad_dual_bnred(const void* dy1, const void* w1, const void* dy2, const void* w2, void* dx,
                                  int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
                                  int accumulate, void* dx_f32, const void* segments, int nseg, int slots, kodStream_t stream);
-int kodhip_conv_wgrad_splits(long M, int N, int Kp);
+int kodhip_conv_wgrad_splits(long M, int N, int Kp);     /* generic split-K kernel */
+/* split count of the kernel kodhip_conv_wgrad[_partial] picks for this geometry (3x3 / stride 1 / pad 1 layers with whole
+ * 32-channel chunks take a form that stages dY once per block and every input row once per kernel row): size the slab
+ * region with this one.  H, W: input dims; ldx / ldy: row strides of x / dy in elements. */
+int kodhip_conv_wgrad_splits_geo(int B, int H, int W, int ldx, int Cin, int N, int KH, int KW, int SH, int SW, int PH, int PW,
+                                 int Kp, int ldy);
 int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* grad,
                       int B, int H, int W, int ldx, int xcoff, int Cin,
                       int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
@@ -150,6 +155,16 @@ int kodhip_bn_finalize_partials(const float* partials, int T, double count, cons
                                 float* running_mean, float* running_var, float momentum, float eps,
                                 float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
                                 kodStream_t stream);
+/* SyncBN forms of the two single launches: the rank's sums are exchanged through the peer buffers (kodhip_peer_*, below)
+ * inside the kernel.  count = pixels of ALL ranks; view = host KodPeerView (copied into the launch); slot = first granule
+ * of this exchange (it uses 4 * C).  Parameter gradients (dgamma, dbeta) keep the rank's own sums. */
+int kodhip_bn_finalize_partials_peer(const float* partials, int T, double count, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum, float eps,
+                                     float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
+                                     const void* view, unsigned int slot, kodStream_t stream);
+int kodhip_bn_bwd_coeffs_partials_peer(const float* partials, int T, double count, const float* gamma, const float* mean,
+                                       const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
+                                       int raw_moment, const void* view, unsigned int slot, kodStream_t stream);
 /* kodhip_bn_bwd_coeffs_partials for two units in one launch (a CSP layer's short_conv + main_conv) */
 int kodhip_bn_bwd_coeffs_partials2(const float* partials0, int T0, double count0, const float* gamma0, const float* mean0,
                                    const float* rstd0, float* dgamma0, float* dbeta0, float* coef0, int C0, int raw_moment0,
@@ -267,6 +282,28 @@ int kodhip_comm_broadcast(void* comm, void* buf, long bytes, int root, kodStream
 /* collectives enqueued between the two calls are launched as one fused operation (ncclGroupStart / ncclGroupEnd) */
 int kodhip_comm_group_start(void);
 int kodhip_comm_group_end(void);
+
+/* ---- SyncBN statistic exchange over peer buffers (sync_batchnorm: True, kod/configs/trainer/ddp.yaml:9; replaces the
+ *      114 small all-reduces torch SyncBatchNorm issues per step).  Every rank of the node owns one small exchange
+ *      buffer - the ONE device allocation this library makes (fine-grained memory), freed by kodhip_peer_destroy - and
+ *      maps the others' through HIP IPC; the BatchNorm finalize / coefficient kernels publish their two fp64 sums per
+ *      channel there and read the other ranks' directly over xGMI: no collective launch, no communicator order. ----- */
+#define KODHIP_PEER_MAX 8
+typedef struct KodPeerView {                       /* passed BY VALUE to the *_peer kernels */
+  unsigned long long* peers[KODHIP_PEER_MAX];
+  int world, rank;
+  const unsigned int* seq;
+  int* timeout_flag;
+} KodPeerView;
+int kodhip_peer_create(void** peer, int rank, int world, long granules /* 8-byte granules: 4 per channel per exchange site */);
+int kodhip_peer_export(void* peer, void* handle64 /* host, 64 bytes out: hipIpcMemHandle_t */);
+int kodhip_peer_connect(void* peer, const void* handles /* host, world x 64 bytes in rank order */);
+int kodhip_peer_view_bytes(void);
+int kodhip_peer_view(void* peer, void* view_out /* host KodPeerView */);
+int kodhip_peer_step_begin(void* peer, kodStream_t stream);      /* once per step, before its first exchange */
+int kodhip_peer_allreduce_f64(void* peer, const double* in, double* out, int n, unsigned int slot, kodStream_t stream);
+int kodhip_peer_timed_out(void* peer, int* flag /* host out; synchronises */);
+int kodhip_peer_destroy(void* peer);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ SIGNATURES = {
     "kodhip_conv_dgrad_dual_bnred_slots": (i32, [i32] * 6),
     "kodhip_conv_dgrad_dual_bnred": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp, vp, i32, i32, vp]),
     "kodhip_conv_wgrad_splits": (i32, [i64, i32, i32]),
+    "kodhip_conv_wgrad_splits_geo": (i32, [i32] * 14),
     "kodhip_conv_wgrad": (i32, [vp, vp, vp, vp] + [i32] * 18 + [f32, vp]),
     "kodhip_conv_wgrad_partial": (i32, [vp, vp, vp] + [i32] * 16 + [vp]),
     "kodhip_wgrad_reduce_desc_bytes": (i32, []),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "kodhip_bn_finalize_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_bwd_coeffs_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_bwd_coeffs_partials2": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, i32] * 2 + [vp]),
+    "kodhip_bn_finalize_partials_peer": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp, u32, vp]),
+    "kodhip_bn_bwd_coeffs_partials_peer": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, i32, vp, u32, vp]),
     "kodhip_bn_silu_apply": (i32, [vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, vp]),
     "kodhip_bn_bwd_slots": (i32, [i64, i32]),
     "kodhip_bn_silu_bwd_reduce": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, i64, i32, vp]),
@@ -83,6 +86,15 @@ SIGNATURES = {
     "kodhip_comm_allreduce_sum": (i32, [vp, vp, i64, i32, vp]),
     "kodhip_comm_allreduce_sum_to": (i32, [vp, vp, vp, i64, i32, vp]),
     "kodhip_comm_broadcast": (i32, [vp, vp, i64, i32, vp]),
+    "kodhip_peer_create": (i32, [C.POINTER(vp), i32, i32, i64]),
+    "kodhip_peer_export": (i32, [vp, vp]),
+    "kodhip_peer_connect": (i32, [vp, vp]),
+    "kodhip_peer_view_bytes": (i32, []),
+    "kodhip_peer_view": (i32, [vp, vp]),
+    "kodhip_peer_step_begin": (i32, [vp, vp]),
+    "kodhip_peer_allreduce_f64": (i32, [vp, vp, vp, i32, u32, vp]),
+    "kodhip_peer_timed_out": (i32, [vp, C.POINTER(i32)]),
+    "kodhip_peer_destroy": (i32, [vp]),
     "kodhip_comm_group_start": (i32, []),
     "kodhip_comm_group_end": (i32, []),
     "kodhip_compose_desc_bytes": (i32, []),

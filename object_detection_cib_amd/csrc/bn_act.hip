@@ -24,6 +24,49 @@ __device__ __forceinline__ double wave_sum_partials(const float* p, int T, int l
   return wave_sum_d((a0 + a1) + (a2 + a3));
 }
 
+// ---------------------------------------------------------------- SyncBN over peer buffers
+// One wave per channel holds the rank's two fp64 sums (s0, s1) in lane 0: publish them as four granules in the rank's
+// own exchange buffer, then poll the same four granules of EVERY rank (lane = 4 * rank + granule) and add the ranks'
+// values in rank order - every rank gets bit-identical totals.  Publishing precedes polling in every wave and waves
+// do not depend on each other, so ranks can arrive in any order; a poll that never sees its tag gives up after
+// ~seconds and raises the timeout flag instead of hanging the GPU.
+__device__ __forceinline__ void peer_allreduce2(const KodPeerView& pv, unsigned int slot, int idx0, int idx1, int lane,
+                                                double& s0, double& s1) {
+  const unsigned int seq = *pv.seq;
+  // lane 0 holds the values; lanes 0..3 store one granule each
+  const unsigned long long b0 = __shfl((unsigned long long)__double_as_longlong(s0), 0, 64);
+  const unsigned long long b1 = __shfl((unsigned long long)__double_as_longlong(s1), 0, 64);
+  const int g = lane & 3;                                // 0: s0.lo, 1: s0.hi, 2: s1.lo, 3: s1.hi
+  const unsigned long long gi = (unsigned long long)slot + 2ull * (unsigned long long)(g < 2 ? idx0 : idx1) + (g & 1);
+  if (lane < 4) {
+    const unsigned long long bits = g < 2 ? b0 : b1;
+    const unsigned int payload = (unsigned int)((g & 1) ? (bits >> 32) : bits);
+    __hip_atomic_store(pv.peers[pv.rank] + gi, ((unsigned long long)seq << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  unsigned int got = 0;
+  const int r = lane >> 2;
+  if (r < pv.world) {
+    const unsigned long long* src = pv.peers[r] + gi;
+    unsigned long long v = 0;
+    long spins = 0;
+    for (;;) {
+      v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((unsigned int)(v >> 32) == seq) break;
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1l << 24)) { *pv.timeout_flag = 1; break; }        // ~seconds: a peer is gone
+    }
+    got = (unsigned int)v;
+  }
+  double t0 = 0.0, t1 = 0.0;
+  for (int q = 0; q < pv.world; ++q) {                   // fixed rank order
+    const unsigned long long lo0 = __shfl(got, 4 * q + 0, 64), hi0 = __shfl(got, 4 * q + 1, 64);
+    const unsigned long long lo1 = __shfl(got, 4 * q + 2, 64), hi1 = __shfl(got, 4 * q + 3, 64);
+    t0 += __longlong_as_double((long long)((hi0 << 32) | lo0));
+    t1 += __longlong_as_double((long long)((hi1 << 32) | lo1));
+  }
+  s0 = t0; s1 = t1;
+}
+
 // ---------------------------------------------------------------- partial slabs -> fp64 sums
 // in: part[2][C][T] fp32 ; out: sums[2][C] fp64.  One wave per (stat, channel).
 __global__ void bn_reduce_partials_kernel(const float* part, double* sums, int C, int T) {
@@ -58,17 +101,20 @@ __global__ void bn_finalize_kernel(const double* sums, double count, const float
   }
 }
 
-// single-GPU fast path: partial slabs -> constants in ONE launch (one wave per channel)
+// single-GPU fast path: partial slabs -> constants in ONE launch (one wave per channel).  PEER: SyncBN - the rank's
+// sums are exchanged through the peer buffers inside the same launch (count = pixels of ALL ranks)
+template <bool PEER>
 __global__ void bn_finalize_fused_kernel(const float* part, int T, double count, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var,
                                          float momentum, float eps, float* scale, float* shift, float* mean_out,
-                                         float* rstd_out, int C, int update_running) {
+                                         float* rstd_out, int C, int update_running, KodPeerView pv, unsigned int slot) {
   int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
   int lane = threadIdx.x & 63;
   const float* p0 = part + (size_t)c * T;
   const float* p1 = part + (size_t)(C + c) * T;
   double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
+  if constexpr (PEER) peer_allreduce2(pv, slot, c, C + c, lane, s0, s1);
   if (lane != 0) return;
   double mean = s0 / count;
   double var = s1 / count - mean * mean;
@@ -88,16 +134,21 @@ __global__ void bn_finalize_fused_kernel(const float* part, int T, double count,
 
 // raw_moment: the second partial is sum dz*y (produced by the data-gradient epilogue, conv_igemm.hip MODE_PLAIN_BN)
 // instead of sum dz*xhat; xhat = (y - mean)*rstd  =>  sum dz*xhat = rstd * (sum dz*y - mean * sum dz), in fp64.
+template <bool PEER = false>
 __device__ __forceinline__ void bn_bwd_coeffs_channel(const float* part, int T, double count, const float* gamma,
                                                       const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                                                      float* coef, int C, int raw_moment, int c, int lane) {
+                                                      float* coef, int C, int raw_moment, int c, int lane,
+                                                      const KodPeerView* pv = nullptr, unsigned int slot = 0) {
   const float* p0 = part + (size_t)c * T;
   const float* p1 = part + (size_t)(C + c) * T;
   double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
+  if (raw_moment) s1 = (double)rstd[c] * (s1 - (double)mean[c] * s0);      // (linear in the sums: ranks may add converted values)
+  if (lane == 0) {          // parameter gradients keep the rank's own sums (the gradient all-reduce adds the ranks later)
+    dbeta[c] = (float)s0;
+    dgamma[c] = (float)s1;
+  }
+  if constexpr (PEER) peer_allreduce2(*pv, slot, c, C + c, lane, s0, s1);   // dX uses the sums over ALL ranks' pixels
   if (lane != 0) return;
-  if (raw_moment) s1 = (double)rstd[c] * (s1 - (double)mean[c] * s0);
-  dbeta[c] = (float)s0;
-  dgamma[c] = (float)s1;
   double g = gamma[c], rs = rstd[c], mu = mean[c];
   double S0 = s0 / count, S1 = s1 / count;
   coef[c] = (float)(g * rs);
@@ -111,6 +162,14 @@ __global__ void bn_bwd_coeffs_fused_kernel(const float* part, int T, double coun
   int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (c >= C) return;
   bn_bwd_coeffs_channel(part, T, count, gamma, mean, rstd, dgamma, dbeta, coef, C, raw_moment, c, threadIdx.x & 63);
+}
+
+__global__ void bn_bwd_coeffs_peer_kernel(const float* part, int T, double count, const float* gamma,
+                                          const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                          float* coef, int C, int raw_moment, KodPeerView pv, unsigned int slot) {
+  int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  bn_bwd_coeffs_channel<true>(part, T, count, gamma, mean, rstd, dgamma, dbeta, coef, C, raw_moment, c, threadIdx.x & 63, &pv, slot);
 }
 
 // the same for TWO units in one launch (blockIdx.y = unit): a CSP layer's short_conv and main_conv reach this point of
@@ -363,9 +422,40 @@ int kodhip_bn_finalize_partials(const float* partials, int T, double count, cons
   KOD_CHECK_ARG(partials && gamma && beta && scale && shift && mean && rstd && C > 0 && T > 0 && count > 0,
                 "bn_finalize_partials: bad args");
   KOD_CHECK_ARG(!update_running || (running_mean && running_var), "bn_finalize_partials: running stats missing");
-  hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, T, count, gamma, beta,
-                     running_mean, running_var, momentum, eps, scale, shift, mean, rstd, C, update_running);
+  hipLaunchKernelGGL(bn_finalize_fused_kernel<false>, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, T, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, scale, shift, mean, rstd, C, update_running, KodPeerView{}, 0u);
   KOD_LAUNCH_CHECK("bn_finalize_partials");
+  return KOD_OK;
+}
+
+// SyncBN forms (kod/configs/trainer/ddp.yaml:9 sync_batchnorm): the same single launches, with the rank's two sums
+// per channel exchanged through the peer buffers of kodhip_peer_* inside the kernel.  count = pixels of ALL ranks;
+// slot = first granule of this exchange in the buffers (4 * C granules); view = kodhip_peer_view's struct.
+int kodhip_bn_finalize_partials_peer(const float* partials, int T, double count, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum, float eps,
+                                     float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
+                                     const void* view, unsigned int slot, hipStream_t stream) {
+  KOD_CHECK_ARG(partials && gamma && beta && scale && shift && mean && rstd && C > 0 && T > 0 && count > 0 && view,
+                "bn_finalize_partials_peer: bad args");
+  KOD_CHECK_ARG(!update_running || (running_mean && running_var), "bn_finalize_partials_peer: running stats missing");
+  const KodPeerView pv = *(const KodPeerView*)view;
+  KOD_CHECK_ARG(pv.world >= 1 && pv.world <= KOD_PEER_MAX && pv.world * 4 <= 64, "bn_finalize_partials_peer: bad peer view");
+  hipLaunchKernelGGL(bn_finalize_fused_kernel<true>, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, T, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, scale, shift, mean, rstd, C, update_running, pv, slot);
+  KOD_LAUNCH_CHECK("bn_finalize_partials_peer");
+  return KOD_OK;
+}
+
+int kodhip_bn_bwd_coeffs_partials_peer(const float* partials, int T, double count, const float* gamma, const float* mean,
+                                       const float* rstd, float* dgamma, float* dbeta, float* coef, int C,
+                                       int raw_moment, const void* view, unsigned int slot, hipStream_t stream) {
+  KOD_CHECK_ARG(partials && gamma && mean && rstd && dgamma && dbeta && coef && C > 0 && T > 0 && count > 0 && view,
+                "bn_bwd_coeffs_partials_peer: bad args");
+  const KodPeerView pv = *(const KodPeerView*)view;
+  KOD_CHECK_ARG(pv.world >= 1 && pv.world <= KOD_PEER_MAX, "bn_bwd_coeffs_partials_peer: bad peer view");
+  hipLaunchKernelGGL(bn_bwd_coeffs_peer_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, partials, T, count, gamma,
+                     mean, rstd, dgamma, dbeta, coef, C, raw_moment, pv, slot);
+  KOD_LAUNCH_CHECK("bn_bwd_coeffs_partials_peer");
   return KOD_OK;
 }
 

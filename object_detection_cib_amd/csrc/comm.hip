@@ -140,3 +140,190 @@ int kodhip_comm_broadcast(void* comm, void* buf, long bytes, int root, hipStream
 }
 
 }  // extern "C"
+
+// ---- SyncBN exchange over peer buffers ---------------------------------------------------------------------------
+// sync_batchnorm (kod/configs/trainer/ddp.yaml:9) needs two fp64 sums per channel from every rank, 114 times per
+// step, each one on the critical chain: as RCCL all-reduces that is 98-114 latency-bound collective launches.  On one
+// node every GPU can map every other GPU's memory (xGMI), so each rank owns a small exchange buffer that all ranks
+// open through HIP IPC; the BatchNorm finalize / coefficient kernels publish their sums there and read the other
+// ranks' directly (csrc/bn_act.hip: peer_allreduce2) - one hop, no collective launch, no communicator ordering (the
+// forward CSP branches stay on their side streams).  The buffer is the one device allocation this library owns
+// (fine-grained, so that system-scope stores / loads of other agents bypass the caches); kodhip_peer_destroy frees it.
+namespace {
+
+struct PeerComm {
+  int rank = 0, world = 1;
+  long granules = 0;
+  unsigned char* local = nullptr;               // [256 B header: seq, timeout flag][granules * 8 B]
+  void* mapped[KOD_PEER_MAX] = {};
+  KodPeerView view = {};
+};
+constexpr long PEER_HEADER = 256;
+
+__global__ void peer_step_begin_kernel(unsigned int* seq) { *seq += 1u; }
+
+// transport self-test / generic form: out[i] = sum over ranks of in[i] (pairs of values per wave, like the BN kernels)
+__global__ void peer_allreduce_f64_kernel(const double* in, double* out, int n, KodPeerView pv, unsigned int slot) {
+  const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int i0 = 2 * pair, i1 = 2 * pair + 1;
+  if (i0 >= n) return;
+  double s0 = in[i0], s1 = i1 < n ? in[i1] : 0.0;
+  const unsigned int seq = *pv.seq;
+  const int g = lane & 3;
+  const unsigned long long gi = (unsigned long long)slot + 2ull * (unsigned long long)(g < 2 ? i0 : (i1 < n ? i1 : i0)) + (g & 1);
+  const unsigned long long b0 = (unsigned long long)__double_as_longlong(s0), b1 = (unsigned long long)__double_as_longlong(s1);
+  const bool second_ok = i1 < n;
+  if (lane < 4 && (g < 2 || second_ok)) {
+    const unsigned long long bits = g < 2 ? b0 : b1;
+    __hip_atomic_store(pv.peers[pv.rank] + gi, ((unsigned long long)seq << 32) | (unsigned int)((g & 1) ? (bits >> 32) : bits),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  unsigned int got = 0;
+  const int r = lane >> 2;
+  if (r < pv.world && (g < 2 || second_ok)) {
+    const unsigned long long* src = pv.peers[r] + gi;
+    unsigned long long v = 0;
+    long spins = 0;
+    for (;;) {
+      v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((unsigned int)(v >> 32) == seq) break;
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1l << 24)) { *pv.timeout_flag = 1; break; }
+    }
+    got = (unsigned int)v;
+  }
+  double t0 = 0.0, t1 = 0.0;
+  for (int q = 0; q < pv.world; ++q) {
+    const unsigned long long lo0 = __shfl(got, 4 * q + 0, 64), hi0 = __shfl(got, 4 * q + 1, 64);
+    const unsigned long long lo1 = __shfl(got, 4 * q + 2, 64), hi1 = __shfl(got, 4 * q + 3, 64);
+    t0 += __longlong_as_double((long long)((hi0 << 32) | lo0));
+    t1 += __longlong_as_double((long long)((hi1 << 32) | lo1));
+  }
+  if (lane == 0) {
+    out[i0] = t0;
+    if (second_ok) out[i1] = t1;
+  }
+}
+
+#define KOD_HIP(call, what)                                                   \
+  do {                                                                        \
+    hipError_t e__ = (call);                                                  \
+    if (e__ != hipSuccess) {                                                  \
+      kodhip_set_error("%s: %s", what, hipGetErrorString(e__));               \
+      return (int)e__;                                                        \
+    }                                                                         \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+// this rank's exchange buffer: `granules` 8-byte granules (4 per channel and exchange site), zero-initialised
+int kodhip_peer_create(void** peer, int rank, int world, long granules) {
+  KOD_CHECK_ARG(peer && world >= 1 && world <= KOD_PEER_MAX && rank >= 0 && rank < world && granules > 0,
+                "peer_create: bad args (rank %d of %d, at most %d ranks of one node)", rank, world, KOD_PEER_MAX);
+  PeerComm* c = new PeerComm();
+  c->rank = rank; c->world = world; c->granules = granules;
+  const size_t bytes = PEER_HEADER + (size_t)granules * 8;
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) { delete c; kodhip_set_error("peer_create: %s", hipGetErrorString(e)); return (int)e; }
+  c->local = (unsigned char*)p;
+  e = hipMemset(p, 0, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(p); delete c; kodhip_set_error("peer_create: %s", hipGetErrorString(e)); return (int)e; }
+  *peer = c;
+  return KOD_OK;
+}
+
+// 64-byte HIP IPC handle of the buffer, to hand to the other ranks out of band
+int kodhip_peer_export(void* peer, void* handle64) {
+  KOD_CHECK_ARG(peer && handle64, "peer_export: null");
+  PeerComm* c = (PeerComm*)peer;
+  hipIpcMemHandle_t h;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
+  KOD_HIP(hipIpcGetMemHandle(&h, c->local), "peer_export");
+  memcpy(handle64, &h, 64);
+  return KOD_OK;
+}
+
+// handles: world x 64 bytes in rank order (this rank's own entry is ignored: it uses its local pointer)
+int kodhip_peer_connect(void* peer, const void* handles) {
+  KOD_CHECK_ARG(peer && handles, "peer_connect: null");
+  PeerComm* c = (PeerComm*)peer;
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) { c->mapped[r] = c->local; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)handles + 64 * r, 64);
+    void* p = nullptr;
+    KOD_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess), "peer_connect");
+    c->mapped[r] = p;
+  }
+  c->view = KodPeerView{};
+  for (int r = 0; r < c->world; ++r) c->view.peers[r] = (unsigned long long*)((unsigned char*)c->mapped[r] + PEER_HEADER);
+  c->view.world = c->world; c->view.rank = c->rank;
+  c->view.seq = (const unsigned int*)c->local;
+  c->view.timeout_flag = (int*)(c->local + 64);
+  return KOD_OK;
+}
+
+int kodhip_peer_view_bytes(void) { return (int)sizeof(KodPeerView); }
+
+// copies the KodPeerView the BatchNorm kernels take by value (device pointers of every rank's granule area)
+int kodhip_peer_view(void* peer, void* view_out) {
+  KOD_CHECK_ARG(peer && view_out, "peer_view: null");
+  PeerComm* c = (PeerComm*)peer;
+  KOD_CHECK_ARG(c->view.world == c->world, "peer_view: call kodhip_peer_connect first");
+  memcpy(view_out, &c->view, sizeof(KodPeerView));
+  return KOD_OK;
+}
+
+// once per training step, before its first exchange (stream-ordered; part of a captured step)
+int kodhip_peer_step_begin(void* peer, hipStream_t stream) {
+  KOD_CHECK_ARG(peer, "peer_step_begin: null");
+  PeerComm* c = (PeerComm*)peer;
+  hipLaunchKernelGGL(peer_step_begin_kernel, dim3(1), dim3(1), 0, stream, (unsigned int*)c->local);
+  KOD_LAUNCH_CHECK("peer_step_begin");
+  return KOD_OK;
+}
+
+// out[i] = sum over ranks of in[i] (fp64, n values, granules [slot, slot + 2 * n)): the transport alone - start-up
+// self-test against an RCCL all-reduce, and the exchange of anything that is not a BatchNorm statistic
+int kodhip_peer_allreduce_f64(void* peer, const double* in, double* out, int n, unsigned int slot, hipStream_t stream) {
+  KOD_CHECK_ARG(peer && in && out && n > 0, "peer_allreduce_f64: bad args");
+  PeerComm* c = (PeerComm*)peer;
+  KOD_CHECK_ARG((long)slot + 2l * n <= c->granules, "peer_allreduce_f64: slot range beyond the exchange buffer");
+  const int pairs = (n + 1) / 2;
+  hipLaunchKernelGGL(peer_allreduce_f64_kernel, dim3(cdiv(pairs, 4)), dim3(256), 0, stream, in, out, n, c->view, slot);
+  KOD_LAUNCH_CHECK("peer_allreduce_f64");
+  return KOD_OK;
+}
+
+// 1 when a poll gave up since the last call (synchronises the device); resets the flag
+int kodhip_peer_timed_out(void* peer, int* flag) {
+  KOD_CHECK_ARG(peer && flag, "peer_timed_out: null");
+  PeerComm* c = (PeerComm*)peer;
+  int v = 0;
+  KOD_HIP(hipMemcpy(&v, c->local + 64, sizeof(int), hipMemcpyDeviceToHost), "peer_timed_out");
+  if (v) { int z = 0; KOD_HIP(hipMemcpy(c->local + 64, &z, sizeof(int), hipMemcpyHostToDevice), "peer_timed_out"); }
+  *flag = v;
+  return KOD_OK;
+}
+
+int kodhip_peer_destroy(void* peer) {
+  if (!peer) return KOD_OK;
+  PeerComm* c = (PeerComm*)peer;
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < c->world; ++r)
+    if (r != c->rank && c->mapped[r]) (void)hipIpcCloseMemHandle(c->mapped[r]);
+  if (c->local) (void)hipFree(c->local);
+  delete c;
+  return KOD_OK;
+}
+
+}  // extern "C"

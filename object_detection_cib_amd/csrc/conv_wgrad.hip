@@ -464,6 +464,259 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
     }
 }
 
+// ---- ROW3 variant: 3x3 / stride 1 / pad 1 (the CSP blocks' conv2, csp.py:30-46) -------------------------------------
+// The generic kernel above gives every 128-column k tile its own block: dY is re-staged once per k tile (5x for a
+// 64-channel layer) and every input pixel once per tap (9x) - these layers run 1.5-1.9x their forward time, bound by
+// that L2 -> LDS fill, not by HBM or the MFMAs.  Here a block covers ALL NINE taps of a 32-channel chunk (x WC chunks):
+// waves are laid out (n group) x (kernel row kh) x (chunk); per 32-row reduction step the dY tile is staged once for
+// the whole block, and for each (kh, chunk) ONE run of 34 consecutive source pixels [m - 1, m + 32] of image row
+// oy + kh - 1 - it serves the three taps kw = 0, 1, 2 as row offsets 0, 1, 2 of the transposed fragment reads.  Pixels
+// are taken in flattened (b, y, x) order; a staged pixel whose image row is outside the image for this kh is an
+// out-of-range buffer offset (zero-filled), and the left / right image border - where the flattened neighbour belongs
+// to another image row - is a per-element mask on the X fragments of taps 0 and 2 (rows with ox == 0 / ox == W - 1,
+// from a wave-uniform row bit mask; most steps have none).  Same slab layout as the generic kernel, so the same
+// reduction kernels follow.
+template <int WN, int RN, int WC, int NST>
+__global__ __launch_bounds__(64 * WN * 3 * WC) void conv_wgrad_row3_kernel(WgradArgs a, uint32_t x_bytes, uint32_t dy_bytes) {
+  constexpr int RS = 32;
+  constexpr int NW = WN * 3 * WC;
+  constexpr int TNB = WN * RN * 32;
+  constexpr int RBY = TNB * 2;               // dY tile row bytes
+  constexpr int RBX = 64;                    // X tile row bytes (32 channels): stride 64 B => conflict-free transposed reads
+  constexpr int XR = 48;                     // staged X rows per (kh, chunk) tile (34 used): 3 DMA instructions x 16 rows
+  constexpr int NIY = RS * RBY / 1024;
+  constexpr int NXT = 3 * WC;                // X tiles per stage, tile = kh * WC + chunk
+  constexpr int NIX = NXT * 3;
+  constexpr int NI = NIY + NIX;
+  constexpr int SLOTS = (NI + NW - 1) / NW;
+  constexpr int XT_BYTES = XR * RBX;
+  constexpr int STAGE = RS * RBY + NXT * XT_BYTES;
+  constexpr int MY = swz_mask(RBY);
+  constexpr int KS = RS / 16;
+  static_assert((RS * RBY) % 1024 == 0 && XT_BYTES % 1024 == 0, "tiles must fill whole DMA instructions");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave % WC, kh = (wave / WC) % 3, wn = wave / (3 * WC);
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int j = bid >> 3;
+  const int tiles = a.tiles_n * a.tiles_k;
+  const int tile = j % tiles;
+  const int split = (j / tiles) * 8 + xcd;
+  if (split >= a.splits) return;
+  const int n0 = (tile % a.tiles_n) * TNB;
+  const int c0 = (tile / a.tiles_n) * (WC * 32);
+  const int m_begin = split * a.m_per_split;
+  int m_end = m_begin + a.m_per_split;
+  if (m_end > a.M) m_end = a.M;
+  const int W = a.Ws, H = a.Hs, HW = a.Hs * a.Ws, BHW = a.B * HW;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, dy_bytes, 0x00020000);
+#endif
+
+  // ---- this wave's DMA slots: instruction t = wave + i * NW; t < NIY feeds the dY tile, else X tile (t - NIY) / 3
+  int s_row[SLOTS];                 // dY: tile row
+  int s_p[SLOTS];                   // X: flattened source pixel of this lane's staged row at step 0 (may be negative)
+  uint32_t s_off[SLOTS];            // dY: running byte offset; X: byte offset of (xcoff + channel)
+  bool s_ok[SLOTS];
+  int s_kh[SLOTS];
+  int my_slots = 0;
+#pragma unroll
+  for (int i = 0; i < SLOTS; ++i) {
+    const int t = wave + i * NW;
+    s_row[i] = 0; s_p[i] = 0; s_off[i] = 0; s_ok[i] = false; s_kh[i] = 1;
+    if (t >= NI) continue;
+    ++my_slots;
+    if (t < NIY) {
+      const int L = t * 1024 + lane * 16;
+      const int row = L / RBY, pc = (L % RBY) >> 4;
+      const int c = pc ^ swz(row, MY);
+      s_row[i] = row;
+      s_ok[i] = (n0 + c * 8) < a.N;
+      s_off[i] = (uint32_t)(((long)(m_begin + row) * a.ldy + a.ycoff + n0 + c * 8) * 2);
+    } else {
+      const int tx = t - NIY;
+      const int xt = tx / 3, part = tx - xt * 3;
+      const int tkh = xt / WC, twc = xt - tkh * WC;
+      const int row = part * 16 + (lane >> 2);
+      const int ch = c0 + twc * 32 + (lane & 3) * 8;
+      s_kh[i] = tkh;
+      s_ok[i] = ch < a.Cin;
+      s_p[i] = m_begin - 1 + (tkh - 1) * W + row;
+      s_off[i] = (uint32_t)((a.xcoff + ch) * 2);
+    }
+  }
+  const uint32_t magic_hw = a.magic_hwo, magic_w = a.magic_wo;        // Ho = Hs, Wo = Ws for this geometry
+  const uint32_t ldx2 = (uint32_t)a.ldx * 2u, ystep = (uint32_t)(RS * a.ldy * 2);
+
+  int issued = 0;
+  auto issue = [&](int stage) {
+    unsigned char* Ys = lds + stage * STAGE;
+    const int mb = m_begin + issued * RS;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+      const int t = wave + i * NW;
+      if (t >= NI) continue;
+      uint32_t vo;
+      bool ok = s_ok[i];
+      if (t < NIY) {
+        ok = ok && (mb + s_row[i]) < m_end;
+        vo = s_off[i];
+        s_off[i] += ystep;
+      } else {
+        const int p = s_p[i];
+        s_p[i] += RS;
+        ok = ok && (unsigned)p < (unsigned)BHW;
+        // image row of the staged pixel: exact magic divisions (estimate q or q + 1)
+        uint32_t b = magic_hw ? __umulhi((uint32_t)p, magic_hw) : (uint32_t)p;
+        int rem = p - (int)b * HW;
+        if (rem < 0) rem += HW;
+        uint32_t y = magic_w ? __umulhi((uint32_t)rem, magic_w) : (uint32_t)rem;
+        if (rem - (int)y * W < 0) --y;
+        // the output pixels this staged pixel serves lie in image row y + 1 - kh
+        ok = ok && (s_kh[i] == 0 ? (int)y + 1 < H : (s_kh[i] == 2 ? y >= 1u : true));
+        vo = (uint32_t)p * ldx2 + s_off[i];
+      }
+      vo = ok ? vo : 0xFFFFFFF0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (t < NIY)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (__attribute__((address_space(3))) void*)(Ys + t * 1024), 16, vo, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Ys + RS * RBY + (t - NIY) * 1024), 16, vo, 0, 0, 0);
+#else
+      (void)vo; (void)Ys;
+#endif
+    }
+    ++issued;
+  };
+
+  f32x16 acc[RN][3];
+#pragma unroll
+  for (int i = 0; i < RN; ++i)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][kw][e] = 0.f;
+
+  const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int sy = swz(tr_row, MY);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  uint32_t yoff[RN], xoff[3];
+#pragma unroll
+  for (int i = 0; i < RN; ++i) {
+    const int col = (wn * RN + i) * 32 + tr_col;
+    yoff[i] = (uint32_t)(tr_row * RBY + (((col >> 3) ^ sy) << 4) + (col & 7) * 2);
+  }
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+    xoff[kw] = (uint32_t)(RS * RBY + (kh * WC + wc) * XT_BYTES + (tr_row + kw) * RBX + ((tr_col >> 3) << 4) + (tr_col & 7) * 2);
+
+  const int nsteps = (m_end - m_begin + RS - 1) / RS;
+  int ox_step = m_begin % W;                // ox of the step's first row (wave-uniform)
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nsteps) issue(p);
+  for (int st = 0; st < nsteps; ++st) {
+    const int newer = nsteps - 1 - st;
+    if (newer >= NST - 2) {
+      if (my_slots == SLOTS) wait_vm<(NST - 2) * SLOTS>(); else wait_vm<(NST - 2) * (SLOTS - 1)>();
+    } else if (newer == 1 && NST > 3) {
+      if (my_slots == SLOTS) wait_vm<SLOTS>(); else wait_vm<SLOTS - 1>();
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (st + NST - 1 < nsteps) issue((st + NST - 1) % NST);
+    // rows of this step on the left / right image border (taps kw = 0 / kw = 2 must not see their flattened neighbour)
+    uint32_t inv0 = 0, inv2 = 0;
+    for (int r = ox_step == 0 ? 0 : W - ox_step; r < RS; r += W) inv0 |= 1u << r;
+    for (int r = W - 1 - ox_step; r < RS; r += W) inv2 |= 1u << r;
+    ox_step += RS;
+    while (ox_step >= W) ox_step -= W;
+
+    const uint32_t sb = lds_base + (uint32_t)((st % NST) * STAGE);
+    s16x4 ylo[KS][RN], yhi[KS][RN], xlo[KS][3], xhi[KS][3];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < RN; ++i) {
+        const uint32_t p = sb + yoff[i] + (uint32_t)(ks * 16 * RBY);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[ks][i]) : "v"(p) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(yhi[ks][i]) : "v"(p + 4 * RBY) : "memory");
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const uint32_t p = sb + xoff[kw] + (uint32_t)(ks * 16 * RBX);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo[ks][kw]) : "v"(p) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xhi[ks][kw]) : "v"(p + 4 * RBX) : "memory");
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      constexpr int PER = 2 * (RN + 3);
+      if (ks == KS - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PER < 15 ? PER : 15) : "memory");
+#pragma unroll
+      for (int i = 0; i < RN; ++i) asm volatile("" : "+v"(ylo[ks][i]), "+v"(yhi[ks][i]));
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) asm volatile("" : "+v"(xlo[ks][kw]), "+v"(xhi[ks][kw]));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      if ((inv0 | inv2) != 0) {      // wave-uniform: border rows in this step (1 step in W / 32 for the wide layers)
+        const int sh = ks * 16 + 8 * (lane >> 5);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const uint32_t bits = ((side == 0 ? inv0 : inv2) >> sh) & 0xFFu;     // element j of this lane's 8 rows
+          const int kw = side == 0 ? 0 : 2;
+          u32x2 lo = __builtin_bit_cast(u32x2, xlo[ks][kw]), hi = __builtin_bit_cast(u32x2, xhi[ks][kw]);
+          lo[0] &= ((bits & 1u) ? 0u : 0xFFFFu) | ((bits & 2u) ? 0u : 0xFFFF0000u);
+          lo[1] &= ((bits & 4u) ? 0u : 0xFFFFu) | ((bits & 8u) ? 0u : 0xFFFF0000u);
+          hi[0] &= ((bits & 16u) ? 0u : 0xFFFFu) | ((bits & 32u) ? 0u : 0xFFFF0000u);
+          hi[1] &= ((bits & 64u) ? 0u : 0xFFFFu) | ((bits & 128u) ? 0u : 0xFFFF0000u);
+          xlo[ks][kw] = __builtin_bit_cast(s16x4, lo); xhi[ks][kw] = __builtin_bit_cast(s16x4, hi);
+        }
+      }
+      bf16x8 yf[RN], xf[3];
+#pragma unroll
+      for (int i = 0; i < RN; ++i) {
+        s16x8 t = {ylo[ks][i][0], ylo[ks][i][1], ylo[ks][i][2], ylo[ks][i][3], yhi[ks][i][0], yhi[ks][i][1], yhi[ks][i][2], yhi[ks][i][3]};
+        yf[i] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        s16x8 t = {xlo[ks][kw][0], xlo[ks][kw][1], xlo[ks][kw][2], xlo[ks][kw][3], xhi[ks][kw][0], xhi[ks][kw][1], xhi[ks][kw][2], xhi[ks][kw][3]};
+        xf[kw] = __builtin_bit_cast(bf16x8, t);
+      }
+#pragma unroll
+      for (int i = 0; i < RN; ++i)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          acc[i][kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i], xf[kw], acc[i][kw], 0, 0, 0);
+    }
+  }
+  // D[n][k]: k = lane & 31, n = 8*(e>>2) + 4*(lane>>5) + (e&3); slab column k = (kh*3 + kw) * Cin + channel
+  float* slab = a.part + (size_t)split * a.N * a.Kp;
+  const int ch = c0 + wc * 32 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < RN; ++i)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int k = (kh * 3 + kw) * a.Cin + ch;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + (wn * RN + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        if (n < a.N && ch < a.Cin) slab[(size_t)n * a.Kp + k] = acc[i][kw][e];
+      }
+    }
+}
+
 // grad[n][ci][kh][kw] = scale * sum_s part[s][n][k(kh,kw,ci)]   (stem: k = (kh, kw', dx, c4), see pack)
 // block = RK consecutive k x RL split lanes (RK * RL = 256): each lane streams RK*4-byte contiguous pieces of its
 // slabs with four independent partial sums (loads in flight), fixed-order LDS combine => deterministic.
@@ -610,6 +863,34 @@ int launch_cfg(WgradArgs a, hipStream_t stream) {
   return KOD_OK;
 }
 
+// ROW3 form (conv_wgrad_row3_kernel): 3x3 / stride 1 / pad 1 with whole 32-channel chunks.  KODHIP_WGRAD_ROW3=0: off.
+struct Row3Cfg { bool on; int wn, rn, wc, tnb; };
+Row3Cfg row3_cfg(int N, int Cin, int KH, int KW, int SH, int SW, int PH, int PW) {
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("KODHIP_WGRAD_ROW3"); mode = e ? atoi(e) : 1; }
+  Row3Cfg c = {false, 0, 0, 0, 0};
+  if (!mode || KH != 3 || KW != 3 || SH != 1 || SW != 1 || PH != 1 || PW != 1 || Cin % 32 != 0 || N % 8 != 0) return c;
+  c.on = true;
+  if (N <= 32) { c.wn = 1; c.rn = 1; }
+  else if (N <= 64) { c.wn = 1; c.rn = 2; }
+  else { c.wn = 2; c.rn = 2; }
+  c.wc = Cin >= 64 ? 2 : 1;
+  c.tnb = c.wn * c.rn * 32;
+  return c;
+}
+
+template <int WN, int RN, int WC>
+int launch_row3(WgradArgs a, hipStream_t stream) {
+  // ring depth: 4 stages where two 6-wave / one 12-wave block still fit a CU's 160 KB, 3 stages for the 3-wave blocks
+  // (4 resident) and the widest 6-wave stage
+  constexpr int NST = (WN * 3 * WC == 3 || (WN == 1 && RN == 2 && WC == 2)) ? 3 : 4;
+  const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, yb = (long)a.M * a.ldy * 2;
+  const int grid = cdiv(a.splits, 8) * 8 * a.tiles_n * a.tiles_k;
+  hipLaunchKernelGGL((conv_wgrad_row3_kernel<WN, RN, WC, NST>), dim3(grid), dim3(64 * WN * 3 * WC), 0, stream, a, (uint32_t)xb, (uint32_t)yb);
+  KOD_LAUNCH_CHECK("conv_wgrad_row3");
+  return KOD_OK;
+}
+
 void tile_shape(int N, int Kp, int* tn, int* tk) {
   *tn = N > 64 ? 128 : (N > 32 ? 64 : 32);
   *tk = Kp > 64 ? 128 : (Kp > 32 ? 64 : 32);
@@ -639,6 +920,30 @@ static int wgrad_rows_per_split(long M, int N, int Kp) {
   return cdiv(cdiv(M, wgrad_splits_target(M, N, Kp)), 32) * 32;
 }
 
+// rows per split for a given geometry: the ROW3 form has its own block count (tiles = n tiles x channel chunks)
+static int wgrad_rows_per_split_geo(long M, int N, int Cin, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
+                                    long x_bytes, long dy_bytes) {
+  const Row3Cfg c = row3_cfg(N, Cin, KH, KW, SH, SW, PH, PW);
+  if (!c.on || x_bytes >= (1l << 32) - 64 || dy_bytes >= (1l << 32) - 64) return wgrad_rows_per_split(M, N, Kp);
+  const int tiles = cdiv(N, c.tnb) * cdiv(Cin, c.wc * 32);
+  const int slots = 3072 / (c.wn * 3 * c.wc);          // resident blocks: 1024 (3 waves), 512 (6), 256 (12)
+  int sp = slots / tiles;
+  if (sp < 1) sp = 1;
+  const long maxs = (M + 255) / 256;
+  if (sp > maxs) sp = (int)maxs;
+  if (sp < 1) sp = 1;
+  return cdiv(cdiv(M, sp), 32) * 32;
+}
+
+// Exact split count for a layer geometry (ldx / ldy: row strides of the operands, for the 32-bit range test).
+int kodhip_conv_wgrad_splits_geo(int B, int H, int W, int ldx, int Cin, int N, int KH, int KW, int SH, int SW, int PH, int PW,
+                                 int Kp, int ldy) {
+  const int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
+  const long M = (long)B * Ho * Wo;
+  const long xb = (long)B * H * W * ldx * 2, yb = M * ldy * 2;
+  return (int)cdiv(M, (long)wgrad_rows_per_split_geo(M, N, Cin, KH, KW, SH, SW, PH, PW, Kp, xb, yb));
+}
+
 // Number of reduction splits the launcher uses (exact; the partials region must hold splits * N * Kp floats).
 int kodhip_conv_wgrad_splits(long M, int N, int Kp) { return (int)cdiv(M, (long)wgrad_rows_per_split(M, N, Kp)); }
 
@@ -660,8 +965,20 @@ static int wgrad_partial(WgradArgs& a, const void* x, const void* dy, float* par
   a.KH = KH; a.KW = KW; a.SH = SH; a.SW = SW; a.PH = PH; a.PW = PW; a.ldy = ldy; a.ycoff = ycoff;
   a.magic_cin = magic_u32((uint32_t)Cin); a.magic_kw = magic_u32((uint32_t)KW);
   a.magic_hwo = magic_u32((uint32_t)(a.Ho * a.Wo)); a.magic_wo = magic_u32((uint32_t)a.Wo);
-  a.m_per_split = wgrad_rows_per_split(M, N, Kp);
+  const long xb = (long)B * H * W * ldx * 2, yb = M * ldy * 2;
+  a.m_per_split = wgrad_rows_per_split_geo(M, N, Cin, KH, KW, SH, SW, PH, PW, Kp, xb, yb);
   a.splits = cdiv(M, a.m_per_split);
+  const Row3Cfg r3 = row3_cfg(N, Cin, KH, KW, SH, SW, PH, PW);
+  if (r3.on && xb < (1l << 32) - 64 && yb < (1l << 32) - 64) {
+    a.tiles_n = cdiv(N, r3.tnb);
+    a.tiles_k = cdiv(Cin, r3.wc * 32);
+    if (r3.wn == 1 && r3.rn == 1 && r3.wc == 1) return launch_row3<1, 1, 1>(a, stream);
+    if (r3.wn == 1 && r3.rn == 1) return launch_row3<1, 1, 2>(a, stream);
+    if (r3.wn == 1 && r3.wc == 1) return launch_row3<1, 2, 1>(a, stream);
+    if (r3.wn == 1) return launch_row3<1, 2, 2>(a, stream);
+    if (r3.wc == 1) return launch_row3<2, 2, 1>(a, stream);
+    return launch_row3<2, 2, 2>(a, stream);
+  }
   int tn, tk, rc;
   tile_shape(N, Kp, &tn, &tk);
   if (tn == 128 && tk == 128) rc = launch_cfg<2, 2, 2, 2>(a, stream);

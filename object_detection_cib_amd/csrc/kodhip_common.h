@@ -51,5 +51,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// ---- SyncBN peer exchange (csrc/comm.hip: kodhip_peer_*): every rank of the node maps every other rank's exchange
+// buffer; a value travels as two 8-byte {tag : 32 | payload : 32} granules written by ONE system-scope store each (the
+// tag is the step's sequence number: a reader polls until it sees it - no separate flag, no ordering between stores).
+#define KOD_PEER_MAX 8
+struct KodPeerView {
+  unsigned long long* peers[KOD_PEER_MAX];   // device-visible base of rank r's granule area (own rank: the local buffer)
+  int world, rank;
+  const unsigned int* seq;                   // device: sequence number of the current step (kodhip_peer_step_begin)
+  int* timeout_flag;                         // device: set when a poll gave up (a peer never published)
+};
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline uint32_t magic_u32(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }

@@ -65,6 +65,8 @@ class Engine:
         self.comm = None               # RcclComm when the process group is RCCL-backed (the product path)
         self.comm_buckets = None       # second communicator: gradient buckets on the weight-gradient stream (comm_overlap)
         self.comm_overlap = self.opt.comm_overlap
+        self.peer = None               # PeerExchange: SyncBN sums over IPC-mapped peer buffers instead of RCCL all-reduces
+        self.peer_slots = None         # {(unit name, "f" | "b"): first granule of that exchange}
         self.collectives = False       # True when gradients / BN sums go through the process group (world > 1)
         self.bucket_bytes = int(self.opt.bucket_mb * (1 << 20))
         self._checked_shapes = set()   # local batch shapes already compared across the ranks (SyncBN, see forward)
@@ -296,9 +298,14 @@ class Engine:
             st.bsums = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
             st.bsums_g = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
             st.coef = torch.empty(3 * u.cout, dtype=torch.float32, device=dev)
-            st.wg_splits = lib.kodhip_conv_wgrad_splits(st.M, u.cout, st.Kp)
-            st.wg_off = max_part                       # this layer's own slab region [splits][cout][Kp] (floats)
-            max_part += _pad(st.wg_splits * u.cout * st.Kp)
+            wgeo = (B, st.H, st.W, 8, 8, u.cout, 6, 3, 2, 1, 2, 1) if u.stem else \
+                (B, st.H, st.W, u.src.buf.C, u.cin, u.cout, u.k, u.k, u.s, u.s, u.p, u.p)
+            st.wg_splits = lib.kodhip_conv_wgrad_splits_geo(*wgeo, st.Kp, u.cout)
+            # slab region [splits][cout][Kp] (floats): ONE scratch shared by all layers (reduced right after each weight
+            # gradient, while it is still in the 256 MB Infinity Cache) - or, for the per-bucket reduction, a region each
+            own = self.opt.wgrad_reduce_batched
+            st.wg_off = max_part if own else 0
+            max_part = max_part + _pad(st.wg_splits * u.cout * st.Kp) if own else max(max_part, st.wg_splits * u.cout * st.Kp)
         self._plan_bn_fusion(B)
         self.gact32 = {}
         if self._f32plan is not None:
@@ -310,9 +317,11 @@ class Engine:
             hs.update(H=hh, W=ww, M=B * hh * ww)
             hs["dy"] = torch.empty((B * hh * ww, self.head_npad), dtype=torch.bfloat16, device=dev)
             hs["ws"] = torch.empty(2048 * self.head_npad, dtype=torch.float32, device=dev)
-            hs["wg_splits"] = lib.kodhip_conv_wgrad_splits(hs["M"], self.head_npad, hs["Kp"])
-            hs["wg_off"] = max_part
-            max_part += _pad(hs["wg_splits"] * self.head_npad * hs["Kp"])
+            hs["wg_splits"] = lib.kodhip_conv_wgrad_splits_geo(B, hh, ww, h.src.buf.C, h.cin, self.head_npad, 1, 1, 1, 1, 0, 0,
+                                                               hs["Kp"], self.head_npad)
+            hs["wg_off"] = max_part if own else 0
+            nslab = hs["wg_splits"] * self.head_npad * hs["Kp"]
+            max_part = max_part + _pad(nslab) if own else max(max_part, nslab)
         self.wg_part = torch.empty(max_part, dtype=torch.float32, device=dev)
         self._plan_wgrad_reduce()
         # SPPF argmax indices
@@ -548,6 +557,16 @@ class Engine:
                                                         pa + 4 * st.b_off, rm + 4 * st.rs_off, rv + 4 * st.rs_off,
                                                         BN_MOMENTUM, BN_EPS, aff, aff + 4 * C_, aff + 8 * C_,
                                                         aff + 12 * C_, C_, 1, s), u.name)
+            elif self.peer is not None:
+                # SyncBN over peer buffers: the same single launch per unit, the ranks' sums meet inside the kernel
+                for u in group:
+                    st, C_ = self.ustate[u.name], u.cout
+                    aff = st.aff.data_ptr()
+                    chk(lib.kodhip_bn_finalize_partials_peer(st.stats.data_ptr(), st.T, float(st.M) * self.world_size,
+                                                             pa + 4 * st.g_off, pa + 4 * st.b_off, rm + 4 * st.rs_off,
+                                                             rv + 4 * st.rs_off, BN_MOMENTUM, BN_EPS, aff, aff + 4 * C_,
+                                                             aff + 8 * C_, aff + 12 * C_, C_, 1, self.peer.view_ptr(),
+                                                             self.peer_slots[(u.name, "f")], s), u.name)
             else:
                 for u in group:
                     st = self.ustate[u.name]
@@ -578,7 +597,10 @@ class Engine:
         # branch sits in a single-block statistics kernel or a latency-bound deep layer.  (Not under SyncBN - the two
         # statistic exchanges travel as one grouped collective on the main stream - and not while timing families.)
         main_stream = torch.cuda.current_stream()
-        branch = training and not sync and self.branch_overlap and self.profile is None
+        if sync and self.peer is not None:
+            self.peer.step_begin(s)            # the step's sequence number: tags every statistic this rank publishes
+        # (with the peer exchange there is no communicator whose call order the side streams could disturb)
+        branch = training and (not sync or self.peer is not None) and self.branch_overlap and self.profile is None
         # the P3 / P4 head convolutions are leaves (only the loss reads them): they run on their own side stream as soon
         # as their input exists, beside the bottom-up path, instead of after it.  head_src: buffer -> "ready" event
         heads_aside = training and self.branch_overlap and self.profile is None          # (also under SyncBN: no collective involved)
@@ -626,8 +648,8 @@ class Engine:
                 after_first_layer = None
             if op.kind == "conv":
                 group = [op.unit]
-                # SyncBN: a unit and its sibling (same input, next in the program) share one statistic exchange
-                if sync and op.unit.sibling is not None and i < len(ops) and ops[i].unit is op.unit.sibling:
+                # SyncBN over RCCL: a unit and its sibling (same input, next in the program) share one statistic exchange
+                if sync and self.peer is None and op.unit.sibling is not None and i < len(ops) and ops[i].unit is op.unit.sibling:
                     group.append(ops[i].unit)
                     i += 1
                 for u in group:
@@ -826,6 +848,7 @@ class Engine:
         pool_i = len(self.pool_idx)
         head_i = len(self.g.heads)
         sync = self.sync_bn and self.collectives
+        rccl_sync = sync and self.peer is None
 
         def bucket_tick():
             """one conv / head unit's gradients are complete: buckets finish from the arena's end toward its start"""
@@ -862,6 +885,17 @@ class Engine:
                                                       st.bpart.data_ptr(), st.M, C_, s), u.name)
                     self._t1(e0, "bn_bwd_reduce", 4.0 * st.M * C_)
             e0 = self._t0()
+            if sync and self.peer is not None:
+                for u in group:
+                    st, C_ = self.ustate[u.name], u.cout
+                    aff = st.aff.data_ptr()
+                    chk(lib.kodhip_bn_bwd_coeffs_partials_peer(st.bpart.data_ptr(), st.T2, float(st.M) * self.world_size,
+                                                               pa + 4 * st.g_off, aff + 8 * C_, aff + 12 * C_,
+                                                               gp + 4 * st.g_off, gp + 4 * st.b_off, st.coef.data_ptr(), C_,
+                                                               1 if st.fused_red else 0, self.peer.view_ptr(),
+                                                               self.peer_slots[(u.name, "b")], s), u.name)
+                self._t1(e0, "bn_bwd_coeffs", sum(8.0 * u.cout * self.ustate[u.name].T2 for u in group))
+                return
             if sync:
                 for u in group:
                     st = self.ustate[u.name]
@@ -961,7 +995,7 @@ class Engine:
                 # SyncBN: short_conv (reached first in reverse order) and its main_conv share one exchange - main's
                 # output gradient is complete by now (everything between them in the forward program ran backward)
                 if ri < len(rops) and rops[ri].kind == "conv" and rops[ri].unit.sibling is op.unit and \
-                        (sync or rops[ri].unit.name in self._dual):
+                        (rccl_sync or rops[ri].unit.name in self._dual):
                     group.append(rops[ri].unit)
                     ri += 1
                 bn_bwd_stats(group)

@@ -38,7 +38,7 @@ class EngineOptions:
     bn_reduce_fused: bool = True      # KODHIP_NO_BNRED=1 switches off
     bn_reduce_min_k: int = 0          # KODHIP_BNRED_MINK
     dx_accum_fp32: bool = False       # KODHIP_DX_FP32: multi-consumer activation gradients accumulated in fp32
-    wgrad_reduce_batched: bool = True  # KODHIP_WGRAD_REDUCE=layer: one slab reduction per layer (round 2) instead of per bucket
+    wgrad_reduce_batched: bool = False  # KODHIP_WGRAD_REDUCE=bucket: one slab-reduction launch per gradient bucket (slower: see DESIGN)
     debug_plan: bool = False          # KODHIP_DEBUG_PLAN
     max_shape_sets: int = 4           # KODHIP_MAX_SHAPE_SETS
     bucket_mb: float = 8.0
@@ -58,7 +58,7 @@ class EngineOptions:
             bn_reduce_fused=not _flag("KODHIP_NO_BNRED", False),
             bn_reduce_min_k=int(e.get("KODHIP_BNRED_MINK", "0")),
             dx_accum_fp32=_flag("KODHIP_DX_FP32", False),
-            wgrad_reduce_batched=e.get("KODHIP_WGRAD_REDUCE", "bucket") != "layer",
+            wgrad_reduce_batched=e.get("KODHIP_WGRAD_REDUCE", "layer") == "bucket",
             debug_plan=_flag("KODHIP_DEBUG_PLAN", False),
             max_shape_sets=int(e.get("KODHIP_MAX_SHAPE_SETS", "4")),
             native={k: e[k] for k in NATIVE_KNOBS if k in e},

@@ -134,6 +134,8 @@ class Yolov5Network(nn.Module):
             eng.comm = RcclComm(process_group, eng.device)
             if eng.comm_overlap:          # default: gradient buckets on the weight-gradient stream, own communicator
                 eng.comm_buckets = RcclComm(process_group, eng.device)
+        if eng.collectives and sync_batchnorm and eng.peer is None and eng.opt.syncbn_exchange in ("auto", "peer"):
+            self._setup_peer_exchange(eng, process_group)
         if eng.collectives:
             # rank 0's parameters and BatchNorm buffers everywhere (torch DDP does this at wrap time)
             for t in (eng.p_arena, eng.rm_arena, eng.rv_arena):
@@ -143,6 +145,51 @@ class Yolov5Network(nn.Module):
                     dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group else 0,
                                    group=process_group)
             eng.mark_params_changed()
+
+    @staticmethod
+    def _setup_peer_exchange(eng, process_group):
+        """SyncBN statistics over IPC-mapped peer buffers (engine/comm.py PeerExchange) when every rank sits on this
+        node and the transport passes its start-up self-test; otherwise the exchanges stay RCCL all-reduces
+        (KODHIP_SYNCBN=rccl forces that, =peer makes a failing set-up an error instead of a fallback)."""
+        import socket
+        import sys
+        import torch.distributed as dist
+        from ...engine.comm import PeerExchange
+        strict = eng.opt.syncbn_exchange == "peer"
+        hosts = [None] * eng.world_size
+        dist.all_gather_object(hosts, socket.gethostname(), group=process_group)
+        why = None
+        if len(set(hosts)) != 1:
+            why = "ranks on several nodes"
+        elif eng.world_size > 8:
+            why = "more than 8 ranks"
+        if why is None:
+            slots, off = {}, 0
+            for u in eng.exec_units:
+                for d in ("f", "b"):
+                    slots[(u.name, d)] = off
+                    off += 4 * u.cout
+            try:
+                peer = PeerExchange(process_group, eng.device, max(off, 4096))
+                if peer.selftest():
+                    eng.peer, eng.peer_slots = peer, slots
+                else:
+                    peer.close()
+                    why = "the transport self-test failed"
+            except RuntimeError as e:          # no IPC between these processes (e.g. HSA_ENABLE_IPC_MODE_LEGACY unset)
+                why = f"set-up failed: {e}"
+            # one decision for the whole job
+            oks = [None] * eng.world_size
+            dist.all_gather_object(oks, eng.peer is not None, group=process_group)
+            if not all(oks) and eng.peer is not None:
+                eng.peer.close()
+                eng.peer, why = None, "another rank could not set it up"
+        if eng.peer is None:
+            if strict:
+                raise RuntimeError(f"KODHIP_SYNCBN=peer: {why}")
+            if dist.get_rank(process_group) == 0:
+                print(f"[kodhip] SyncBN statistics through RCCL all-reduces ({why})", file=sys.stderr, flush=True)
+        eng.opt.syncbn_exchange = "peer" if eng.peer is not None else "rccl"
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)

@@ -40,14 +40,16 @@ def _run(net, loss, x, tg, size):
     return total.item()
 
 
-def _worker(rank, world, port, size, out):
+def _worker(rank, world, port, size, out, syncbn="rccl"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["KODHIP_SYNCBN"] = syncbn             # "rccl": collectives of the group (gloo here); "peer": IPC peer buffers
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
         net, loss = _build(5)
         net.configure_distributed(None, sync_batchnorm=True, bucket_mb=0.5)
+        assert (net.engine().peer is not None) == (syncbn == "peer")
         x, tg = _data(size)
         _run(net, loss, x[2 * rank:2 * rank + 2], tg[2 * rank:2 * rank + 2], size)
         g = torch.cat([p.grad.flatten() for p in net.parameters()]).cpu()
@@ -55,6 +57,9 @@ def _worker(rank, world, port, size, out):
         net.engine().sgd_step((0.1, 0.01, 0.01), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0), 1.0 / world)
         torch.cuda.synchronize()
         p = torch.cat([q.detach().flatten() for q in net.parameters()]).cpu()
+        if net.engine().peer is not None:
+            assert not net.engine().peer.timed_out()
+            net.engine().peer.close()
         if rank == 0:
             torch.save(dict(g=g, rm=rm, p=p), out)
     finally:
@@ -70,18 +75,25 @@ def test_two_rank_ddp_syncbn_equals_single_process(tmp_path):
     changed.)"""
     import torch.multiprocessing as mp
     size = 256
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    out = str(tmp_path / "ddp.pt")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, size, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
-    got = torch.load(out)
+    res = {}
+    # SyncBN statistics through the group's collectives, and through IPC-mapped peer buffers (two processes mapping
+    # each other's exchange buffer on the one GPU): the two transports must agree bit for bit
+    for mode in ("rccl", "peer"):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = str(tmp_path / f"ddp_{mode}.pt")
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, size, out, mode)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0, mode
+        res[mode] = torch.load(out)
+    for k in ("g", "rm", "p"):
+        assert torch.equal(res["peer"][k], res["rccl"][k]), k
+    got = res["peer"]
     # single process on all 4 images
     net, loss = _build(5)
     x, tg = _data(size)
@@ -116,9 +128,11 @@ def _native_worker(port, size, out):
 
         x, tg = _data(size)
         res = {}
-        for mode in ("plain", "default-eager", "default-graph", "inorder-eager", "inorder-graph"):
+        for mode in ("plain", "default-eager", "default-graph", "inorder-eager", "inorder-graph", "rccl-eager", "rccl-graph"):
             net, loss = _build(5)
             eng = net.engine()
+            if mode.startswith("rccl"):          # SyncBN statistics as RCCL all-reduces instead of the peer exchange (default)
+                eng.opt.syncbn_exchange = "rccl"
             # default-*: what a job gets without any switch - gradient buckets overlapped with backward on the
             # weight-gradient stream through their own communicator; inorder-*: KODHIP_COMM_OVERLAP=0
             assert eng.comm_overlap, "bucket / backward overlap must be the default"
@@ -128,6 +142,7 @@ def _native_worker(port, size, out):
                 net.configure_distributed(None, sync_batchnorm=True, bucket_mb=0.5, native_rccl=True)
                 assert eng.comm is not None and eng.collectives
                 assert (eng.comm_buckets is not None) == eng.comm_overlap
+                assert (eng.peer is not None) == (not mode.startswith("rccl"))
             eng.sgd_step((0.1, 0.01, 0.01), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0), 1.0)
             from object_detection_cib_amd.core.label_assignment.yv5 import BatchedTargets
             from object_detection_cib_amd.core.types import FeatureShape
@@ -161,7 +176,9 @@ def _native_worker(port, size, out):
             else:
                 losses += [step().item() for _ in range(3)]
             res[mode] = (losses, torch.cat([q.detach().flatten() for q in net.parameters()]).cpu())
-            for c in (eng.comm, eng.comm_buckets):
+            if eng.peer is not None:
+                assert not eng.peer.timed_out()
+            for c in (eng.comm, eng.comm_buckets, eng.peer):
                 if c is not None:
                     c.close()
         torch.save(res, out)
@@ -186,7 +203,8 @@ def test_native_rccl_comm_and_captured_step(tmp_path):
     ref_l, ref_p = res["plain"]
     # default-*: gradient buckets on the weight-gradient stream through their own communicator, eager and captured;
     # inorder-*: every collective on the main stream (KODHIP_COMM_OVERLAP=0)
-    for mode in ("default-eager", "default-graph", "inorder-eager", "inorder-graph"):
+    # rccl-*: SyncBN statistics as RCCL all-reduces (KODHIP_SYNCBN=rccl) instead of the peer-buffer exchange
+    for mode in ("default-eager", "default-graph", "inorder-eager", "inorder-graph", "rccl-eager", "rccl-graph"):
         l, prm = res[mode]
         assert l == ref_l, (mode, l, ref_l)
         assert torch.equal(prm, ref_p), mode

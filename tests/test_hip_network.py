@@ -639,8 +639,9 @@ def test_multi_producer_dx_b64_640_vs_fp32_torch():
 
 
 def test_batched_wgrad_reduction_equals_per_layer_reduction():
-    """Weight gradients: one slab-reduction launch per gradient bucket (the default) must give, bit for bit, what one
-    reduction per layer gives - same slabs, same fixed-order sums, only the launch granularity differs.  Two bucket
+    """Weight gradients: one slab-reduction launch per gradient bucket (KODHIP_WGRAD_REDUCE=bucket; measured slower than the
+    default, DESIGN 4: the per-layer scratch stays in the Infinity Cache, per-layer regions do not) must give, bit for bit,
+    what one reduction per layer gives - same slabs, same fixed-order sums, only the launch granularity differs.  Two bucket
     sizes (several buckets / one) at a size where every layer really splits its reduction."""
     from object_detection_cib_amd.engine.options import EngineOptions
     widen, deepen, nc, B, size, seed = 0.5, 0.33, 10, 4, 320, 7

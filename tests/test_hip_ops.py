@@ -37,6 +37,14 @@ CONV_CASES = [
     (2, 16, 8, 8, 48, 3, 1, 1),          # 16 input channels: every half step is a new tap
     (2, 96, 10, 10, 48, 3, 2, 1),        # stride-2 dgrad gathers 48-channel dY: half-step form in the merged launch
     (3, 80, 7, 9, 80, 3, 1, 1),          # yv5x-like 80 channels
+    # the CSP blocks' 3x3 layers at their real widths (weight gradient: conv_wgrad_row3_kernel - image rows of 160 / 80 /
+    # 40 / 20 pixels against 32-row reduction steps, border masks, every wave layout)
+    (2, 32, 160, 160, 32, 3, 1, 1),
+    (2, 64, 80, 80, 64, 3, 1, 1),
+    (3, 128, 40, 40, 128, 3, 1, 1),
+    (5, 256, 20, 20, 256, 3, 1, 1),
+    (2, 64, 24, 40, 32, 3, 1, 1),        # N = 32 with two channel chunks
+    (2, 32, 10, 6, 64, 3, 1, 1),         # image rows shorter than a DMA piece
 ]
 
 
@@ -75,7 +83,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     _close(nchw(dxb), 2 * xr.grad, 2e-2, 6e-2, "dgrad accumulate")
     # wgrad
     M = B * Ho * Wo
-    splits = lib.kodhip_conv_wgrad_splits(M, Cout, pk["Kp"])
+    splits = lib.kodhip_conv_wgrad_splits_geo(B, H, W, Cin, Cin, Cout, k, k, s, s, p, p, pk["Kp"], Cout)
     part = torch.zeros(splits * Cout * pk["Kp"], dtype=torch.float32, device="cuda")
     gw = torch.zeros_like(w, device="cuda")
     _lib.check(lib.kodhip_conv_wgrad(xb.data_ptr(), dyb.data_ptr(), part.data_ptr(), gw.data_ptr(), B, H, W, Cin, 0,
@@ -151,7 +159,7 @@ def test_stem_conv():
     dyb = nhwc(dy)
     M = B * (H // 2) * (W // 2)
     Kw = 160                                   # weight-gradient slabs keep the 6x3-tap x 8-channel K (144 -> 160)
-    splits = lib.kodhip_conv_wgrad_splits(M, Cout, Kw)
+    splits = lib.kodhip_conv_wgrad_splits_geo(B, H, W // 2, 8, 8, Cout, 6, 3, 2, 1, 2, 1, Kw, Cout)
     part = torch.zeros(splits * Cout * Kw, dtype=torch.float32, device="cuda")
     gw = torch.zeros_like(w, device="cuda")
     _lib.check(lib.kodhip_conv_wgrad(img.data_ptr(), dyb.data_ptr(), part.data_ptr(), gw.data_ptr(), B, H, W // 2, 8, 0,
@@ -197,7 +205,7 @@ def test_head_conv_fwd_bwd():
     _lib.check(lib.kodhip_conv_dgrad(dy.data_ptr(), pk["d"].data_ptr(), dx.data_ptr(), B, H, W, C, 0, C, npad, 1, 1, 1, 1,
                                      0, 0, pk["Kdp"], npad, 0, 0, None, stream()), "head dgrad")
     _close(nchw(dx), xr.grad, 2e-2, 3e-2, "head dgrad")
-    splits = lib.kodhip_conv_wgrad_splits(B * H * W, npad, pk["Kp"])
+    splits = lib.kodhip_conv_wgrad_splits_geo(B, H, W, C, C, npad, 1, 1, 1, 1, 0, 0, pk["Kp"], npad)
     part = torch.zeros(splits * npad * pk["Kp"], dtype=torch.float32, device="cuda")
     gw = torch.zeros(A * (5 + nc), C, device="cuda")
     _lib.check(lib.kodhip_conv_wgrad(xb.data_ptr(), dy.data_ptr(), part.data_ptr(), gw.data_ptr(), B, H, W, C, 0, C, npad,

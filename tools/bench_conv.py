@@ -32,7 +32,7 @@ for name in which:
     dx = torch.empty_like(x)
     T = lib.kodhip_conv_stats_slots(M, Cout)
     stats = torch.empty(2 * Cout * T, device="cuda")
-    splits = lib.kodhip_conv_wgrad_splits(M, Cout, pk["Kp"])
+    splits = lib.kodhip_conv_wgrad_splits_geo(B, H, W, Cin, Cin, Cout, k, k, s, s, p, p, pk["Kp"], Cout)
     part = torch.empty(splits * Cout * pk["Kp"], device="cuda")
     gw = torch.empty(Cout, Cin, k, k, device="cuda")
     st = stream()
