@@ -863,13 +863,20 @@ int launch_cfg(WgradArgs a, hipStream_t stream) {
   return KOD_OK;
 }
 
-// ROW3 form (conv_wgrad_row3_kernel): 3x3 / stride 1 / pad 1 with whole 32-channel chunks.  KODHIP_WGRAD_ROW3=0: off.
+// ROW3 form (conv_wgrad_row3_kernel): 3x3 / stride 1 / pad 1 with whole 32-channel chunks.
+// KODHIP_WGRAD_ROW3: 0 = off, 1 (default) = where it measured faster, 2 = every eligible layer.
+// Measured at B = 64 / 640 px (profiles/r03_convbench.txt, generic -> ROW3): 32->32 @160 138 -> 125 us, 256->256 @20
+// 93 -> 77 us, but 64->64 @80 92 -> 104 us and 128->128 @40 58 -> 75 us: a block that owns all nine taps has a 4.5x larger
+// output tile, so the same number of resident blocks writes 4.5x the split-K slab bytes (75 MB against 15-33 MB for
+// the two middle layers, whose whole operand traffic is 52-105 MB).  It pays where the slab is small against the
+// operands (N <= 32) or where the generic kernel's tile count leaves it few rows per block (Cin >= 256).
 struct Row3Cfg { bool on; int wn, rn, wc, tnb; };
 Row3Cfg row3_cfg(int N, int Cin, int KH, int KW, int SH, int SW, int PH, int PW) {
   static int mode = -1;
   if (mode < 0) { const char* e = getenv("KODHIP_WGRAD_ROW3"); mode = e ? atoi(e) : 1; }
   Row3Cfg c = {false, 0, 0, 0, 0};
   if (!mode || KH != 3 || KW != 3 || SH != 1 || SW != 1 || PH != 1 || PW != 1 || Cin % 32 != 0 || N % 8 != 0) return c;
+  if (mode == 1 && !(N <= 32 || Cin >= 256)) return c;
   c.on = true;
   if (N <= 32) { c.wn = 1; c.rn = 1; }
   else if (N <= 64) { c.wn = 1; c.rn = 2; }

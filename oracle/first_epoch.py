@@ -123,6 +123,7 @@ def main():
         res[f"map_{tag}"] = np.array([r["report"][k] for k in keys])
         samples.append(res[f"map_{tag}"])
     res["map_cpu_samples"] = np.stack(samples)           # [6 runs, 5 metrics]: five fp32 summation orders + the bf16 emulation
+    res["map_sample_tags"] = np.array(["fp32", "fp32_alt", "bf16emu", "fp32_t6", "fp32_t3", "fp32_t5"])      # (--extra appends)
     np.savez_compressed(out, config=np.array([repr(sorted(CONFIG.items()))]), map_keys=np.array(keys), **res)
     print(f"wrote {out}")
 

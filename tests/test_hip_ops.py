@@ -530,3 +530,18 @@ def test_conv3x3_result_independent_of_tile_position(case):
     assert torch.equal(torch.cat([y0, y1]), y), "forward: a pixel's result depends on its tile position"
     dx = dgrad(dyb)
     assert torch.equal(torch.cat([dgrad(dyb[:h].contiguous()), dgrad(dyb[h:].contiguous())]), dx), "dgrad: tile position"
+
+
+def test_wgrad_row3_form_on_every_eligible_layer():
+    """conv_wgrad_row3_kernel is selected only where it measured faster (N <= 32 or Cin >= 256); the other wave layouts stay
+    compiled and must stay right: the conv cases again, in a fresh process, with KODHIP_WGRAD_ROW3=2 (every eligible 3x3 /
+    stride-1 layer takes the ROW3 form).  (The kernel knobs are read once per process, hence the child process.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KODHIP_WGRAD_ROW3="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_ops.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_conv_fwd_dgrad_wgrad"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "passed" in r.stdout

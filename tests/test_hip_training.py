@@ -174,56 +174,75 @@ def test_first_epoch_map_vs_cpu_trainer(golden):
     The two trajectories decorrelate after a few hundred steps (chaos, not error), so the bars are epoch-level:
       * per-step total loss within 1e-2 rel over the first 5 steps, 5e-2 over the first 50;
       * mean total loss of each fifth of the epoch within 3e-2 rel;
-      * mAP / mAP30 / mAP50: first-epoch mAP is a NOISY statistic of a chaotic trajectory - the fixture holds six CPU
-        runs of this very epoch (fp32 under five different torch thread counts, i.e. summation orders, plus the
-        bf16-storage emulation); their mAP50 spans 0.064 .. 0.094 (mean 0.074, sigma 0.012).  The HIP value must lie
-        within mean +- 4 sigma of those CPU samples and above 40 % of their mean.  (Measured this round: HIP 0.044 ..
-        0.061 over three summation-order variants of the kernels, i.e. at the low end of the CPU spread; evaluating
-        the HIP-trained weights with the CPU oracle's eval pipeline gives the same mAP to 1e-4, so validation itself
-        is exact - DESIGN section 5.)"""
+      * mAP / mAP30 / mAP50: first-epoch mAP is a NOISY statistic of a chaotic trajectory.  The fixture holds TWELVE CPU
+        runs of this very epoch (seven fp32 runs under different torch thread counts = summation orders, five runs of the
+        bf16-storage emulation): mAP50 0.064 .. 0.094, mean 0.076, sigma 0.011.  The HIP trainer is run THREE times here,
+        under three summation orders of its own kernels (default; CSP main / short data gradients as two launches;
+        separate BatchNorm-backward reduce pass - EngineOptions, no other difference), and the MEAN of the three must lie
+        within mean +- 2 sigma of the CPU samples, every single run within +- 4 sigma.  (Round 3, 16 HIP epochs over
+        eight kernel variants x {bf16, fp32} accumulation of multi-producer activation gradients,
+        profiles/r03_first_epoch_samples.txt: HIP mean mAP50 0.072 vs CPU 0.076 - z = -1.0, no detectable deficit - and
+        fp32 accumulation changes nothing, 0.0722 vs 0.0724.  Evaluating HIP-trained weights with the CPU oracle's eval
+        pipeline reproduces the HIP mAP to 1e-4: validation itself is exact - DESIGN section 5.)"""
     from oracle import first_epoch as FE
     from object_detection_cib_amd.data.detection import DetectionTarget
+    from object_detection_cib_amd.engine.options import EngineOptions
     g = golden("first_epoch")
     cfg = FE.CONFIG
     assert repr(sorted(cfg.items())) == str(g["config"][0]), "fixture was generated with another CONFIG: regenerate"
     S, B, nc, seed = cfg["S"], cfg["B"], cfg["nc"], cfg["seed"]
     train = synth.coco_zipf_like(cfg["n_train"], S, cfg["data_seed"], nc)
     val = synth.coco_zipf_like(cfg["n_val"], S, cfg["data_seed"] + 1, nc)
-    pipe = DeviceTrainPipeline([c[0] for c in train], [c[1] for c in train], [c[2] for c in train], S, "cuda", rng_seed=51)
-    exp = _experiment(cfg["widen"], cfg["deepen"], nc, seed)
-    exp.val_nms_conf_threshold, exp.val_nms_iou_threshold = cfg["conf_thres"], cfg["nms_thres"]
     order = FE.epoch_order(cfg)
     n_batches = len(order) // B
-    random.seed(seed); np.random.seed(seed)
-    losses = []
-    for step in range(n_batches):
-        img, _, targets = pipe.make_batch([int(i) for i in order[step * B:(step + 1) * B]])
-        losses.append(exp.optimize((img, targets, None), n_batches).detach())
-    exp.end_epoch()
-    hip = torch.stack(losses).cpu().numpy().astype(np.float64)
-    cpu = g["losses_fp32"][:, 3]
-    assert np.isfinite(hip).all()
-    rel = np.abs(hip - cpu) / np.abs(cpu)
-    assert rel[:5].max() < 1e-2 and rel[:50].max() < 5e-2, (rel[:5], rel[:50].max())
-    fifth = n_batches // 5
-    for k in range(5):
-        a, b = hip[k * fifth:(k + 1) * fifth].mean(), cpu[k * fifth:(k + 1) * fifth].mean()
-        assert abs(a - b) <= 3e-2 * b, (k, a, b)
     vb = [(x.cuda(), tuple(DetectionTarget(torch.from_numpy(b), torch.from_numpy(l)) for b, l in tg), None)
           for x, tg in FE.validation_batches(cfg, val)]
-    rep = exp.validate(vb, nc)
+    cpu = g["losses_fp32"][:, 3]
     keys = [str(k) for k in g["map_keys"]]
-    samples = g["map_cpu_samples"]                          # [6 CPU runs, 5 metrics]
+    samples = g["map_cpu_samples"]                          # [12 CPU runs, 5 metrics]
+    assert samples.shape[0] >= 12
     mean, sd = samples.mean(0), samples.std(0, ddof=1)
-    print("first-epoch mAP  HIP:", {k: round(rep[k], 4) for k in keys},
-          " CPU samples mean:", {k: round(float(m), 4) for k, m in zip(keys, mean)},
-          " sigma:", {k: round(float(v), 4) for k, v in zip(keys, sd)},
-          " z:", {k: round(float((rep[k] - m) / v), 2) for k, m, v in zip(keys[:3], mean, sd)})
     assert mean[keys.index("map50")] > 0.03, "the fixture epoch must leave zero for the comparison to mean anything"
+
+    def hip_epoch(**switches):
+        pipe = DeviceTrainPipeline([c[0] for c in train], [c[1] for c in train], [c[2] for c in train], S, "cuda", rng_seed=51)
+        exp = _experiment(cfg["widen"], cfg["deepen"], nc, seed)
+        opts = EngineOptions.from_env()
+        for k, v in switches.items():
+            assert hasattr(opts, k)
+            setattr(opts, k, v)
+        exp.net.engine_options = opts
+        exp.val_nms_conf_threshold, exp.val_nms_iou_threshold = cfg["conf_thres"], cfg["nms_thres"]
+        random.seed(seed); np.random.seed(seed)
+        losses = []
+        for step in range(n_batches):
+            img, _, targets = pipe.make_batch([int(i) for i in order[step * B:(step + 1) * B]])
+            losses.append(exp.optimize((img, targets, None), n_batches).detach())
+        exp.end_epoch()
+        hip = torch.stack(losses).cpu().numpy().astype(np.float64)
+        assert np.isfinite(hip).all()
+        rel = np.abs(hip - cpu) / np.abs(cpu)
+        assert rel[:5].max() < 1e-2 and rel[:50].max() < 5e-2, (switches, rel[:5], rel[:50].max())
+        fifth = n_batches // 5
+        for k in range(5):
+            a, b = hip[k * fifth:(k + 1) * fifth].mean(), cpu[k * fifth:(k + 1) * fifth].mean()
+            assert abs(a - b) <= 3e-2 * b, (switches, k, a, b)
+        rep = exp.validate(vb, nc)
+        del exp, pipe
+        torch.cuda.empty_cache()
+        return np.array([rep[k] for k in keys])
+
+    runs = np.stack([hip_epoch(), hip_epoch(dual_dgrad=False), hip_epoch(bn_reduce_fused=False)])
+    hmean = runs.mean(0)
+    print("first-epoch mAP  HIP runs:", [{k: round(float(v), 4) for k, v in zip(keys[:3], r)} for r in runs],
+          " HIP mean:", {k: round(float(v), 4) for k, v in zip(keys[:3], hmean)},
+          " CPU samples mean:", {k: round(float(m), 4) for k, m in zip(keys[:3], mean)},
+          " sigma:", {k: round(float(v), 4) for k, v in zip(keys[:3], sd)},
+          " z of the HIP mean:", {k: round(float((h - m) / v), 2) for k, h, m, v in zip(keys[:3], hmean, mean, sd)})
     for k in ("map", "map30", "map50"):
         i = keys.index(k)
-        assert abs(rep[k] - mean[i]) <= 4 * sd[i], (k, rep[k], mean[i], sd[i])
-        assert rep[k] >= 0.4 * mean[i], (k, rep[k], mean[i])
+        assert abs(hmean[i] - mean[i]) <= 2 * sd[i], (k, hmean[i], mean[i], sd[i])
+        assert (np.abs(runs[:, i] - mean[i]) <= 4 * sd[i]).all(), (k, runs[:, i], mean[i], sd[i])
 
 
 def test_class_aware_mixup_reweighted_config_tracks_cpu_oracle():
