@@ -474,8 +474,9 @@ def main():
                                    f"batch {B}/GPU, fwd+assign+loss+bwd+SGD, targets 4-30 boxes/img",
                        "global_batch": world * B, "parallelism": f"dp{world}" + ("+syncbn" if use_dist and not args.no_sync_bn else ""),
                        "launch": launch_note,
-                       "collectives": ("none" if not use_dist else
-                                       "RCCL, native: SyncBN sums in stream order, gradient buckets "
+                       "collectives": ("none" if not (use_dist and eng.collectives) else
+                                       ("SyncBN sums over IPC peer buffers (in the BatchNorm kernels)" if eng.peer is not None else
+                                        "RCCL, native: SyncBN sums in stream order" if eng.sync_bn else "no SyncBN") + ", RCCL gradient buckets "
                                        + ("overlapped with backward on the weight-gradient stream (own communicator)"
                                           if eng.comm_buckets is not None else "in stream order")),
                        "launcher": os.environ.get("KODHIP_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none")},

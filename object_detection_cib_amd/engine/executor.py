@@ -868,7 +868,10 @@ class Engine:
                 # overlapped buckets use their own communicator: SyncBN sums (main stream) and buckets (side stream)
                 # never interleave on one communicator from two streams
                 bc = self.comm_buckets if (cs is not None and self.comm_buckets is not None) else self.comm
-                self._pending.append(launch_bucket(ga, lo, hi, self.process_group, cs, bc, also_after=wg))
+                # on the weight-gradient stream the bucket's last weight gradient has already waited for an event recorded
+                # behind every BatchNorm / bias gradient of the bucket (fork_point): no new edge from the main chain
+                self._pending.append(launch_bucket(ga, lo, hi, self.process_group, cs, bc, also_after=wg,
+                                                   wait_caller=not (cs is not None and cs is wg and defer)))
 
         def bn_bwd_stats(group):
             """BatchNorm-backward sums -> coefficients.  Under SyncBN the [sum dz, sum dz*xhat] vectors of the group's

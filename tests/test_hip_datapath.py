@@ -16,10 +16,14 @@ def _cache(n, S, seed):
     return synth.source_samples(n, S, seed)
 
 
-@pytest.mark.parametrize("S,mixup,seed", [(64, 0.0, 1), (64, 1.0, 2), (128, 0.5, 3), (96, 0.3, 4)])
+@pytest.mark.parametrize("S,mixup,seed", [(64, 0.0, 1), (64, 1.0, 2), (128, 0.5, 3), (96, 0.3, 4), (640, 0.5, 5), (640, 1.0, 6)])
 def test_batch_matches_oracle_protocol(S, mixup, seed):
+    """Default AugParams = the reference's training defaults: mosaic + random affine + HSV jitter + flip (+ mixup with the
+    given probability), all switched ON - also at the benchmark resolution (640 px: 1280 x 1280 mosaic canvases, B = 4)."""
     cache = _cache(12, S, seed)
-    idxs = [3, 0, 7, 11, 5, 2]
+    idxs = [3, 0, 7, 11, 5, 2] if S < 640 else [3, 0, 7, 11]
+    a = AugParams()
+    assert a.flip_lr_prob > 0 and a.hsv_params.hue > 0 and a.affine_params.scale > 0     # augmentation really is on
     random.seed(seed); np.random.seed(seed)
     rng = np.random.default_rng(51)
     ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup) for i in idxs]

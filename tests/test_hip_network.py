@@ -663,3 +663,68 @@ def test_batched_wgrad_reduction_equals_per_layer_reduction():
     assert torch.isfinite(got["layer"]).all() and got["layer"].abs().sum() > 0
     for tag in ("bucket8", "bucket1", "one"):
         assert torch.equal(got[tag], got["layer"]), tag
+
+
+def test_yv5m_bench_geometry_b64_640_deterministic_and_teacher_forced():
+    """BASELINE configs[4] at its per-GPU batch: yv5m (widen .75, deepen .67: 48 / 96 / 192 / 384 / 768 channels, 88 convs),
+    B=64, 640 px - the 256-pixel-tile / split-K / padded-tap geometry of those widths.  (1) two steps on the same batch give
+    bit-identical gradients; (2) the largest-M units of every width class plus a stride-2 stage conv and a 3x3 block conv
+    are checked teacher-forced (fp32 torch on the HIP path's own bf16 operands): raw conv output, BatchNorm batch
+    statistics, dW."""
+    import torch.nn.functional as F
+    widen, deepen, nc, B, size, seed = 0.75, 0.67, 10, 64, 640, 77
+    torch.manual_seed(seed)
+    net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen).cuda().train()
+    x = torch.rand(B, 3, size, size, generator=torch.Generator().manual_seed(seed))
+    tg = synth.targets(B, size, nc, seed, nmin=4, nmax=30)
+    xg = x.cuda()
+    runs = []
+    for _ in range(2):
+        for p in net.parameters():
+            p.grad = None
+        _, lr, tot = _step(net, xg, tg, size, B)
+        runs.append((tot.item(), torch.cat([p.grad.flatten() for p in net.parameters()]).clone()))
+    assert np.isfinite(runs[0][0]) and runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]), "gradients differ between two runs of the same step"
+    eng = net.engine()
+    grads = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    params = {k: p.detach().cpu() for k, p in net.named_parameters()}
+    bf = lambda t: t.to(torch.bfloat16).float()
+    by_m = sorted(eng.exec_units, key=lambda u: -eng.ustate[u.name].M)
+    units, seen = [], set()
+    for u in by_m:                                    # the largest-M unit of every (cin, cout, k, s) class, first five classes
+        key = (u.cin, u.cout, u.k, u.s)
+        if key not in seen and not u.stem:
+            seen.add(key)
+            units.append(u)
+        if len(units) == 5:
+            break
+    units += [u for u in eng.exec_units if u.name in ("backbone.stages.stage3.blocks.0", "backbone.stages.stage2.blocks.1.blocks.0.conv2")]
+    assert {u.cin for u in units} & {48, 96, 192}
+    worst, ref_y = {}, {}
+    for u in units:
+        st = eng.ustate[u.name]
+        X = eng.act[u.src.buf.name][..., u.src.coff:u.src.coff + u.src.C].float().permute(0, 3, 1, 2).cpu()
+        W = bf(params[u.name + ".0.weight"]).requires_grad_(True)
+        y = F.conv2d(X, W, None, u.s, u.p)
+        y.backward(st.raw.float().permute(0, 3, 1, 2).cpu())          # st.raw holds dY after backward
+        e = _rel(grads[u.name + ".0.weight"], W.grad)
+        worst["dW"] = max(worst.get("dW", 0.0), e)
+        assert e <= 5e-3, ("dW", u.name, e)
+        ref_y[u.name] = y.detach()
+    with torch.no_grad():
+        net.forward_raw(xg)             # train-mode forward again: st.raw = pre-BN output, st.aff = batch statistics
+    for u in units:
+        st = eng.ustate[u.name]
+        raw = st.raw.float().permute(0, 3, 1, 2).cpu()
+        e = _rel(raw, ref_y.pop(u.name))
+        worst["conv_raw"] = max(worst.get("conv_raw", 0.0), e)
+        assert e <= 4e-3, ("conv_raw", u.name, e)
+        C_ = u.cout
+        aff = st.aff.cpu().double()
+        r64 = raw.double()
+        mean, var = r64.mean((0, 2, 3)), r64.var((0, 2, 3), unbiased=False)
+        e_m = ((aff[2 * C_:3 * C_] - mean).abs().max() / (var.sqrt().max() + 1e-30)).item()
+        e_r = _rel(aff[3 * C_:4 * C_], 1.0 / torch.sqrt(var + 1e-3))
+        assert e_m <= 1e-4 and e_r <= 1e-4, ("bn stats", u.name, e_m, e_r)
+    print("yv5m B=64/640 teacher-forced worst:", {k: round(v, 6) for k, v in worst.items()}, [u.name for u in units])
