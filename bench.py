@@ -254,7 +254,7 @@ def self_launch(args) -> int:
     return 0
 
 
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def pmc_traffic(family, B, S):

@@ -116,3 +116,37 @@ def plan_f32_accumulation(writes: List[Write], buf_channels: Dict[str, int]) -> 
             else:
                 modes[w.key] = 2 if (later_overlap[i] or i == 0) else 3
     return F32Plan(modes, shadow, zero_first, unsupported)
+
+
+def plan_dual_dgrads(g: Graph) -> Dict[str, str]:
+    """{main_conv name: short_conv name} of every CSP layer whose two entry convs can share ONE data-gradient launch
+    (kodhip_conv_dgrad_dual): both pointwise, same input view, same output width (kod/nn/layers/csp.py:96-111)."""
+    out = {}
+    for op in g.ops:
+        if op.kind != "conv":
+            continue
+        u, v = op.unit, op.unit.sibling
+        if (v is not None and u.k == v.k == 1 and u.s == v.s == 1 and u.p == v.p == 0 and u.cout == v.cout
+                and (u.src.buf.name, u.src.coff, u.src.C) == (v.src.buf.name, v.src.coff, v.src.C) and u.cout % 8 == 0):
+            out[u.name] = v.name
+    return out
+
+
+def plan_bn_reduce_fusion(g: Graph, writes: List[Write], upos: Dict[str, int], max_segments: int = 3) -> Dict[str, List[Tuple[str, int]]]:
+    """For every conv unit U: the LAST write into U's output-gradient slice before U's own BatchNorm backward.  When that
+    write is a conv data gradient covering the whole slice, it can carry U's BatchNorm-backward reduction in its epilogue
+    (csrc/conv_igemm.hip MODE_PLAIN_BN).  Returns {writer unit name: [(producer unit name, channel offset of the
+    producer's slice inside the writer's output), ...]} (at most `max_segments` per writer: the kernel's MAX_SEG)."""
+    plan: Dict[str, List[Tuple[str, int]]] = {}
+    for op in g.ops:
+        if op.kind != "conv":
+            continue
+        u = op.unit
+        lo, hi = u.dst.coff, u.dst.coff + u.dst.C
+        cand = [w for w in writes if w.pos < upos[u.name] and w.buf == u.dst.buf.name and w.lo < hi and w.hi > lo]
+        if not cand:
+            continue
+        last = max(cand, key=lambda w: w.pos)
+        if last.unit is not None and last.lo <= lo and last.hi >= hi:
+            plan.setdefault(last.unit, []).append((u.name, lo - last.lo))
+    return {k: v[:max_segments] for k, v in plan.items()}
