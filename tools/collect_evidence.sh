@@ -9,7 +9,7 @@ O="$R/gpurun_out/ev_$tag"; rm -rf "$O"; mkdir -p "$O"
 cd "$R" && timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err" || { echo "bench failed"; tail -5 "$O/bench.err"; exit 1; }
 tail -1 "$O/bench.json" | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o t -- python3 "$R/bench.py" --steps 5 --warmup 3 --no-cpu-baseline > "$O/trace.json" 2> "$O/trace.err" || { echo "trace failed"; tail -5 "$O/trace.err"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o t -- python3 "$R/bench.py" --steps 5 --warmup 3 --no-cpu-baseline --no-loop > "$O/trace.json" 2> "$O/trace.err" || { echo "trace failed"; tail -5 "$O/trace.err"; exit 1; }
 echo "trace ok"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/pmc_$c" -o p -- python3 "$R/bench.py" --no-graph --steps 2 --warmup 1 --no-cpu-baseline > "$O/pmc_$c.json" 2> "$O/pmc_$c.err" || { echo "pmc $c failed"; tail -5 "$O/pmc_$c.err"; exit 1; }
