@@ -106,7 +106,14 @@ __device__ __forceinline__ void wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0
 // zero-filling buffer load did per tap for the left / right image border becomes a per-lane mask on the pixel
 // fragments of taps 0 and 2.  Per unit of MFMA work the L2 -> LDS fill drops by 30-50 % (these layers are bound by it)
 // and there is one barrier per three taps.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST, bool ROW3 = false, bool F32ACC = false>
+// STEM (FAST, the 6x6 / stride 2 / pad 2 stem in its wide-pixel form: 8-channel pixel PAIRS, a K step = one kernel row =
+// four consecutive pairs, the fourth with zero weights): the generic form stages 4 pairs (64 B) per output pixel and
+// kernel row although neighbouring output pixels share three of them; here a K step stages ONE run of BM + 3 pairs (16-byte
+// rows; output pixel i, tap j reads staged row i + j) - a quarter of the L2 -> LDS fill of a layer that is bound by it.
+// Rows are taken in flattened (b, oy, ox) order with each staged row addressed by its own pixel, so tiles may cross image
+// rows; the taps that would then read the neighbouring image row's pairs (j = 0 at ox = 0, j = 2 at ox = Wo - 1) are
+// zero-padding and masked on the fragments, as in ROW3.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE, bool FAST, bool ROW3 = false, bool F32ACC = false, bool STEM = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int NW = NT / 64;
@@ -122,7 +129,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   constexpr int B_PER_THREAD = (B_CHUNKS + NT - 1) / NT;
   static_assert(!ROW3 || (FAST && BM == 128), "ROW3 is a FAST-path form for 128-pixel tiles");
   constexpr int A3_ROWS = BM + 16;                   // ROW3: staged source rows (BM + 2 used)
-  constexpr int STAGE_ELEMS = ROW3 ? (A3_ROWS + 3 * BN) * LDS_ROW : (BM + BN) * LDS_ROW;
+  static_assert(!STEM || (FAST && BM == 128 && !ROW3 && MODE == MODE_RAW), "STEM is a forward FAST-path form for 128-pixel tiles");
+  constexpr int AS_ROWS = BM + 64;                   // STEM: staged 16-byte pair rows (BM + 3 used): 3 DMA instructions
+  constexpr int STAGE_ELEMS = STEM ? AS_ROWS * 8 + BN * LDS_ROW : (ROW3 ? (A3_ROWS + 3 * BN) * LDS_ROW : (BM + BN) * LDS_ROW);
   constexpr int CS_ROW = BN + 8;            // epilogue staging row (bf16)
   // LDS stages.  The fill of the wide tiles is latency-bound - a CU moves (bytes in flight) / (L2-or-HBM latency) -
   // so 256-row tiles (2 blocks per CU) run a 3-stage ring; 128-row tiles keep 2 stages and 4 blocks per CU (a third
@@ -158,7 +167,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
   float bn_run = 0.f;                        // MODE_PLAIN_BN: running sum of (channel tid>>1, statistic tid&1)
 
-  const int nk = ROW3 ? 3 * (a.cin_step / BK) : (a.nk1 ? 2 * a.nk1 : a.Kp / BK);
+  const int nk = STEM ? a.KH : (ROW3 ? 3 * (a.cin_step / BK) : (a.nk1 ? 2 * a.nk1 : a.Kp / BK));
   // FAST path (Cin % 32 == 0, unit tap stride, no K tail): operands come through raw buffer loads - the tap of a
   // K step is wave-uniform (scalar registers), invalid (padding) elements are fetched from an out-of-range offset
   // that the buffer unit returns as zeros, so a step costs ~10 VALU instead of ~110 and has no branches.
@@ -218,7 +227,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     int f_tap = 0, f_kh = 0, f_kw = 0, f_ci = 0;      // wave-uniform K-step state
     if constexpr (FAST) {
 #pragma unroll
-      for (int i = 0; i < (ROW3 ? 0 : A_PER_WAVE); ++i) {
+      for (int i = 0; i < ((ROW3 || STEM) ? 0 : A_PER_WAVE); ++i) {
         int row = (uwave * A_PER_WAVE + i) * 16 + (lane >> 2);
         int m = m0 + row;
         bool valid = m < a.M;
@@ -345,6 +354,65 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #endif
       f_ci += BK;
       if (f_ci >= a.cin_step) { f_ci = 0; ++f_kh; }
+    };
+
+
+    // ---- STEM staging state (see the header comment of this function)
+    constexpr int AS_INSTR = AS_ROWS / 64;
+    constexpr int AS_PW = (AS_INSTR + NW - 1) / NW;
+    uint32_t as_voff[STEM ? AS_PW : 1], as_mask[STEM ? AS_PW : 1];
+    if constexpr (STEM) {
+#pragma unroll
+      for (int i = 0; i < AS_PW; ++i) {
+        const int blk = uwave + i * NW;               // DMA instruction = 64 staged rows of 16 B
+        const int r = blk * 64 + lane;
+        const long q = (long)m0 - 1 + r;              // output pixel whose CENTRE pair (tap j = 1) this row is
+        const bool valid = blk < AS_INSTR && r < BM + 3 && q >= 0 && q < a.M;
+        const int qq = valid ? (int)q : 0;
+        int b, rem, oy, ox;
+        fast_divmod(qq, HWo, a.rcp_hwo, b, rem);
+        fast_divmod(rem, a.Wo, a.rcp_wo, oy, ox);
+        const int by = oy * a.mul_h + a.add_h;
+        as_voff[i] = (uint32_t)(((long)(b * a.Hs + by) * a.Ws + ox) * a.ldx * 2);
+        uint32_t mk = 0;
+        for (int kh = 0; kh < a.KH; ++kh)
+          if ((unsigned)(by + kh) < (unsigned)a.Hs) mk |= 1u << kh;
+        as_mask[i] = valid ? mk : 0u;
+      }
+#pragma unroll
+      for (int jj = 0; jj < TM; ++jj) {
+        const int p = m0 + wm * WM + jj * 32 + (lane & 31);
+        int b, rem, oy, ox;
+        fast_divmod(p < a.M ? p : 0, HWo, a.rcp_hwo, b, rem);
+        fast_divmod(rem, a.Wo, a.rcp_wo, oy, ox);
+        xmask |= (ox != 0 ? 1u : 0u) << (2 * jj) | (ox != a.Wo - 1 ? 1u : 0u) << (2 * jj + 1);
+      }
+    }
+    auto dma_tileS = [&](int buf) {
+      // step state: f_kh = kernel row
+      const uint32_t soff = (uint32_t)(f_kh * a.Ws * a.ldx * 2);
+      char* As = reinterpret_cast<char*>(lds + buf * STAGE_ELEMS);
+      char* Bs = As + AS_ROWS * 16;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KOD_ABL_NODMA)
+#pragma unroll
+      for (int i = 0; i < AS_PW; ++i) {
+        const int blk = uwave + i * NW;
+        if (blk < AS_INSTR) {
+          const uint32_t vo = ((as_mask[i] >> f_kh) & 1u) ? as_voff[i] + soff : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(As + blk * 1024), 16, vo, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < B_PER_WAVE; ++q) {
+        const int blk = uwave * B_PER_WAVE + q;
+        if (blk < B_INSTR)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Bs + blk * 16 * 64),
+                                                   16, dbvoff[q], f_kh * (BK * 2), 0, 0);
+      }
+#else
+      (void)soff; (void)As; (void)Bs;
+#endif
+      ++f_kh;
     };
 
     u32x4 areg[2];
@@ -490,7 +558,44 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       }
     };
 
-    if constexpr (ROW3) {
+    auto computeS = [&](int stage) {
+      const bf16_t* As = lds + stage * STAGE_ELEMS;
+      const bf16_t* Bs = As + AS_ROWS * 8;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 wf[TN], xf[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int row = wn * WN + i * 32 + fr;
+          const int ch = (ks * 2 + fh) ^ ((row >> 2) & 3);
+          wf[i] = *reinterpret_cast<const bf16x8*>(Bs + row * LDS_ROW + ch * 8);
+        }
+#pragma unroll
+        for (int jj = 0; jj < TM; ++jj) {
+          // tap j = ks * 2 + fh of output pixel (local) i reads staged pair row i + j
+          bf16x8 v = *reinterpret_cast<const bf16x8*>(As + (wm * WM + jj * 32 + fr + ks * 2 + fh) * 8);
+          if (ks == 0 && fh == 0 && !((xmask >> (2 * jj)) & 1u)) v = bf16x8{};
+          if (ks == 1 && fh == 0 && !((xmask >> (2 * jj + 1)) & 1u)) v = bf16x8{};
+          xf[jj] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int jj = 0; jj < TM; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[jj], acc[i][jj], 0, 0, 0);
+      }
+    };
+
+    if constexpr (STEM) {
+      dma_tileS(0);
+      for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) dma_tileS((kt + 1) & 1);
+        computeS(kt & 1);
+      }
+      __syncthreads();
+    } else if constexpr (ROW3) {
       dma_tile3(0);
       for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -833,6 +938,185 @@ void conv_igemm_row3_kernel(ConvArgs a) {
   conv_igemm_body<128, BN, WAVES_M, WAVES_N, MODE, true, true, F32ACC>(a, blockIdx.x);
 }
 
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4)
+void conv_igemm_stem_kernel(ConvArgs a) {
+  conv_igemm_body<128, BN, WAVES_M, WAVES_N, MODE_RAW, true, false, false, true>(a, blockIdx.x);
+}
+
+// ---- the stem as its own kernel: weights resident, whole-tile double buffering -------------------------------------
+// conv_igemm_body<STEM> cut the stem's fill to a quarter but still ran one barrier + one DMA round trip per kernel row
+// (two MFMAs per wave between them): 290 us for a layer whose traffic is 0.52 GB.  Here the block keeps ALL weights of the
+// stem in LDS for its lifetime (6 kernel rows x 32 channels x 32 k = 12 KB), stages the six pair-row runs of a WHOLE
+// 128-pixel tile at once (6 x 3 KB) and does so for tile t + 1 while tile t is multiplied and stored: one counted wait
+// per tile, DMA latency behind a full tile of work.  Measured at B = 64 / 640 px: generic per-tap staging 355 us, row-shared
+// staging in the generic body 290 us, this kernel 240 us (0.52 GB of traffic: 2.2 TB/s; what is left is the prefetch depth
+// of one tile per block, three blocks per CU).  N <= 32.
+__global__ __launch_bounds__(256, 3) void conv_stem_fwd_kernel(ConvArgs a) {
+  constexpr int BM = 128, BN = 32, NWV = 4;
+  constexpr int PR = 192;                              // staged pair rows per kernel row (BM + 3 used)
+  constexpr int KHM = 6;
+  constexpr int W_BYTES = KHM * BN * 64;               // 12 KB
+  constexpr int P_BYTES = KHM * PR * 16;               // 18 KB per tile
+  constexpr int CS_ROW = BN + 8;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[W_BYTES + 2 * P_BYTES];
+  float* sred = reinterpret_cast<float*>(lds + W_BYTES);      // reused after the tile loop
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int HWo = a.Ho * a.Wo;
+  const int grid = gridDim.x, blk = blockIdx.x;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+#endif
+  // ---- weights, once: instruction t = wave + 4 i (12 of 1 KB): kernel row t / 2, rows 16 (t & 1) .. + 16
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int t = wave + NWV * i;
+    const int kh = t >> 1, row = (t & 1) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    const uint32_t vo = row < a.N ? (uint32_t)(((size_t)row * a.Kp + kh * 32 + chunk * 8) * 2) : 0xFFFFFFF0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(lds + t * 1024), 16, vo, 0, 0, 0);
+#else
+    (void)vo;
+#endif
+  }
+  // ---- pixel rows of one tile: instruction t = wave + 4 i (18 of 1 KB): kernel row t / 3, rows 64 (t % 3) .. + 64
+  auto stage_tile = [&](int mt, int buf) {
+    const int m0 = mt * BM;
+    unsigned char* P = lds + W_BYTES + buf * P_BYTES;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int t = wave + NWV * i;
+      if (t >= 18) continue;
+      const int kh = t / 3, part = t - kh * 3;
+      const int r = part * 64 + lane;
+      const long q = (long)m0 - 1 + r;               // output pixel whose centre pair this row is
+      bool ok = r < BM + 3 && q >= 0 && q < a.M;
+      int b, rem, oy, ox;
+      fast_divmod(ok ? (int)q : 0, HWo, a.rcp_hwo, b, rem);
+      fast_divmod(rem, a.Wo, a.rcp_wo, oy, ox);
+      const int iy = oy * a.mul_h + a.add_h + kh;
+      ok = ok && (unsigned)iy < (unsigned)a.Hs;
+      const uint32_t vo = ok ? (uint32_t)(((long)(b * a.Hs + iy) * a.Ws + ox) * 16) : 0xFFFFFFF0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(P + t * 1024), 16, vo, 0, 0, 0);
+#else
+      (void)vo; (void)P;
+#endif
+    }
+  };
+
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+
+  const int my_p = wave < 2 ? 5 : 4;                   // this wave's share of a tile's 18 DMA instructions
+  int buf = 0;
+  if (blk < a.tiles_m) stage_tile(blk, 0);
+  for (int mt = blk; mt < a.tiles_m; mt += grid) {
+    const int m0 = mt * BM;
+    const bool more = mt + grid < a.tiles_m;
+    if (more) stage_tile(mt + grid, buf ^ 1);
+    // everything but the next tile's instructions of this wave must have landed (the weights too, first time round).  The
+    // previous tile's stores may still be outstanding and may retire in any order relative to the loads - that only makes
+    // the wait longer: DMA loads retire in order among themselves, so the count cannot fall to my_p while one of this
+    // tile's loads is pending
+    if (more) { if (my_p == 5) wait_vm_imm<5>(); else wait_vm_imm<4>(); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // this lane's output pixel: taps that would read the neighbouring image row's pairs are zero padding
+    int pb, prem, poy, pox;
+    const int pm = m0 + wave * 32 + fr;
+    fast_divmod(pm < a.M ? pm : 0, HWo, a.rcp_hwo, pb, prem);
+    fast_divmod(prem, a.Wo, a.rcp_wo, poy, pox);
+    const bool ok0 = pox != 0, ok2 = pox != a.Wo - 1;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const bf16_t* Wl = reinterpret_cast<const bf16_t*>(lds);
+    const bf16_t* Pl = reinterpret_cast<const bf16_t*>(lds + W_BYTES + buf * P_BYTES);
+#pragma unroll
+    for (int kh = 0; kh < KHM; ++kh)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = (ks * 2 + fh) ^ ((fr >> 2) & 3);
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wl + (kh * BN + fr) * 32 + ch * 8);
+        bf16x8 xf = *reinterpret_cast<const bf16x8*>(Pl + (kh * PR + wave * 32 + fr + ks * 2 + fh) * 8);
+        if (ks == 0 && fh == 0 && !ok0) xf = bf16x8{};
+        if (ks == 1 && fh == 0 && !ok2) xf = bf16x8{};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
+      }
+    __builtin_amdgcn_s_barrier();                      // every wave has read this tile's rows: its buffer becomes the store staging
+
+    // ---- epilogue: acc[e]: pixel fr of this wave, channel 8 (e >> 2) + 4 fh + (e & 3); through LDS so that the tile leaves
+    //      as 16-byte channel-contiguous stores (measured: 240 us; 8-byte stores straight from the accumulators, one barrier
+    //      per tile, statistics kept per lane: 257 us)
+    bf16_t* Cs = reinterpret_cast<bf16_t*>(lds + W_BYTES + buf * P_BYTES);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16_t)acc[g * 4 + e];
+      *reinterpret_cast<bf16x4*>(Cs + (wave * 32 + fr) * CS_ROW + 8 * g + 4 * fh) = v;
+    }
+    __syncthreads();
+    const int c = tid & 3, r0 = tid >> 2;
+    const bool col_ok = c * 8 < a.N;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = r0 + p * 64;
+      const int m = m0 + row;
+      if (m < a.M && col_ok) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS_ROW + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          ssum[e] += f;
+          ssq[e] += f * f;
+        }
+        *reinterpret_cast<bf16x8*>(a.y + (size_t)m * a.ldy + a.ycoff + c * 8) = v;
+      }
+    }
+    __syncthreads();                                   // the next iteration's DMA overwrites this buffer
+    buf ^= 1;
+  }
+
+  // ---- BatchNorm partial statistics of this block: rows by shuffle, waves by the owner thread (fixed order)
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ssum[e] += __shfl_xor(ssum[e], o, 64);
+      ssq[e] += __shfl_xor(ssq[e], o, 64);
+    }
+  if (lane < 4) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sred[(wave * BN + lane * 8 + e) * 2 + 0] = ssum[e];
+      sred[(wave * BN + lane * 8 + e) * 2 + 1] = ssq[e];
+    }
+  }
+  __syncthreads();
+  if (tid < BN * 2) {
+    const int ch = tid >> 1, st = tid & 1;
+    float sacc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) sacc += sred[(w * BN + ch) * 2 + st];
+    if (ch < a.N) {
+      float* slot = a.stats + ((size_t)st * a.N + ch) * a.stats_slots;
+      slot[blk] = sacc;
+      for (int t = blk + grid; t < a.stats_slots; t += grid) slot[t] = 0.f;     // slots this launch does not use
+    }
+  }
+}
+
 // Four problems of identical tiling in one launch (the parity classes of a stride-2 dgrad).  The classes have 4, 2, 2
 // and 1 taps - reductions of very different length - and the launch is a few rounds of resident blocks at most, so
 // blocks are dispatched longest class first (class 3, then 1 and 2, then 0): a long block never starts in the last
@@ -946,6 +1230,25 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     args.slot_base = 0; args.slot_used = need;
   }
   dim3 g(p.grid);
+  if constexpr (MODE == MODE_RAW) {
+    // the stem's wide-pixel form (KODHIP_STEM_ROW=0: the generic per-tap staging, for A/B)
+    static const bool stem_row = !(getenv("KODHIP_STEM_ROW") && getenv("KODHIP_STEM_ROW")[0] == '0');
+    if (stem_row && fast && !row3 && a.wide_px == 4 && a.KW == 1 && a.mul_w == 1 && a.add_w == -1 && a.ldx == 8 && a.xcoff == 0 &&
+        p.bm == 128 && (p.bn == 32 || p.bn == 64) && (long)a.M + 256 < (1l << 31)) {
+      // KODHIP_STEM_ROW: 1 = row-shared staging inside the generic body, default = the dedicated kernel (N <= 32)
+      if (p.bn == 32 && a.N <= 32 && a.KH == 6 && a.ycoff % 8 == 0 && !(getenv("KODHIP_STEM_ROW") && getenv("KODHIP_STEM_ROW")[0] == '1')) {
+        int blocks = p.tiles_m < 768 ? p.tiles_m : 768;             // 3 resident blocks per CU (48 KB of LDS each)
+        if (blocks > a.stats_slots) blocks = a.stats_slots;
+        hipLaunchKernelGGL(conv_stem_fwd_kernel, dim3(blocks), dim3(256), 0, stream, args);
+        KOD_LAUNCH_CHECK("conv_stem_fwd");
+        return KOD_OK;
+      }
+      if (p.bn == 32) hipLaunchKernelGGL((conv_igemm_stem_kernel<32, 4, 1>), g, dim3(256), 0, stream, args);
+      else hipLaunchKernelGGL((conv_igemm_stem_kernel<64, 2, 2>), g, dim3(256), 0, stream, args);
+      KOD_LAUNCH_CHECK("conv_igemm_stem");
+      return KOD_OK;
+    }
+  }
   if constexpr (MODE != MODE_HEAD) {
     if (row3) {
       if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_row3_kernel<128, 2, 2, MODE, F32ACC>), g, dim3(256), 0, stream, args);
