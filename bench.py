@@ -448,6 +448,8 @@ def main():
     torch.cuda.synchronize()
     prof = eng.profile
     eng.profile, eng.wgrad_overlap = None, ov
+    if eng.peer is not None and eng.peer.timed_out():
+        raise SystemExit(f"[bench rank {rank}] a SyncBN peer exchange gave up waiting for another rank: the run is invalid")
     per_rank = [round(B * args.steps / dt, 1)]
     if dist is not None:
         dts = [None] * world

@@ -294,6 +294,7 @@ typedef struct KodPeerView {                       /* passed BY VALUE to the *_p
   int world, rank;
   const unsigned int* seq;
   int* timeout_flag;
+  long max_spins;                                  /* polls before a wait gives up and raises the flag */
 } KodPeerView;
 int kodhip_peer_create(void** peer, int rank, int world, long granules /* 8-byte granules: 4 per channel per exchange site */);
 int kodhip_peer_export(void* peer, void* handle64 /* host, 64 bytes out: hipIpcMemHandle_t */);

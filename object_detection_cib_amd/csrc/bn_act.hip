@@ -29,7 +29,7 @@ __device__ __forceinline__ double wave_sum_partials(const float* p, int T, int l
 // own exchange buffer, then poll the same four granules of EVERY rank (lane = 4 * rank + granule) and add the ranks'
 // values in rank order - every rank gets bit-identical totals.  Publishing precedes polling in every wave and waves
 // do not depend on each other, so ranks can arrive in any order; a poll that never sees its tag gives up after
-// ~seconds and raises the timeout flag instead of hanging the GPU.
+// max_spins polls (about a minute) and raises the timeout flag instead of hanging the GPU.
 __device__ __forceinline__ void peer_allreduce2(const KodPeerView& pv, unsigned int slot, int idx0, int idx1, int lane,
                                                 double& s0, double& s1) {
   const unsigned int seq = *pv.seq;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void peer_allreduce2(const KodPeerView& pv, unsigned 
       v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if ((unsigned int)(v >> 32) == seq) break;
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1l << 24)) { *pv.timeout_flag = 1; break; }        // ~seconds: a peer is gone
+      if (++spins > pv.max_spins) { *pv.timeout_flag = 1; break; }          // a peer is gone
     }
     got = (unsigned int)v;
   }

@@ -189,7 +189,7 @@ __global__ void peer_allreduce_f64_kernel(const double* in, double* out, int n, 
       v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if ((unsigned int)(v >> 32) == seq) break;
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1l << 24)) { *pv.timeout_flag = 1; break; }
+      if (++spins > pv.max_spins) { *pv.timeout_flag = 1; break; }
     }
     got = (unsigned int)v;
   }
@@ -269,6 +269,7 @@ int kodhip_peer_connect(void* peer, const void* handles) {
   c->view.world = c->world; c->view.rank = c->rank;
   c->view.seq = (const unsigned int*)c->local;
   c->view.timeout_flag = (int*)(c->local + 64);
+  c->view.max_spins = 1l << 26;              // inside a training step: about a minute
   return KOD_OK;
 }
 
@@ -299,7 +300,9 @@ int kodhip_peer_allreduce_f64(void* peer, const double* in, double* out, int n, 
   PeerComm* c = (PeerComm*)peer;
   KOD_CHECK_ARG((long)slot + 2l * n <= c->granules, "peer_allreduce_f64: slot range beyond the exchange buffer");
   const int pairs = (n + 1) / 2;
-  hipLaunchKernelGGL(peer_allreduce_f64_kernel, dim3(cdiv(pairs, 4)), dim3(256), 0, stream, in, out, n, c->view, slot);
+  KodPeerView v = c->view;
+  v.max_spins = 1l << 22;                    // the transport alone (self-test): a few seconds
+  hipLaunchKernelGGL(peer_allreduce_f64_kernel, dim3(cdiv(pairs, 4)), dim3(256), 0, stream, in, out, n, v, slot);
   KOD_LAUNCH_CHECK("peer_allreduce_f64");
   return KOD_OK;
 }

@@ -60,6 +60,8 @@ struct KodPeerView {
   int world, rank;
   const unsigned int* seq;                   // device: sequence number of the current step (kodhip_peer_step_begin)
   int* timeout_flag;                         // device: set when a poll gave up (a peer never published)
+  long max_spins;                            // polls before giving up: ~a minute inside a training step (ranks may reach their
+                                             // first exchange seconds apart), seconds in the start-up self-test
 };
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

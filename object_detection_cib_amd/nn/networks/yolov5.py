@@ -170,20 +170,15 @@ class Yolov5Network(nn.Module):
                     slots[(u.name, d)] = off
                     off += 4 * u.cout
             try:
-                peer = PeerExchange(process_group, eng.device, max(off, 4096))
-                if peer.selftest():
+                peer = PeerExchange(process_group, eng.device, max(off, 4096))       # (raises on every rank or on none)
+            except RuntimeError as e:          # no IPC between these processes (e.g. HSA_ENABLE_IPC_MODE_LEGACY unset)
+                peer, why = None, str(e)
+            if peer is not None:
+                if peer.selftest():            # (one verdict for the whole job: the flags are gathered inside)
                     eng.peer, eng.peer_slots = peer, slots
                 else:
                     peer.close()
                     why = "the transport self-test failed"
-            except RuntimeError as e:          # no IPC between these processes (e.g. HSA_ENABLE_IPC_MODE_LEGACY unset)
-                why = f"set-up failed: {e}"
-            # one decision for the whole job
-            oks = [None] * eng.world_size
-            dist.all_gather_object(oks, eng.peer is not None, group=process_group)
-            if not all(oks) and eng.peer is not None:
-                eng.peer.close()
-                eng.peer, why = None, "another rank could not set it up"
         if eng.peer is None:
             if strict:
                 raise RuntimeError(f"KODHIP_SYNCBN=peer: {why}")
