@@ -326,6 +326,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP hot path has no CPU fallback)")
+    # KODHIP_BENCH_ONE_GPU=1: every rank on GPU 0 (rehearsal of the multi-rank control flow on a one-GPU box: RCCL wants one
+    # GPU per rank, so gradient buckets then go through the gloo group and the step runs eagerly; SyncBN still takes the
+    # peer-buffer exchange, the ranks being processes of one node)
+    one_gpu = os.environ.get("KODHIP_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
@@ -356,7 +362,7 @@ def main():
         assert abs(algo_bytes - ALGO_BYTES_PER_IMG_BF16) < 1e-3 * ALGO_BYTES_PER_IMG_BF16 and abs(algo_flop - ALGO_FLOP_PER_IMG) < 1e-3 * ALGO_FLOP_PER_IMG
     eng = net.engine()
     if use_dist:
-        net.configure_distributed(None, sync_batchnorm=not args.no_sync_bn, native_rccl=True)
+        net.configure_distributed(None, sync_batchnorm=not args.no_sync_bn, native_rccl=not one_gpu)
     from object_detection_cib_amd.core.types import FeatureShape
     x, targets = synth_batch(B, S, nc, 2023 + rank, device)
     shape = FeatureShape(width=S, height=S)
@@ -387,7 +393,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and not (one_gpu and use_dist)      # (gloo collectives cannot be captured)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -478,7 +484,8 @@ def main():
                        "launch": launch_note,
                        "collectives": ("none" if not (use_dist and eng.collectives) else
                                        ("SyncBN sums over IPC peer buffers (in the BatchNorm kernels)" if eng.peer is not None else
-                                        "RCCL, native: SyncBN sums in stream order" if eng.sync_bn else "no SyncBN") + ", RCCL gradient buckets "
+                                        "RCCL, native: SyncBN sums in stream order" if eng.sync_bn else "no SyncBN")
+                                       + (", RCCL gradient buckets " if eng.comm is not None else ", gradient buckets through torch.distributed ")
                                        + ("overlapped with backward on the weight-gradient stream (own communicator)"
                                           if eng.comm_buckets is not None else "in stream order")),
                        "launcher": os.environ.get("KODHIP_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none")},

@@ -4,6 +4,8 @@ SyncBN + bucketed gradient all-reduce must reproduce the single-process step on 
 import os
 import socket
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -233,3 +235,29 @@ def test_bench_self_launch_runs_the_collective_path():
     assert "RCCL" in cfg["collectives"] and "overlapped with backward" in cfg["collectives"], cfg
     assert d["engine_options"]["comm_overlap"] is True and d["engine_options"]["force_collectives"] is True
     assert abs(sum(f["share_of_step"] for f in d["families"]) - 1.0) < 0.02
+
+
+def test_bench_two_ranks_on_one_gpu_control_flow():
+    """`python bench.py --gpus 2` end to end on the one GPU of the test box (KODHIP_BENCH_ONE_GPU=1): the parent starts two
+    fresh ranks, they rendezvous, map each other's SyncBN exchange buffer through HIP IPC, train with bucketed gradient
+    all-reduces (through the gloo group here: RCCL wants one GPU per rank) and rank 0 reports ONE line for the job with
+    both ranks' rates.  What an 8-GPU run adds to this is RCCL and xGMI, not control flow."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["KODHIP_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--batch", "4", "--size", "256", "--no-cpu-baseline", "--timeout", "400"],
+                       capture_output=True, text=True, timeout=500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and len(d["per_rank_images_per_sec"]) == 2
+    assert d["config"]["launcher"] == "self" and d["config"]["parallelism"] == "dp2+syncbn"
+    assert "IPC peer buffers" in d["config"]["collectives"], d["config"]
+    assert d["engine_options"]["syncbn_exchange"] == "peer"
+    assert abs(d["value"] - 2 * 4 * 3 / (3 * d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]      # whole-job rate over both ranks
+    assert np.isfinite(d["final_loss"])
