@@ -13,7 +13,7 @@ EV = os.path.join(ROOT, "gpurun_out", f"ev_{tag}")
 PR = os.path.join(ROOT, "profiles")
 
 FAMILIES = {   # name -> regex on the demangled kernel name
-    "conv_fwd": r"conv_igemm_kernel<\d+, \d+, \d+, \d+, 0, |conv_igemm_row3_kernel<\d+, \d+, \d+, 0[,>]",
+    "conv_fwd": r"conv_igemm_kernel<\d+, \d+, \d+, \d+, 0, |conv_igemm_row3_kernel<\d+, \d+, \d+, 0[,>]|conv_stem_fwd_kernel|conv_igemm_stem_kernel",
     "dgrad": r"conv_igemm(_x4)?_kernel<\d+, \d+, \d+, \d+, 1, |conv_igemm_row3_kernel<\d+, \d+, \d+, 1[,>]",
     "dgrad+bn_reduce": r"conv_igemm(_x4)?_kernel<\d+, \d+, \d+, \d+, 3, |conv_igemm_row3_kernel<\d+, \d+, \d+, 3[,>]",
     "wgrad": r"conv_wgrad(_dma|_row3)?_kernel<",
