@@ -113,6 +113,10 @@ __global__ void bn_finalize_fused_kernel(const float* part, int T, double count,
   int lane = threadIdx.x & 63;
   const float* p0 = part + (size_t)c * T;
   const float* p1 = part + (size_t)(C + c) * T;
+  // the per-channel parameters are loaded up front: behind the reduction they would be a second, dependent memory round
+  // trip in a kernel that is nothing but latency (one wave per channel, 57 launches on the critical chain)
+  const float g = gamma[c], b = beta[c];
+  const float rm0 = update_running ? running_mean[c] : 0.f, rv0 = update_running ? running_var[c] : 0.f;
   double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
   if constexpr (PEER) peer_allreduce2(pv, slot, c, C + c, lane, s0, s1);
   if (lane != 0) return;
@@ -120,15 +124,15 @@ __global__ void bn_finalize_fused_kernel(const float* part, int T, double count,
   double var = s1 / count - mean * mean;
   if (var < 0.0) var = 0.0;
   float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  float sc = gamma[c] * rstd;
+  float sc = g * rstd;
   scale[c] = sc;
-  shift[c] = beta[c] - (float)mean * sc;
+  shift[c] = b - (float)mean * sc;
   mean_out[c] = (float)mean;
   rstd_out[c] = rstd;
   if (update_running) {
     double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    running_mean[c] = (1.f - momentum) * rm0 + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * rv0 + momentum * (float)unbiased;
   }
 }
 
@@ -141,15 +145,16 @@ __device__ __forceinline__ void bn_bwd_coeffs_channel(const float* part, int T, 
                                                       const KodPeerView* pv = nullptr, unsigned int slot = 0) {
   const float* p0 = part + (size_t)c * T;
   const float* p1 = part + (size_t)(C + c) * T;
+  const float g_ = gamma[c], rs_ = rstd[c], mu_ = mean[c];      // up front: not a second round trip behind the reduction
   double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
-  if (raw_moment) s1 = (double)rstd[c] * (s1 - (double)mean[c] * s0);      // (linear in the sums: ranks may add converted values)
+  if (raw_moment) s1 = (double)rs_ * (s1 - (double)mu_ * s0);      // (linear in the sums: ranks may add converted values)
   if (lane == 0) {          // parameter gradients keep the rank's own sums (the gradient all-reduce adds the ranks later)
     dbeta[c] = (float)s0;
     dgamma[c] = (float)s1;
   }
   if constexpr (PEER) peer_allreduce2(*pv, slot, c, C + c, lane, s0, s1);   // dX uses the sums over ALL ranks' pixels
   if (lane != 0) return;
-  double g = gamma[c], rs = rstd[c], mu = mean[c];
+  double g = g_, rs = rs_, mu = mu_;
   double S0 = s0 / count, S1 = s1 / count;
   coef[c] = (float)(g * rs);
   coef[C + c] = (float)(-g * rs * rs * S1);
