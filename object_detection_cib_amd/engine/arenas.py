@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .graph import Graph, ConvUnit, HeadUnit, View, Buf
+from .graph import Graph, ConvUnit, HeadUnit, View, Buf, head_param
 
 
 def _pad(n: int, a: int = 64) -> int:
@@ -57,12 +57,12 @@ class ArenaMixin:
             place([u.name + ".1.weight"], 2)
             place([u.name + ".1.bias"], 0)
         for h in g.heads:
-            place([f"{h.name}.{k}_head.conv.weight" for k in ("box", "obj", "cls")], 1)
-            place([f"{h.name}.{k}_head.conv.bias" for k in ("box", "obj", "cls")], 0)
+            place([head_param(h, k, "weight") for k in ("box", "obj", "cls")], 1)
+            place([head_param(h, k, "bias") for k in ("box", "obj", "cls")], 0)
         self.n_arena = off
         self.layout = layout
         self.unit_starts = ([layout[u.name + '.0.weight'][0] for u in exec_units]
-                            + [layout[f'{h.name}.box_head.conv.weight'][0] for h in g.heads])
+                            + [layout[head_param(h, 'box', 'weight')][0] for h in g.heads])
         self.p_arena = torch.zeros(off, dtype=torch.float32, device=device)
         self.g_arena = [torch.zeros(off, dtype=torch.float32, device=device) for _ in range(2)]
         self.g_cur = 0
@@ -138,11 +138,11 @@ class ArenaMixin:
             Kp = _pad(h.cin, 32)
             Kdp = _pad(self.head_npad, 32)
             hs = dict(f_off=foff, d_off=doff, Kp=Kp, Kdp=Kdp,
-                      w_off=layout[f"{h.name}.box_head.conv.weight"][0],
-                      b_off=layout[f"{h.name}.box_head.conv.bias"][0])
+                      w_off=layout[head_param(h, "box", "weight")][0],
+                      b_off=layout[head_param(h, "box", "bias")][0])
             n_off = 0
             for k, n in (("box", 4 * A), ("obj", A), ("cls", nc * A)):
-                add_desc(f"{h.name}.{k}_head.conv.weight", foff + n_off * Kp, doff, n, h.cin, 1, 1, Kp, Kdp,
+                add_desc(head_param(h, k, "weight"), foff + n_off * Kp, doff, n, h.cin, 1, 1, Kp, Kdp,
                          self.head_npad, n_off, 0)
                 n_off += n
             foff += self.head_npad * Kp

@@ -15,14 +15,15 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .graph import Graph, ConvUnit, HeadUnit, View, Buf
+from .graph import Graph, ConvUnit, HeadUnit, View, Buf, head_param
 from .ddp import plan_buckets, launch_bucket
 
 
 class BackwardMixin:
     # ------------------------------------------------------------------ backward
-    def backward(self, head_grads: List[torch.Tensor]):
-        """head_grads: d loss / d (ll, ml, hl) head tensors.  Fills the gradient arena; returns nothing."""
+    def backward(self, head_grads: List[torch.Tensor], out_grads: Optional[List[torch.Tensor]] = None):
+        """head_grads: d loss / d (ll, ml, hl) head tensors.  Fills the gradient arena.  Sub-network graphs: out_grads =
+        d loss / d Graph.outputs (NCHW, None = zero); returns d loss / d Graph.inputs (NCHW fp32), else nothing."""
         assert self.training_ready, "backward() needs a preceding training forward()"
         self.training_ready = False
         lib, chk = self.lib, _lib.check
@@ -131,6 +132,17 @@ class BackwardMixin:
             return mode << 8, (sh.data_ptr() if (sh is not None and mode in (1, 2, 3)) else None)
         self._f32 = f32
 
+        # sub-network graphs: the callers' output gradients are the first writers of those buffers
+        if self.g.outputs:
+            og = list(out_grads) if out_grads is not None else [None] * len(self.g.outputs)
+            for v, t in zip(self.g.outputs, og):
+                name = v.buf.name
+                if name not in touched:
+                    touched.add(name)
+                    if v.C != v.buf.C or t is None:
+                        self.gact[name].zero_()
+                if t is not None:
+                    self.gact[name][..., v.coff:v.coff + v.C].copy_(t.permute(0, 2, 3, 1))
         self._pending = []
         if self._red_bucket_bytes != self.bucket_bytes:      # the reductions follow the all-reduce buckets
             self._plan_wgrad_reduce()
@@ -255,7 +267,7 @@ class BackwardMixin:
                 hs = self.hstate[hu.name]
                 gten = head_grads[head_i].contiguous()
                 assert gten.shape == (B, A, hs["H"], hs["W"], 5 + nc) and gten.dtype == torch.float32
-                names = [f"{hu.name}.{k}_head.conv.bias" for k in ("box", "obj", "cls")]
+                names = [head_param(hu, k, "bias") for k in ("box", "obj", "cls")]
                 offs = [self.layout[n][0] for n in names]
                 src = hu.src
                 # The three head chains (gradient re-layout -> data gradient) are independent until the neck: the P5
@@ -327,6 +339,9 @@ class BackwardMixin:
         if wg is not None:
             main.wait_stream(wg)
         self._publish_grads()
+        if self.g.inputs:
+            return [self.gact[v.buf.name][..., v.coff:v.coff + v.C].permute(0, 3, 1, 2).float() if v.buf.name in touched
+                    else torch.zeros((B, v.C, H // v.stride, W // v.stride), device=self.device) for v in self.g.inputs]
 
     def _bwd_unit(self, u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad, dgrad="own", partner=None):
         """bn/silu backward apply -> data gradient -> weight gradient of one conv unit (coefficients already in st.coef).

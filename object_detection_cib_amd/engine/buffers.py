@@ -55,7 +55,8 @@ class BufferMixin:
         key = (B, H, W)
         if self.shape == key:
             return
-        assert H % 32 == 0 and W % 32 == 0, "image size must be a multiple of 32"
+        top = max(b.stride for b in self.g.bufs)
+        assert H % top == 0 and W % top == 0, f"input size must be a multiple of {top} (the graph's coarsest map)"
         if self.shape is not None:
             self._sets.pop(self.shape, None)
             self._sets[self.shape] = self._export_set()          # (re-inserted last = most recently used)
@@ -83,6 +84,7 @@ class BufferMixin:
             if b.name != "image":
                 self.gact[b.name] = torch.empty(shp, dtype=torch.bfloat16, device=dev)
         max_part = 0
+        own = self.opt.wgrad_reduce_batched        # slab regions: one per layer (batched reduction) or one shared scratch
         for u in self.exec_units:
             st = self.ustate[u.name]
             if u.stem:
@@ -108,7 +110,6 @@ class BufferMixin:
             st.wg_splits = lib.kodhip_conv_wgrad_splits_geo(*wgeo, st.Kp, u.cout)
             # slab region [splits][cout][Kp] (floats): ONE scratch shared by all layers (reduced right after each weight
             # gradient, while it is still in the 256 MB Infinity Cache) - or, for the per-bucket reduction, a region each
-            own = self.opt.wgrad_reduce_batched
             st.wg_off = max_part if own else 0
             max_part = max_part + _pad(st.wg_splits * u.cout * st.Kp) if own else max(max_part, st.wg_splits * u.cout * st.Kp)
         self._plan_bn_fusion(B)

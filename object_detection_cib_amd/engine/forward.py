@@ -69,18 +69,32 @@ class ForwardMixin:
                     t = outs[k]
                 torch.distributed.all_reduce(t, group=self.process_group)
     # ------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor, training: bool = True, after_first_layer=None):
-        """x: [B,3,H,W] fp32 NCHW on this device.  Returns 3 tensors [B,A,h,w,5+nc] fp32 (ll, ml, hl).
+    def forward(self, x, training: bool = True, after_first_layer=None):
+        """Whole network / backbone: x = [B,3,H,W] fp32 NCHW on this device.  Sub-network graphs (Graph.inputs): x = a
+        sequence of NCHW tensors, one per input view (copied into the channels-last bf16 buffers; torch does the layout
+        change, the arithmetic stays in libkodhip).  Returns the head tensors [B,A,h,w,5+nc] fp32 (ll, ml, hl) followed
+        by the Graph.outputs views as NCHW fp32 tensors.
         after_first_layer: called once after the first layer's kernels are launched (a hook for side-stream work that only
         depends on the step's inputs: it is then captured behind the forward chain's head, see Yolov5Network.train_step)."""
         lib, chk = self.lib, _lib.check
-        B, Cimg, H, W = x.shape
-        assert Cimg == 3 and x.dtype == torch.float32 and x.is_contiguous() and x.device == self.device
-        self.allocate(B, H, W)
+        if self.g.inputs:
+            xs = list(x)
+            assert len(xs) == len(self.g.inputs)
+            v0 = self.g.inputs[0]
+            B, H, W = xs[0].shape[0], xs[0].shape[2] * v0.stride, xs[0].shape[3] * v0.stride
+            self.allocate(B, H, W)
+            for v, t in zip(self.g.inputs, xs):
+                assert tuple(t.shape) == (B, v.C, H // v.stride, W // v.stride) and t.device == self.device, (t.shape, v.C, v.stride)
+                self.act[v.buf.name][..., v.coff:v.coff + v.C].copy_(t.permute(0, 2, 3, 1))
+        else:
+            B, Cimg, H, W = x.shape
+            assert Cimg == 3 and x.dtype == torch.float32 and x.is_contiguous() and x.device == self.device
+            self.allocate(B, H, W)
         s = self._stream()
         if self._packed_version != self.param_version:
             self.pack_weights()
-        chk(lib.kodhip_nchw_to_nhwc4(x.data_ptr(), self.act["image"].data_ptr(), B, 3, H, W, s), "nchw_to_nhwc4")
+        if not self.g.inputs:
+            chk(lib.kodhip_nchw_to_nhwc4(x.data_ptr(), self.act["image"].data_ptr(), B, 3, H, W, s), "nchw_to_nhwc4")
         A, nc = self.g.num_anchors, self.g.num_classes
         outs = []
         pool_i = 0
@@ -252,6 +266,8 @@ class ForwardMixin:
             self.nbt_arena += 1
             self.stats_version += 1              # running statistics moved
         self.training_ready = training          # an eval forward overwrites the saved pre-BN tensors
+        for v in self.g.outputs:                # sub-network graphs: their output views, NCHW fp32
+            outs.append(self.act[v.buf.name][..., v.coff:v.coff + v.C].permute(0, 3, 1, 2).float())
         return outs
 
     def _eval_affine_ptrs(self):

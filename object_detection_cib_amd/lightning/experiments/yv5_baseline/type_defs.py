@@ -1,4 +1,4 @@
-"""Mirrors kod/lightning/experiments/yv5_baseline/type_defs.py:10-31."""
+"""Mirrors kod/lightning/experiments/yv5_baseline/type_defs.py:10-37."""
 from __future__ import annotations
 
 from typing import NamedTuple
@@ -18,6 +18,12 @@ class LayerwiseAnchorInfo(NamedTuple):
     ll: AnchorBoxInfo
     ml: AnchorBoxInfo
     hl: AnchorBoxInfo
+
+
+class LayerwisePredictionResult(NamedTuple):
+    ll: PredictionResult
+    ml: PredictionResult
+    hl: PredictionResult
 
 
 class LossResult(NamedTuple):

@@ -1,0 +1,138 @@
+"""GraphModule - an nn.Module whose forward / backward run a static sub-network program on the HIP engine.
+
+The reference builds its network out of importable nn.Modules (kod/nn/layers/csp.py, sppf.py, backbones/yolov5.py,
+necks/yolov5_pafpn.py, heads/yolov5.py); Yolov5Network here is ONE engine program, and these classes give the same
+pieces the same names, constructor signatures, parameter paths (so `state_dict()` keys and seeded initial weights
+equal the reference's) and call signatures - each as a small engine program of its own (engine/graph.py build_*_graph).
+NCHW tensors in and out; the layout change at the module edge is a torch copy, every arithmetic op is a libkodhip
+kernel.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+from ..engine.executor import Engine, BN_EPS, BN_MOMENTUM
+from ..engine.graph import Graph, head_param
+
+
+class _Slot(nn.Module):
+    """Name-space node: only holds children so parameter paths equal the reference's."""
+
+    def forward(self, *a, **k):       # pragma: no cover
+        raise RuntimeError("holder module: the sub-network runs through the HIP engine, not nn.Module.forward")
+
+
+def ensure_path(root: nn.Module, path: str) -> nn.Module:
+    node = root
+    for part in path.split("."):
+        if not part:
+            continue
+        if part not in node._modules:
+            node.add_module(part, _Slot())
+        node = node._modules[part]
+    return node
+
+
+def check_norm_act(norm_layer, activation_layer):
+    """The HIP path implements BatchNorm2d(eps=1e-3, momentum=0.03) + SiLU (kod/nn/networks/yolov5.py:24); anything else
+    is refused rather than silently replaced."""
+    if norm_layer is not None:
+        probe = norm_layer(8)
+        if not (isinstance(probe, nn.BatchNorm2d) and abs(probe.eps - BN_EPS) < 1e-12 and abs(probe.momentum - BN_MOMENTUM) < 1e-12):
+            raise ValueError("the HIP path implements BatchNorm2d(eps=1e-3, momentum=0.03) only "
+                             "(object_detection_cib_amd.nn.networks.yolov5.Yolov5BatchNorm2d)")
+    if activation_layer is not None:
+        probe = activation_layer()
+        if not isinstance(probe, nn.SiLU) and type(probe).__name__ not in ("SiLU", "SiLUInplace"):
+            raise ValueError("the HIP path implements SiLU only")
+
+
+def add_unit_parameters(root: nn.Module, graph: Graph, norm_layer):
+    """conv(bias=False) + BatchNorm holders in the graph's registration order (= the reference's construction order)."""
+    for u in graph.units:
+        slot = ensure_path(root, u.name)
+        cin = 3 if u.stem else u.cin
+        slot.add_module("0", nn.Conv2d(cin, u.cout, 6 if u.stem else u.k, u.s, u.p, bias=False))
+        slot.add_module("1", norm_layer(u.cout))
+
+
+def add_head_parameters(root: nn.Module, graph: Graph, use_yv5_init: bool = True):
+    """The three biased 1x1 convs of every head, with the reference's bias initialisation (heads/yolov5.py:65-73,113-121)."""
+    A, nc = graph.num_anchors, graph.num_classes
+    for h in graph.heads:
+        for key, p, shift in (("box", 4, 0.0), ("obj", 1, math.log(8 / (640 / h.stride) ** 2)),
+                              ("cls", nc, math.log(0.6 / (nc - 0.99999)))):
+            conv = nn.Conv2d(h.cin, A * p, 1)
+            if shift and use_yv5_init:
+                with torch.no_grad():
+                    conv.bias.add_(shift)
+            ensure_path(root, head_param(h, key, "weight")[:-len(".conv.weight")]).add_module("conv", conv)
+
+
+class _GraphFn(torch.autograd.Function):
+    """The whole sub-network as one autograd node: forward / backward are the engine's op lists."""
+
+    @staticmethod
+    def forward(ctx, mod, n_heads, _anchor, *xs):
+        ctx.mod, ctx.n_heads, ctx.n_in = mod, n_heads, len(xs)
+        outs = mod._engine.forward(xs if mod.graph.inputs else xs[0], training=True)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        nh = ctx.n_heads
+        eng = ctx.mod._engine
+        head_grads = [g if g is not None else torch.zeros_like(o) for g, o in zip(grads[:nh], ctx.mod._last_heads)]
+        gin = eng.backward(head_grads, list(grads[nh:]))
+        if gin is None:
+            gin = [None] * ctx.n_in
+        return (None, None, None, *gin)
+
+
+class GraphModule(nn.Module):
+    """Base of the sub-network modules: parameters as torch holders, execution through an Engine over `self.graph`."""
+
+    def _init_graph(self, graph: Graph, norm_layer):
+        from .networks.yolov5 import Yolov5BatchNorm2d
+        self.graph = graph
+        add_unit_parameters(self, graph, norm_layer or Yolov5BatchNorm2d)
+        if graph.heads:
+            add_head_parameters(self, graph)
+        self._engine = None
+        self._engine_device = None
+        self._last_heads = ()
+        self.engine_options = None
+
+    def engine(self) -> Engine:
+        dev = next(self.parameters()).device
+        if self._engine is None or self._engine_device != dev:
+            if dev.type != "cuda":
+                raise RuntimeError(f"{type(self).__name__} (HIP) must be on an MI355X: call .cuda() first; no CPU fallback")
+            eng = Engine(self.graph, dict(self.named_parameters()), dict(self.named_buffers()), self.engine_options)
+            eng._build_arenas(dev)
+            self._engine, self._engine_device = eng, dev
+        return self._engine
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        if self._engine is not None:
+            self._engine.mark_params_changed()
+        return out
+
+    def _run(self, xs: Sequence[torch.Tensor]):
+        """-> (head tensors [B, A, h, w, 5+nc], output views NCHW fp32)"""
+        eng = self.engine()
+        xs = [x.float().contiguous() for x in xs]
+        nh = len(self.graph.heads)
+        if self.training and torch.is_grad_enabled():
+            anchor = next(self.parameters())
+            outs = _GraphFn.apply(self, nh, anchor, *xs)
+            self._last_heads = tuple(outs[:nh])
+        else:
+            with torch.no_grad():
+                outs = eng.forward(xs if self.graph.inputs else xs[0], training=self.training)
+        return list(outs[:nh]), list(outs[nh:])

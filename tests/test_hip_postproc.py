@@ -61,3 +61,29 @@ def test_nms_empty_and_single_class():
     det = torch.zeros((2, 100, 6), device="cuda")
     res = non_max_suppression(det, 0.25, 0.45)
     assert [r.shape for r in res] == [(0, 6), (0, 6)]
+
+
+def test_per_level_prediction_classes_equal_get_detections():
+    """Yolov5BoxPrediction / ObjectnessPrediction / ClassPrediction / Yolov5Prediction / Yolov5PredictionAssembler
+    (kod/lightning/experiments/yv5_baseline/layers.py:15-155, same names and call signatures): assembling the three levels'
+    predictions reproduces get_detections - which the golden vectors pin to the reference - bit for bit."""
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.layers import (
+        Yolov5BoxPrediction, Yolov5ClassPrediction, Yolov5ObjectnessPrediction, Yolov5Prediction, Yolov5PredictionAssembler)
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.type_defs import LayerwisePredictionResult, PredictionResult
+    size, nc, B = 160, 10, 3
+    shape = FeatureShape(width=size, height=size)
+    heads = synth.head_logits(B, size, nc, seed=11, scale=1.5)
+    net = tuple(tuple(t.cuda() for t in h) for h in heads)
+    want = get_detections(shape, net, ANCH)
+    preds = []
+    for (box, obj, cls), info in zip(net, ANCH):
+        p = Yolov5Prediction(info.stride, shape, info.boxes_wh)(box, obj, cls)
+        assert isinstance(p, PredictionResult) and p.box.shape == (B, 3 * (size // info.stride) ** 2, 4)
+        # the single-quantity classes agree with the fused one
+        assert torch.equal(Yolov5BoxPrediction(info.stride, shape, info.boxes_wh)(box), p.box)
+        assert torch.equal(Yolov5ObjectnessPrediction()(obj), p.obj)
+        assert torch.equal(Yolov5ClassPrediction()(cls), p.cls)
+        preds.append(p)
+    lw = LayerwisePredictionResult(*preds)
+    det = Yolov5PredictionAssembler()([p.box for p in lw], [p.obj for p in lw], [p.cls for p in lw])
+    assert torch.equal(det, want)

@@ -278,3 +278,35 @@ def test_dual_dgrad_and_bn_reduce_fusion_plans():
     for w, prods in plan.items():
         for p, ch0 in prods:
             assert ch0 % 8 == 0
+
+
+def test_submodule_classes_mirror_reference_parameters_and_refuse_cpu():
+    """CSPBlock / CSPLayer / SPPFBottleneck / Yolov5Backbone / Yolov5PAFPN / Yolov5Head (kod/nn/layers, backbones, necks,
+    heads): constructor signatures of the reference, state_dict keys / shapes / seeded initial values equal to the oracle's
+    restatement (which the golden vectors pin to the reference); like the network they have no CPU path."""
+    from oracle import network as N
+    from object_detection_cib_amd.nn.backbones.yolov5 import StageConfig, Yolov5Backbone
+    from object_detection_cib_amd.nn.heads.yolov5 import Yolov5Head
+    from object_detection_cib_amd.nn.layers.csp import CSPBlock, CSPLayer
+    from object_detection_cib_amd.nn.layers.sppf import SPPFBottleneck
+    from object_detection_cib_amd.nn.necks.yolov5_pafpn import Yolov5PAFPN
+    from object_detection_cib_amd.nn.networks.yolov5 import Yolov5BatchNorm2d
+    act = torch.nn.SiLU
+    pairs = [
+        (lambda: CSPBlock(32, 32, 1.0, True, Yolov5BatchNorm2d, act), lambda: N.Bottleneck(32, True)),
+        (lambda: CSPLayer(64, 128, 0.5, False, 3, Yolov5BatchNorm2d, act), lambda: N.CSP(64, 128, 3, False)),
+        (lambda: SPPFBottleneck(256, 256, 5, True, 0.5, Yolov5BatchNorm2d, act), lambda: N.SPPF(256, 256)),
+        (lambda: Yolov5Backbone(Yolov5BatchNorm2d, act, [StageConfig(*s) for s in N.P5], 0.33, 0.5), lambda: N.Backbone(0.5, 0.33)),
+        (lambda: Yolov5PAFPN([256, 512, 1024], Yolov5BatchNorm2d, act, 3, 0.5, 0.33, 0.5), lambda: N.Neck([256, 512, 1024], 0.5, 0.33)),
+        (lambda: Yolov5Head(128, 3, 10, 16), lambda: N.Head(128, 3, 10, 16)),
+    ]
+    for make_hip, make_ref in pairs:
+        torch.manual_seed(11); hip = make_hip()
+        torch.manual_seed(11); ref = make_ref()
+        sh, sr = hip.state_dict(), ref.state_dict()
+        assert list(sh.keys()) == list(sr.keys()), type(hip).__name__
+        assert all(torch.equal(a, b) for a, b in zip(sh.values(), sr.values())), type(hip).__name__
+    with pytest.raises(RuntimeError, match="MI355X"):
+        CSPLayer(64, 64)(torch.zeros(1, 64, 8, 8))
+    with pytest.raises(ValueError):
+        CSPBlock(32, 32, norm_layer=torch.nn.BatchNorm2d)
