@@ -143,6 +143,17 @@ int kodhip_wgrad_reduce_blocks(int n_valid, int K);
 int kodhip_wgrad_reduce_batched(const float* partials, float* grads, const void* descs /* device KodWgradReduceDesc[n] */,
                                 int n_desc, int total_blocks, kodStream_t stream);
 
+/* The stem's whole backward in one kernel + the slab reduction: dY = k1 * dA * silu'(y * scale + shift) + k2 * y + k3 is
+ * formed on the fly and multiplied into dW; dY is never written (the stem - kod/nn/backbones/yolov5.py:44-52, 6x6 / stride 2
+ * / pad 2 on the image - has no data gradient, so the weight gradient is dY's only reader).  Replaces
+ * kodhip_bn_silu_bwd_apply + kodhip_conv_wgrad(stem = 1) for that unit.  x: pixel pairs [B][H][Wp][8] bf16 (Wp = width / 2);
+ * dA: [B * H/2 * Wp][lda] (+dacoff), y: [..][ldy] pre-BatchNorm output (left untouched); coef = k1[N] | k2[N] | k3[N] from
+ * kodhip_bn_bwd_coeffs*; partials: kodhip_stem_bwd_fused_blocks(B, H, Wp) * 32 * 160 floats; grad: fp32 [N][3][6][6].  N <= 32. */
+int kodhip_stem_bwd_fused_blocks(int B, int H, int Wp);
+int kodhip_stem_bwd_fused(const void* x, const void* dA, int lda, int dacoff, const void* y, int ldy,
+                          const float* scale, const float* shift, const float* coef, float* partials, float* grad,
+                          int B, int H, int Wp, int N, float gscale, kodStream_t stream);
+
 /* ---- BatchNorm2d(eps 1e-3, momentum .03) + SiLU (kod/nn/networks/yolov5.py:24,
  *      kod/nn/layers/activations.py:7; aten::native_batch_norm(+backward), silu(+backward)) ---------- */
 int kodhip_bn_reduce_partials(const float* partials, double* sums, int C, int T, kodStream_t stream);

@@ -863,6 +863,192 @@ int launch_cfg(WgradArgs a, hipStream_t stream) {
   return KOD_OK;
 }
 
+// ---- the stem's backward in one kernel: dY = f(dA, y) formed on the fly, dW slabs out ---------------------------------
+// The stem (6x6 / stride 2 / pad 2 on the image, here a 6x3 / stride (2,1) conv over 8-value pixel PAIRS) has no data
+// gradient, so its dY = k1 * dA * silu'(z) + k2 * y + k3 has exactly one reader: this weight gradient.  The separate
+// BatchNorm/SiLU backward pass read dA and y (2 x 0.42 GB at B = 64 / 640 px), wrote dY (0.42 GB) and the generic weight
+// gradient read it back and gathered every pixel pair 18 x from L2 (fill-bound: 233 us for 0.63 GB).  Here a block walks
+// row-aligned tiles of TW output pixels.  Everything a tile needs goes HBM -> LDS by DMA, one tile ahead of the
+// arithmetic: the six pair-row runs (TW + 2 pairs each, the two border pairs zero-filled by out-of-range offsets - no tap
+// masks; they serve all 18 taps through per-lane fragment addresses, run row i + kw') and the dA / y tiles.  dY is formed
+// IN LDS with the arithmetic of bn_silu_bwd_apply_kernel (same bf16 rounding), over the dA tile, which then is the
+// [m][n] operand; wave w owns k columns 32 w .. 32 w + 31 of the 160-column slab.  dY never exists in HBM.
+// Every LDS access is inline asm: with compiler-visible LDS writes or register loads next to the DMA the compiler's own
+// waits drain the prefetch in front of them (measured: movement 256 us + transform 98 us + MFMA 80 us ran back to back).
+__device__ __forceinline__ float stem_sigmoid(float z) {      // = bn_act.hip fast_sigmoid
+  const float d = 1.0f + __expf(-z);
+  const float r = __builtin_amdgcn_rcpf(d);
+  return r * (2.0f - d * r);
+}
+
+struct StemBwdArgs {
+  const bf16_t* x;            // pixel pairs [B][Hs][Wp][8]
+  const bf16_t* dA; int lda, dacoff;
+  const bf16_t* y; int ldy;
+  const float* scale; const float* shift; const float* coef;      // coef: k1[N] | k2[N] | k3[N]
+  float* part;                // [blocks][32][160]
+  int B, Hs, Wp, Ho, Wo, N;
+  int tiles_per_row, tiles, tiles_per_block;
+  uint32_t x_bytes, da_bytes, y_bytes;
+};
+
+// staged pairs per kernel row: TW + 2 used, and PRW * 16 B = 128 mod 256 so that the two kernel rows a 4-tap column group
+// touches land on disjoint LDS banks
+__host__ __device__ constexpr int stem_prw(int TW) { return TW == 160 ? 168 : 88; }
+__host__ __device__ constexpr int stem_xb(int TW) { return (6 * stem_prw(TW) * 16 + 1023) / 1024 * 1024; }
+
+template <int TW>
+__global__ __launch_bounds__(320, TW == 160 ? 3 : 5) void conv_stem_bwd_fused_kernel(StemBwdArgs a) {
+  constexpr int PRW = stem_prw(TW), NW = 5;
+  constexpr int XB = stem_xb(TW), GB = TW * 64;          // X runs | dA tile (becomes dY) | y tile
+  constexpr int STAGE = XB + 2 * GB;
+  constexpr int NIX = XB / 1024, NIG = GB / 1024, NI = NIX + 2 * NIG;     // DMA instructions per tile (1 KB each)
+  constexpr int ITEMS = TW * 4 / 320;                    // 16-byte (pixel, 8-channel chunk) items per thread
+  static_assert(GB % 1024 == 0 && TW * 4 % 320 == 0, "tile must fill whole DMA instructions / thread items");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t_begin = blockIdx.x * a.tiles_per_block;
+  int t_end = t_begin + a.tiles_per_block;
+  if (t_end > a.tiles) t_end = a.tiles;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)a.dA, 0, a.da_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+#endif
+
+  // per-thread constants of the dY arithmetic: this thread's items are (pixel q >> 2, channel chunk q & 3), q = tid + 320 j
+  const int cc = tid & 3;
+  float sc[8], sh[8], k1[8], k2[8], k3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cc * 8 + e;
+    const bool ok = c < a.N;
+    sc[e] = ok ? a.scale[c] : 0.f; sh[e] = ok ? a.shift[c] : 0.f;
+    k1[e] = ok ? a.coef[c] : 0.f; k2[e] = ok ? a.coef[a.N + c] : 0.f; k3[e] = ok ? a.coef[2 * a.N + c] : 0.f;
+  }
+  const bool ch_ok = cc * 8 < a.N;
+
+  // one tile's DMA: instruction i = wave + 5 k; i < NIX: pair-row runs (LDS slot 64 i + lane = kh * PRW + r), then the dA
+  // tile, then the y tile (slot = 4 * pixel + chunk)
+  auto stage = [&](int t, int buf) {
+    const int row = t / a.tiles_per_row;                  // b * Ho + oy
+    const int ox0 = (t - row * a.tiles_per_row) * TW;
+    const int b = row / a.Ho, oy = row - b * a.Ho;
+    unsigned char* S = lds + buf * STAGE;
+#pragma unroll
+    for (int k = 0; k < (NI + NW - 1) / NW; ++k) {
+      const int i = wave + NW * k;
+      if (i >= NI) continue;
+      uint32_t vo = 0xFFFFFFF0u;
+      if (i < NIX) {
+        const int L = i * 64 + lane;
+        const int kh = L / PRW, r = L - kh * PRW;
+        const int iy = 2 * oy - 2 + kh, px = ox0 - 1 + r;
+        if (kh < 6 && r < TW + 2 && (unsigned)iy < (unsigned)a.Hs && (unsigned)px < (unsigned)a.Wp)
+          vo = (uint32_t)((((long)b * a.Hs + iy) * a.Wp + px) * 16);
+      } else {
+        const bool is_g = i < NIX + NIG;
+        const int q = (i - NIX - (is_g ? 0 : NIG)) * 64 + lane;
+        const int p = q >> 2, c = q & 3;
+        const long m = (long)row * a.Wo + ox0 + p;
+        if (ox0 + p < a.Wo && c * 8 < a.N)
+          vo = is_g ? (uint32_t)((m * a.lda + a.dacoff + c * 8) * 2) : (uint32_t)((m * a.ldy + c * 8) * 2);
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (i < NIX)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(S + i * 1024), 16, vo, 0, 0, 0);
+      else if (i < NIX + NIG)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(S + i * 1024), 16, vo, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (__attribute__((address_space(3))) void*)(S + i * 1024), 16, vo, 0, 0, 0);
+#else
+      (void)vo; (void)S;
+#endif
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+  // fragment addresses (transposing reads, lane geometry of conv_wgrad_dma_kernel): rows = reduction index m
+  const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
+  const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  const uint32_t yoff = (uint32_t)(XB + tr_row * 64 + tr_col * 2);
+  int tap = wave * 4 + (tr_col >> 3);
+  if (tap > 17) tap = 17;                                   // slab columns 144 .. 159 are padding (never reduced)
+  const int tkh = tap / 3, tkw = tap - tkh * 3;
+  const uint32_t xoff = (uint32_t)((tkh * PRW + tkw + tr_row) * 16 + (tr_col & 7) * 2);
+
+  if (t_begin < t_end) stage(t_begin, 0);
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();       // this tile has landed (every wave's share); the other stage's readers are done
+    if (t + 1 < t_end) stage(t + 1, buf ^ 1);
+
+    // ---- dY of this tile, in place over the dA tile
+    const uint32_t sb = lds_base + (uint32_t)(buf * STAGE);
+    const int ox0 = (t % a.tiles_per_row) * TW;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int q = tid + 320 * j, p = q >> 2;
+      const uint32_t ga = sb + XB + (uint32_t)q * 16, ya = ga + GB;
+      u32x4 gr, yr;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(gr) : "v"(ga) : "memory");
+      asm volatile("ds_read_b128 %0, %1" : "=v"(yr) : "v"(ya) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(gr), "+v"(yr));
+      const bf16x8 g8 = __builtin_bit_cast(bf16x8, gr);
+      const bf16x8 y8 = __builtin_bit_cast(bf16x8, yr);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yv = (float)y8[e];
+        const float z = yv * sc[e] + sh[e];
+        const float sg = stem_sigmoid(z);
+        const float dz = (float)g8[e] * sg * (1.f + z * (1.f - sg));
+        o[e] = (bf16_t)(k1[e] * dz + k2[e] * yv + k3[e]);
+      }
+      if (!(ch_ok && ox0 + p < a.Wo)) o = bf16x8{};        // ragged last tile of a row / channels past N: zero rows
+      const u32x4 ov = __builtin_bit_cast(u32x4, o);
+      asm volatile("ds_write_b128 %0, %1" ::"v"(ga), "v"(ov) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll 2
+    for (int ks = 0; ks < TW / 16; ++ks) {
+      s16x4 ylo, yhi, xlo, xhi;
+      const uint32_t py = sb + yoff + (uint32_t)(ks * 16 * 64);
+      const uint32_t px = sb + xoff + (uint32_t)(ks * 16 * 16);
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo) : "v"(py) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(yhi) : "v"(py + 4 * 64) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo) : "v"(px) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xhi) : "v"(px + 4 * 16) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(ylo), "+v"(yhi), "+v"(xlo), "+v"(xhi));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 ty = {ylo[0], ylo[1], ylo[2], ylo[3], yhi[0], yhi[1], yhi[2], yhi[3]};
+      const s16x8 tx = {xlo[0], xlo[1], xlo[2], xlo[3], xhi[0], xhi[1], xhi[2], xhi[3]};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ty), __builtin_bit_cast(bf16x8, tx), acc, 0, 0, 0);
+    }
+    buf ^= 1;
+  }
+
+  // D[n][k]: k = 32 wave + (lane & 31), n = 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
+  float* slab = a.part + (size_t)blockIdx.x * 32 * 160;
+  const int k = wave * 32 + (lane & 31);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int n = 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+    slab[(size_t)n * 160 + k] = acc[e];
+  }
+}
+
 // ROW3 form (conv_wgrad_row3_kernel): 3x3 / stride 1 / pad 1 with whole 32-channel chunks.
 // KODHIP_WGRAD_ROW3: 0 = off, 1 (default) = where it measured faster, 2 = every eligible layer.
 // Measured at B = 64 / 640 px (profiles/r03_convbench.txt, generic -> ROW3): 32->32 @160 138 -> 125 us, 256->256 @20
@@ -1025,6 +1211,58 @@ int kodhip_conv_wgrad_partial(const void* x, const void* dy, float* partials,
                               int ldy, int ycoff, hipStream_t stream) {
   WgradArgs a;
   return wgrad_partial(a, x, dy, partials, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, stream);
+}
+
+// The stem's BatchNorm/SiLU backward + weight gradient as one kernel (conv_stem_bwd_fused_kernel) followed by the slab
+// reduction: replaces kodhip_bn_silu_bwd_apply + kodhip_conv_wgrad(stem = 1) for the unit that has no data gradient
+// (kod/nn/backbones/yolov5.py:44-52: the 6x6 / stride 2 / pad 2 stem; aten::native_batch_norm_backward + silu_backward +
+// convolution_backward dW).  x: pixel pairs [B][H][Wp][8] bf16 (Wp = image width / 2), dA / y: [B * H/2 * Wp][N] slices,
+// coef = kodhip_bn_bwd_coeffs*'s k1 | k2 | k3; partials: kodhip_stem_bwd_fused_blocks(B, H, Wp) * 32 * 160 floats; grad: fp32
+// [N][3][6][6].  y is left untouched (dY is never materialised).  N <= 32.
+// tile width: 80 pixels (four 5-wave blocks per CU; measured 336 us at B = 64 / 640 px against 443 us for 160-pixel tiles
+// with two blocks per CU); KODHIP_STEM_BWD_TW = 80 | 160 is the A/B knob
+static int stem_bwd_tw(int Wp) {
+  static int tw = 0;
+  if (!tw) { const char* e = getenv("KODHIP_STEM_BWD_TW"); tw = e ? atoi(e) : 80; if (tw != 80 && tw != 160) tw = 80; }
+  return Wp <= 80 ? 80 : tw;
+}
+
+int kodhip_stem_bwd_fused_blocks(int B, int H, int Wp) {
+  const int TW = stem_bwd_tw(Wp);
+  const long tiles = (long)B * (H / 2) * cdiv(Wp, TW);
+  static int slots = 0;                  // KODHIP_STEM_BWD_BLOCKS: A/B knob (default: every resident slot of the chip)
+  if (!slots) { const char* e = getenv("KODHIP_STEM_BWD_BLOCKS"); slots = e ? atoi(e) : 0; if (slots < 1) slots = 0; }
+  const int want = slots ? slots : (TW == 160 ? 512 : 1024);
+  const int tpb = cdiv(tiles, want);
+  return cdiv(tiles, tpb);
+}
+
+int kodhip_stem_bwd_fused(const void* x, const void* dA, int lda, int dacoff, const void* y, int ldy,
+                          const float* scale, const float* shift, const float* coef, float* partials, float* grad,
+                          int B, int H, int Wp, int N, float gscale, hipStream_t stream) {
+  KOD_CHECK_ARG(x && dA && y && scale && shift && coef && partials && grad, "stem_bwd_fused: null pointer");
+  KOD_CHECK_ARG(B > 0 && H >= 2 && H % 2 == 0 && Wp > 0 && N > 0 && N <= 32 && N % 8 == 0, "stem_bwd_fused: bad geometry");
+  KOD_CHECK_ARG(lda % 8 == 0 && dacoff % 8 == 0 && dacoff + N <= lda && ldy % 8 == 0 && ldy >= N, "stem_bwd_fused: bad slices");
+  StemBwdArgs a = {};
+  a.x = (const bf16_t*)x; a.dA = (const bf16_t*)dA; a.lda = lda; a.dacoff = dacoff; a.y = (const bf16_t*)y; a.ldy = ldy;
+  a.scale = scale; a.shift = shift; a.coef = coef; a.part = partials;
+  a.B = B; a.Hs = H; a.Wp = Wp; a.Ho = H / 2; a.Wo = Wp; a.N = N;
+  const long M = (long)B * a.Ho * a.Wo;
+  const long xb = (long)B * H * Wp * 16, gb = M * lda * 2, yb = M * ldy * 2;
+  KOD_CHECK_ARG(xb < (1l << 32) - 64 && gb < (1l << 32) - 64 && yb < (1l << 32) - 64, "stem_bwd_fused: tensor beyond the 32-bit buffer range");
+  a.x_bytes = (uint32_t)xb; a.da_bytes = (uint32_t)gb; a.y_bytes = (uint32_t)yb;
+  const int TW = stem_bwd_tw(Wp);
+  a.tiles_per_row = cdiv(a.Wo, TW);
+  a.tiles = B * a.Ho * a.tiles_per_row;
+  const int blocks = kodhip_stem_bwd_fused_blocks(B, H, Wp);
+  a.tiles_per_block = cdiv(a.tiles, blocks);
+  if (TW == 160) hipLaunchKernelGGL(conv_stem_bwd_fused_kernel<160>, dim3(blocks), dim3(320), 0, stream, a);
+  else hipLaunchKernelGGL(conv_stem_bwd_fused_kernel<80>, dim3(blocks), dim3(320), 0, stream, a);
+  KOD_LAUNCH_CHECK("stem_bwd_fused");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(N * 144, RED_K)), dim3(256), 0, stream,
+                     (const float*)partials, grad, blocks, 32, N, 144, 160, 8, 18, 1, gscale);
+  KOD_LAUNCH_CHECK("stem_bwd_fused reduce");
+  return KOD_OK;
 }
 
 int kodhip_wgrad_reduce_desc_bytes(void) { return (int)sizeof(ReduceDesc); }

@@ -44,7 +44,27 @@ class BackwardMixin:
         if self.wgrad_overlap:
             if self.wg_stream is None:
                 self.wg_stream = torch.cuda.Stream(device=self.device)
+                self.wg_more = [torch.cuda.Stream(device=self.device) for _ in range(self._wg_streams - 1)]
             wg = self.wg_stream
+        # further weight-gradient streams (EngineOptions.wgrad_streams): the launches rotate over them, each stream with its
+        # own slab scratch; stream 0 is the one the gradient buckets ride on
+        wgs = [wg] + (self.wg_more if (wg is not None and self.wgrad_fork != "legacy") else []) if wg is not None else []
+        rr = [0]
+
+        def join_main():
+            """the weight-gradient stream (where the gradient buckets ride) waits for what the main stream has queued"""
+            if wg is not None and buckets:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                wg.wait_event(ev)
+        self._join_main = join_main
+
+        def join_wg():
+            """stream 0 waits for everything queued on the other weight-gradient streams"""
+            for o in wgs[1:]:
+                ev = torch.cuda.Event()
+                ev.record(o)
+                wg.wait_event(ev)
 
         # How a weight gradient joins the side stream matters in the captured graph: this stack's graph executor keeps a
         # node's FIRST captured successor on the node's queue and hands the later ones to other queues (~11 us per
@@ -66,10 +86,15 @@ class BackwardMixin:
         batched = self.opt.wgrad_reduce_batched     # slab reductions: one launch per bucket (default) | per layer
 
         def launch_wgrad(name, nbytes, args, stream_obj):
-            """args = kodhip_conv_wgrad's (x, dy, slab region, grad, geometry ..., n_valid, stem, scale)"""
+            """args = kodhip_conv_wgrad's (x, dy, slab region, grad, geometry ..., n_valid, stem, scale), or
+            ("stem", region offset in bytes, kodhip_stem_bwd_fused's arguments with the region base in place 9)"""
             e0 = self._t0(stream_obj)
             sid = stream_obj.cuda_stream if stream_obj is not None else s
-            if batched:
+            if args[0] == "stem":
+                fa = list(args[2:])
+                fa[9] += args[1]
+                chk(lib.kodhip_stem_bwd_fused(*fa, sid), name + ".bwd_fused")
+            elif batched:
                 chk(lib.kodhip_conv_wgrad_partial(*args[:3], *args[4:-3], sid), name + ".wgrad")
             else:
                 chk(lib.kodhip_conv_wgrad(*args, sid), name + ".wgrad")
@@ -78,8 +103,13 @@ class BackwardMixin:
         def flush_wgrads():
             """call after the main stream's next kernel has been launched"""
             for ev, name, nbytes, args in deferred:
-                wg.wait_event(ev)
-                launch_wgrad(name, nbytes, args, wg)
+                k = rr[0] % len(wgs)
+                rr[0] += 1
+                if k:
+                    args = list(args)
+                    args[1 if args[0] == "stem" else 2] += 4 * k * self._wg_region
+                wgs[k].wait_event(ev)
+                launch_wgrad(name, nbytes, args, wgs[k])
             deferred.clear()
             if due:
                 self._launch_due()
@@ -169,6 +199,7 @@ class BackwardMixin:
                 if idx in buckets:
                     lo, hi = buckets[idx]
                     cs = self._comm_stream()
+                    join_wg()
                     # overlapped buckets use their own communicator: SyncBN sums (main stream) and buckets (side stream)
                     # never interleave on one communicator from two streams
                     bc = self.comm_buckets if (cs is not None and self.comm_buckets is not None) else self.comm
@@ -336,8 +367,8 @@ class BackwardMixin:
         flush_wgrads()
         for name in list(grad_events):
             sync_grad(name)
-        if wg is not None:
-            main.wait_stream(wg)
+        for o in wgs:
+            main.wait_stream(o)
         self._publish_grads()
         if self.g.inputs:
             return [self.gact[v.buf.name][..., v.coff:v.coff + v.C].permute(0, 3, 1, 2).float() if v.buf.name in touched
@@ -353,6 +384,28 @@ class BackwardMixin:
         aff = st.aff.data_ptr()
         dA = u.dst
         res = u.residual
+        if st.stem_fused and res is None:
+            # the stem has no data gradient: dY = f(dA, y) is formed inside its weight gradient and never written
+            # (csrc/conv_wgrad.hip conv_stem_bwd_fused_kernel); the launch joins the weight-gradient stream behind the
+            # coefficient kernel
+            fargs = (self._ptr(u.src), self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
+                     aff, aff + 4 * C_, st.coef.data_ptr())
+            nb = 2.0 * (B * H * W * 3 + 2 * st.M * C_)
+            if self.opt.native.get("KODHIP_STEM_BWD_STREAM", "main") == "main":
+                # on the MAIN stream, with a slab scratch of its own: it is the main chain's last kernel, and the chip is
+                # otherwise left to the tail of the weight-gradient stream (small launches, one at a time) - this HBM-bound
+                # kernel runs beside them instead of behind them
+                e0 = self._t0()
+                chk(lib.kodhip_stem_bwd_fused(*fargs, self.stem_part.data_ptr(), gp + 4 * st.w_off,
+                                              B, st.H, st.W, C_, 1.0, s), u.name + ".bwd_fused")
+                self._t1(e0, "wgrad", nb)
+                self._flush_wgrads()
+                self._join_main()          # a gradient bucket on the weight-gradient stream must see this gradient
+                return
+            self._fork_point()
+            timed_wgrad(u.name, nb, "stem", 0, *fargs, wgp + 4 * st.wg_off, gp + 4 * st.w_off, B, st.H, st.W, C_, 1.0)
+            self._flush_wgrads()
+            return
         racc = acc_flag(res) if res else 0
         e0 = self._t0()
         chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,

@@ -25,18 +25,19 @@ from .plan import backward_writes, plan_f32_accumulation, plan_dual_dgrads, plan
 class BufferMixin:
     # ------------------------------------------------------------------ activations
     _UNIT_FIELDS = ("stats", "T", "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho",
-                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld", "wg_splits", "wg_off")
+                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld", "wg_splits", "wg_off", "stem_fused")
     _HEAD_FIELDS = ("H", "W", "M", "dy", "ws", "wg_splits", "wg_off")
 
     def _export_set(self) -> dict:
         return dict(act=self.act, gact=self.gact, gact32=self.gact32, wg_part=self.wg_part, pool_idx=self.pool_idx,
-                    red_groups=self.red_groups,
+                    red_groups=self.red_groups, wg_region=self._wg_region, stem_part=getattr(self, "stem_part", None),
                     units={n: {f: getattr(st, f) for f in self._UNIT_FIELDS} for n, st in self.ustate.items()},
                     heads={n: {f: hs[f] for f in self._HEAD_FIELDS} for n, hs in self.hstate.items()})
 
     def _import_set(self, d: dict):
         self.act, self.gact, self.wg_part, self.pool_idx = d["act"], d["gact"], d["wg_part"], d["pool_idx"]
-        self.gact32, self.red_groups = d["gact32"], d["red_groups"]
+        self.gact32, self.red_groups, self._wg_region = d["gact32"], d["red_groups"], d["wg_region"]
+        self.stem_part = d["stem_part"]
         for n, fields in d["units"].items():
             st = self.ustate[n]
             for f, v in fields.items():
@@ -108,10 +109,17 @@ class BufferMixin:
             wgeo = (B, st.H, st.W, 8, 8, u.cout, 6, 3, 2, 1, 2, 1) if u.stem else \
                 (B, st.H, st.W, u.src.buf.C, u.cin, u.cout, u.k, u.k, u.s, u.s, u.p, u.p)
             st.wg_splits = lib.kodhip_conv_wgrad_splits_geo(*wgeo, st.Kp, u.cout)
+            nslab = st.wg_splits * u.cout * st.Kp
+            # the stem's backward as one kernel (kodhip_stem_bwd_fused): a slab per block, 32 rows whatever cout is
+            st.stem_fused = bool(u.stem and u.cout <= 32 and self.opt.stem_bwd_fused and not own)
+            if st.stem_fused:
+                st.wg_splits = lib.kodhip_stem_bwd_fused_blocks(B, st.H, st.W)
+                nslab = st.wg_splits * 32 * 160
+                self.stem_part = torch.empty(nslab, dtype=torch.float32, device=dev)    # (it runs on the main stream)
             # slab region [splits][cout][Kp] (floats): ONE scratch shared by all layers (reduced right after each weight
             # gradient, while it is still in the 256 MB Infinity Cache) - or, for the per-bucket reduction, a region each
             st.wg_off = max_part if own else 0
-            max_part = max_part + _pad(st.wg_splits * u.cout * st.Kp) if own else max(max_part, st.wg_splits * u.cout * st.Kp)
+            max_part = max_part + _pad(nslab) if own else max(max_part, nslab)
         self._plan_bn_fusion(B)
         self.gact32 = {}
         if self._f32plan is not None:
@@ -128,7 +136,9 @@ class BufferMixin:
             hs["wg_off"] = max_part if own else 0
             nslab = hs["wg_splits"] * self.head_npad * hs["Kp"]
             max_part = max_part + _pad(nslab) if own else max(max_part, nslab)
-        self.wg_part = torch.empty(max_part, dtype=torch.float32, device=dev)
+        # shared scratch: one region per weight-gradient stream (engine/backward.py)
+        self._wg_region = _pad(max_part)
+        self.wg_part = torch.empty(max_part if own else self._wg_region * self._wg_regions, dtype=torch.float32, device=dev)
         self._plan_wgrad_reduce()
         # SPPF argmax indices
         self.pool_idx = []

@@ -50,7 +50,11 @@ class Engine(ArenaMixin, BufferMixin, ForwardMixin, BackwardMixin):
         self.process_group = None
         self.world_size = 1
         self.wg_stream = None          # side stream of the weight-gradient kernels (see backward)
+        self.wg_more = []              # further weight-gradient streams (EngineOptions.wgrad_streams)
         self.wgrad_overlap = self.opt.wgrad_overlap
+        # regions of the slab scratch = weight-gradient streams (the per-bucket reduction keeps a region per layer: one stream)
+        self._wg_streams = 1 if self.opt.wgrad_reduce_batched else max(1, int(self.opt.wgrad_streams))
+        self._wg_regions = self._wg_streams
         self.wgrad_fork = self.opt.wgrad_fork     # see backward(): deferred capture of the wgrad launches
         self.comm = None               # RcclComm when the process group is RCCL-backed (the product path)
         self.comm_buckets = None       # second communicator: gradient buckets on the weight-gradient stream (comm_overlap)

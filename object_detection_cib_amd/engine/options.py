@@ -15,7 +15,7 @@ from typing import Dict
 
 # knobs libkodhip.so reads with getenv (csrc/conv_igemm.hip, csrc/conv_wgrad.hip)
 NATIVE_KNOBS = ("KODHIP_NO_FAST", "KODHIP_FORCE_BM", "KODHIP_FORCE_BN", "KODHIP_S2_SEPARATE", "KODHIP_S2_FOLD_MAXC",
-                "KODHIP_S2_INTERLEAVE", "KODHIP_ROW3", "KODHIP_ROW3_MODES", "KODHIP_WGRAD_DMA", "KODHIP_WGRAD_SLOTS", "KODHIP_WGRAD_ROW3", "KODHIP_STEM_ROW",
+                "KODHIP_S2_INTERLEAVE", "KODHIP_ROW3", "KODHIP_ROW3_MODES", "KODHIP_WGRAD_DMA", "KODHIP_WGRAD_SLOTS", "KODHIP_WGRAD_ROW3", "KODHIP_STEM_ROW", "KODHIP_STEM_BWD_BLOCKS", "KODHIP_STEM_BWD_TW", "KODHIP_STEM_BWD_STREAM",
                 "KODHIP_LIB")
 
 
@@ -29,6 +29,7 @@ def _flag(name: str, default: bool) -> bool:
 @dataclass
 class EngineOptions:
     wgrad_overlap: bool = True        # KODHIP_WGRAD_OVERLAP: weight gradients on a side stream
+    wgrad_streams: int = 1            # KODHIP_WGRAD_STREAMS: side streams the weight gradients rotate over (a slab scratch each)
     wgrad_fork: str = "apply"         # KODHIP_WGRAD_FORK: "apply" (event where dY is ready, captured after the dgrad) | "legacy"
     branch_overlap: bool = True       # KODHIP_BRANCH_OVERLAP: CSP short_conv branches / P3-P4 heads on side streams
     comm_overlap: bool = True         # KODHIP_COMM_OVERLAP: gradient buckets on the weight-gradient stream, own communicator
@@ -38,6 +39,7 @@ class EngineOptions:
     bn_reduce_fused: bool = True      # KODHIP_NO_BNRED=1 switches off
     bn_reduce_min_k: int = 0          # KODHIP_BNRED_MINK
     dx_accum_fp32: bool = False       # KODHIP_DX_FP32: multi-consumer activation gradients accumulated in fp32
+    stem_bwd_fused: bool = True       # KODHIP_STEM_BWD_FUSED: the stem's BN/SiLU backward inside its weight gradient (dY never written)
     wgrad_reduce_batched: bool = False  # KODHIP_WGRAD_REDUCE=bucket: one slab-reduction launch per gradient bucket (slower: see DESIGN)
     debug_plan: bool = False          # KODHIP_DEBUG_PLAN
     max_shape_sets: int = 4           # KODHIP_MAX_SHAPE_SETS
@@ -49,6 +51,7 @@ class EngineOptions:
         e = os.environ
         return EngineOptions(
             wgrad_overlap=_flag("KODHIP_WGRAD_OVERLAP", True),
+            wgrad_streams=int(e.get("KODHIP_WGRAD_STREAMS", "1")),
             wgrad_fork=e.get("KODHIP_WGRAD_FORK", "apply"),
             branch_overlap=_flag("KODHIP_BRANCH_OVERLAP", True),
             comm_overlap=_flag("KODHIP_COMM_OVERLAP", True),
@@ -58,6 +61,7 @@ class EngineOptions:
             bn_reduce_fused=not _flag("KODHIP_NO_BNRED", False),
             bn_reduce_min_k=int(e.get("KODHIP_BNRED_MINK", "0")),
             dx_accum_fp32=_flag("KODHIP_DX_FP32", False),
+            stem_bwd_fused=_flag("KODHIP_STEM_BWD_FUSED", True),
             wgrad_reduce_batched=e.get("KODHIP_WGRAD_REDUCE", "layer") == "bucket",
             debug_plan=_flag("KODHIP_DEBUG_PLAN", False),
             max_shape_sets=int(e.get("KODHIP_MAX_SHAPE_SETS", "4")),

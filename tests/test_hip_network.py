@@ -178,6 +178,22 @@ def test_train_step_well_conditioned_batch():
         assert _rel(a, b) <= tol, (suffix, _rel(a, b))
 
 
+def _dY(eng, u):
+    """dY of a conv unit after backward (device, [B, Ho, Wo, C] bf16): st.raw holds it - except for a stem that ran the
+    fused backward (kodhip_stem_bwd_fused never writes dY; st.raw still holds y): there the stand-alone pass forms it from
+    the same dA / y / coefficients."""
+    from object_detection_cib_amd import _lib
+    st = eng.ustate[u.name]
+    if not st.stem_fused:
+        return st.raw
+    dy = st.raw.clone()
+    C_, aff, dA = u.cout, st.aff.data_ptr(), eng.gact[u.dst.buf.name]
+    _lib.check(_lib.lib().kodhip_bn_silu_bwd_apply(dA.data_ptr(), u.dst.buf.C, u.dst.coff, dy.data_ptr(), st.raw_ld,
+                                                   aff, aff + 4 * C_, st.coef.data_ptr(), None, 0, 0, 0, st.M, C_,
+                                                   torch.cuda.current_stream().cuda_stream), "bwd_apply")
+    return dy
+
+
 def test_bench_geometry_b64_640_deterministic_and_teacher_forced():
     """BASELINE configs[1] at its real batch: B=64, 640 px (M up to 6.55 M pixels: 256-pixel tiles, full split-K /
     statistic-slot geometry, exactly what bench.py times).  (1) two steps on the same batch give bit-identical
@@ -211,7 +227,7 @@ def test_bench_geometry_b64_640_deterministic_and_teacher_forced():
         X = bf(x) if u.stem else eng.act[u.src.buf.name][..., u.src.coff:u.src.coff + u.src.C].float().permute(0, 3, 1, 2).cpu()
         W = bf(params[u.name + ".0.weight"]).requires_grad_(True)
         y = F.conv2d(X, W, None, u.s, u.p)
-        dY = st.raw.float().permute(0, 3, 1, 2).cpu()
+        dY = _dY(eng, u).float().permute(0, 3, 1, 2).cpu()
         y.backward(dY)
         worst.setdefault("dW", 0.0)
         e = _rel(grads[u.name + ".0.weight"], W.grad)
@@ -349,7 +365,7 @@ def test_layers_teacher_forced(case):
         note("act", u.name, _rel(view(u.dst), out.detach()), 4e-3)
         dA = view(u.dst, True)
         out.backward(dA)
-        dY_hip = st.raw.float().permute(0, 3, 1, 2).cpu()
+        dY_hip = _dY(eng, u).float().permute(0, 3, 1, 2).cpu()
         note("dY", u.name, _rel(dY_hip, yb.grad), 1.5e-2)
         note("dgamma", u.name, _rel(grads[u.name + ".1.weight"], gamma.grad), 2e-2)
         note("dbeta", u.name, _rel(grads[u.name + ".1.bias"], beta.grad), 2e-2)
@@ -573,7 +589,7 @@ def test_multi_producer_dx_b64_640_vs_fp32_torch():
 
         def conv_dx(u):               # fp32 torch data gradient of one conv unit from the HIP path's bf16 dY and weights
             st = eng.ustate[u.name]
-            dY = st.raw.float().permute(0, 3, 1, 2).cpu()
+            dY = _dY(eng, u).float().permute(0, 3, 1, 2).cpu()
             W = bf(params[u.name + ".0.weight"])
             shape = (B, u.cin, st.H, st.W)
             return torch.nn.grad.conv2d_input(shape, W, dY, u.s, u.p)
@@ -652,6 +668,7 @@ def test_batched_wgrad_reduction_equals_per_layer_reduction():
         net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen)
         opts = EngineOptions.from_env()
         opts.wgrad_reduce_batched, opts.bucket_mb = batched, mb
+        opts.stem_bwd_fused = False       # (the batched form keeps the stem's two-launch backward: compare like with like)
         net.engine_options = opts
         net = net.cuda().train()
         _step(net, x.cuda(), tg, size, B)
@@ -663,6 +680,44 @@ def test_batched_wgrad_reduction_equals_per_layer_reduction():
     assert torch.isfinite(got["layer"]).all() and got["layer"].abs().sum() > 0
     for tag in ("bucket8", "bucket1", "one"):
         assert torch.equal(got[tag], got["layer"]), tag
+
+
+def test_schedule_switches_keep_the_gradients():
+    """Launch-schedule switches of the backward program against the default, one training step at 320 px:
+    * EngineOptions.wgrad_streams = 2 (weight gradients rotating over two side streams, a slab scratch each; measured slower,
+      DESIGN 4) - same kernels, same slabs: bit-identical gradients;
+    * EngineOptions.stem_bwd_fused = False (the stem's BatchNorm/SiLU backward as its own pass + the generic weight gradient
+      instead of kodhip_stem_bwd_fused) and the fused kernel on the weight-gradient stream instead of the main stream: only
+      the stem's weight gradient may differ, by fp32 summation order (same bf16 dY)."""
+    from object_detection_cib_amd.engine.options import EngineOptions
+    widen, deepen, nc, B, size, seed = 0.5, 0.33, 10, 4, 320, 11
+    x, tg = synth.batch(B, size, nc, seed)
+    got = {}
+    for tag in ("default", "streams2", "unfused", "fused_wg"):
+        torch.manual_seed(seed)
+        net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen)
+        opts = EngineOptions.from_env()
+        if tag == "streams2":
+            opts.wgrad_streams = 2
+        if tag == "unfused":
+            opts.stem_bwd_fused = False
+        if tag == "fused_wg":
+            opts.native = dict(opts.native, KODHIP_STEM_BWD_STREAM="wg")
+        net.engine_options = opts
+        net = net.cuda().train()
+        _step(net, x.cuda(), tg, size, B)
+        eng = net.engine()
+        assert eng.ustate["backbone.stem"].stem_fused == (tag != "unfused")
+        got[tag] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    for k, g in got["default"].items():
+        assert torch.isfinite(g).all()
+        assert torch.equal(got["streams2"][k], g), k
+        assert torch.equal(got["fused_wg"][k], g), k
+        if k == "backbone.stem.0.weight":
+            top = g.abs().max().item()
+            assert top > 0 and (got["unfused"][k] - g).abs().max().item() <= 1e-4 * top, k
+        else:
+            assert torch.equal(got["unfused"][k], g), k
 
 
 def test_yv5m_bench_geometry_b64_640_deterministic_and_teacher_forced():

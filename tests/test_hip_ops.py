@@ -167,6 +167,55 @@ def test_stem_conv():
     _close(gw.cpu(), wr.grad, 2e-3, 2e-3 * wr.grad.abs().max().item(), "stem wgrad")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 72, 32, 32, 0), (1, 16, 640, 32, 32, 0), (3, 12, 400, 16, 16, 0), (2, 8, 416, 32, 64, 16)])
+def test_stem_backward_fused(case):
+    """kodhip_stem_bwd_fused (BatchNorm/SiLU backward formed inside the stem's weight gradient, dY never written) against
+    the two launches it replaces (kodhip_bn_silu_bwd_apply + kodhip_conv_wgrad stem form - same dY rounding, other
+    summation order) and against torch on the dY those produce.  Rows of 36 / 320 / 200 / 208 pixel pairs: one ragged
+    tile, two full tiles, a full + a ragged tile; 16 output channels; dA as a channel slice of a wider buffer."""
+    B, H, W, Cout, lda, dacoff = case
+    g = torch.Generator().manual_seed(11 + H)
+    lib = _lib.lib()
+    x = bf(torch.rand(B, 3, H, W, generator=g))
+    img = torch.empty((B, H, W // 2, 8), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.kodhip_nchw_to_nhwc4(x.cuda().data_ptr(), img.data_ptr(), B, 3, H, W, stream()), "nhwc4")
+    Ho, Wo = H // 2, W // 2
+    M = B * Ho * Wo
+    y = torch.randn(M, Cout, generator=g).to(torch.bfloat16).cuda()
+    dA = torch.randn(M, lda, generator=g).to(torch.bfloat16).cuda()
+    scale = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    shift = (torch.randn(Cout, generator=g) * 0.3).cuda()
+    coef = torch.cat([torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.05,
+                      torch.randn(Cout, generator=g) * 0.05]).cuda()
+    # the fused kernel
+    blocks = lib.kodhip_stem_bwd_fused_blocks(B, H, Wo)
+    part = torch.full((blocks * 32 * 160,), float("nan"), dtype=torch.float32, device="cuda")
+    gw = torch.zeros((Cout, 3, 6, 6), dtype=torch.float32, device="cuda")
+    y_before = y.clone()
+    _lib.check(lib.kodhip_stem_bwd_fused(img.data_ptr(), dA.data_ptr(), lda, dacoff, y.data_ptr(), Cout,
+                                         scale.data_ptr(), shift.data_ptr(), coef.data_ptr(), part.data_ptr(), gw.data_ptr(),
+                                         B, H, Wo, Cout, 1.0, stream()), "stem_bwd_fused")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_before), "y must stay untouched"
+    # the two launches it replaces
+    dy = y.clone()
+    _lib.check(lib.kodhip_bn_silu_bwd_apply(dA.data_ptr(), lda, dacoff, dy.data_ptr(), Cout, scale.data_ptr(), shift.data_ptr(),
+                                            coef.data_ptr(), None, 0, 0, 0, M, Cout, stream()), "bwd_apply")
+    Kw = 160
+    splits = lib.kodhip_conv_wgrad_splits_geo(B, H, Wo, 8, 8, Cout, 6, 3, 2, 1, 2, 1, Kw, Cout)
+    part2 = torch.zeros(splits * Cout * Kw, dtype=torch.float32, device="cuda")
+    gw2 = torch.zeros_like(gw)
+    _lib.check(lib.kodhip_conv_wgrad(img.data_ptr(), dy.data_ptr(), part2.data_ptr(), gw2.data_ptr(), B, H, Wo, 8, 0,
+                                     8, Cout, 6, 3, 2, 1, 2, 1, Kw, Cout, 0, Cout, 1, 1.0, stream()), "stem wgrad")
+    torch.cuda.synchronize()
+    top = gw2.abs().max().item()
+    _close(gw.cpu(), gw2.cpu(), 1e-4, 2e-5 * top, "fused vs two launches")
+    # and torch's convolution weight gradient on that dY
+    wr = torch.zeros(Cout, 3, 6, 6, requires_grad=True)
+    F.conv2d(x, wr, None, 2, 2).backward(dy.float().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2))
+    _close(gw.cpu(), wr.grad, 2e-3, 2e-3 * wr.grad.abs().max().item(), "fused vs torch")
+
+
 def test_head_conv_fwd_bwd():
     g = torch.Generator().manual_seed(3)
     B, C, H, W, A, nc = 2, 128, 8, 8, 3, 10

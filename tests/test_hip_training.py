@@ -223,16 +223,24 @@ def test_first_epoch_map_vs_cpu_trainer(golden):
         assert np.isfinite(hip).all()
         rel = np.abs(hip - cpu) / np.abs(cpu)
         assert rel[:5].max() < 1e-2 and rel[:50].max() < 5e-2, (switches, rel[:5], rel[:50].max())
+        # per-fifth means of the loss: the trajectories separate as the epoch goes on (chaotic dynamics; the eight HIP
+        # summation-order variants of profiles/r03_first_epoch_samples.txt end between 2.745 and 2.859, the three CPU
+        # trajectories of the fixture between 2.755 and 2.781), so a single run is held to 2 % over the first three fifths,
+        # 3 % in the fourth, 5 % in the last - and the MEAN of the three runs' last fifths to 3 % below
         fifth = n_batches // 5
         for k in range(5):
             a, b = hip[k * fifth:(k + 1) * fifth].mean(), cpu[k * fifth:(k + 1) * fifth].mean()
-            assert abs(a - b) <= 3e-2 * b, (switches, k, a, b)
+            assert abs(a - b) <= (2e-2, 2e-2, 2e-2, 3e-2, 5e-2)[k] * b, (switches, k, a, b)
+        last_fifths.append(hip[4 * fifth:].mean())
         rep = exp.validate(vb, nc)
         del exp, pipe
         torch.cuda.empty_cache()
         return np.array([rep[k] for k in keys])
 
+    last_fifths = []
     runs = np.stack([hip_epoch(), hip_epoch(dual_dgrad=False), hip_epoch(bn_reduce_fused=False)])
+    cpu_last = np.mean([g[k][4 * (n_batches // 5):, 3].mean() for k in ("losses_fp32", "losses_fp32_alt", "losses_bf16emu")])
+    assert abs(np.mean(last_fifths) - cpu_last) <= 3e-2 * cpu_last, (last_fifths, cpu_last)
     hmean = runs.mean(0)
     print("first-epoch mAP  HIP runs:", [{k: round(float(v), 4) for k, v in zip(keys[:3], r)} for r in runs],
           " HIP mean:", {k: round(float(v), 4) for k, v in zip(keys[:3], hmean)},
