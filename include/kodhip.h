@@ -143,6 +143,14 @@ int kodhip_wgrad_reduce_blocks(int n_valid, int K);
 int kodhip_wgrad_reduce_batched(const float* partials, float* grads, const void* descs /* device KodWgradReduceDesc[n] */,
                                 int n_desc, int total_blocks, kodStream_t stream);
 
+/* Weight gradients of TWO pointwise layers with the same input (a CSP layer's main_conv and short_conv,
+ * kod/nn/layers/csp.py:85-99) in one launch + one reduction: the shared input is streamed from HBM once.  dy1 / dy2:
+ * [B*H*W][ldy] (+ycoff, N channels each); partials: kodhip_conv_wgrad_dual_splits(...) * 2N * Kp floats; grad1 / grad2: fp32
+ * [N][Cin].  kodhip_conv_wgrad_dual_splits returns 0 where the form does not apply (then: two kodhip_conv_wgrad launches). */
+int kodhip_conv_wgrad_dual_splits(int B, int H, int W, int ldx, int Cin, int N, int Kp, int ldy);
+int kodhip_conv_wgrad_dual(const void* x, const void* dy1, const void* dy2, float* partials, float* grad1, float* grad2,
+                           int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
+                           float scale, kodStream_t stream);
 /* The stem's whole backward in one kernel + the slab reduction: dY = k1 * dA * silu'(y * scale + shift) + k2 * y + k3 is
  * formed on the fly and multiplied into dW; dY is never written (the stem - kod/nn/backbones/yolov5.py:44-52, 6x6 / stride 2
  * / pad 2 on the image - has no data gradient, so the weight gradient is dY's only reader).  Replaces

@@ -27,6 +27,10 @@ struct WgradArgs {
   int tiles_n, tiles_k;
   uint32_t magic_cin, magic_kw;
   uint32_t magic_hwo, magic_wo;      // ceil(2^32 / d); 0 encodes d == 1
+  // dual form (kodhip_conv_wgrad_dual): two layers with the same input, N = 2 * n_half slab rows; n tiles of the second
+  // half take their dY from dy2.  n_half = 0: one layer
+  const bf16_t* dy2;
+  int n_half;
 };
 
 __host__ __device__ constexpr int row_bytes(int T) { return (T * 2) % 128 == 0 ? T * 2 + 64 : T * 2; }
@@ -251,7 +255,13 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
   const int tile = j % tiles;
   const int split = (j / tiles) * 8 + xcd;
   if (split >= a.splits) return;
-  const int n0 = (tile % a.tiles_n) * TNB;
+  // slab rows n0 .. of this block; dY columns ny0 .. of its layer (dual form: the second half of the n tiles reads dy2)
+  const int nt = tile % a.tiles_n;
+  const bool half2 = a.n_half && nt >= (a.tiles_n >> 1);
+  const int n0 = half2 ? a.n_half + (nt - (a.tiles_n >> 1)) * TNB : nt * TNB;
+  const int ny0 = half2 ? n0 - a.n_half : n0;
+  const int ny_hi = a.n_half ? a.n_half : a.N;                       // dY columns of one layer
+  const int n_hi = (a.n_half && !half2) ? a.n_half : a.N;            // slab rows this block may write
   const int k0 = (tile / a.tiles_n) * TKB;
   const int m_begin = split * a.m_per_split;
   int m_end = m_begin + a.m_per_split;
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
 
 #if defined(__HIP_DEVICE_COMPILE__)
   __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, dy_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(half2 ? a.dy2 : a.dy), 0, dy_bytes, 0x00020000);
 #endif
 
   // ---- per-lane constants of this wave's DMA slots: instruction t = wave + i*NW; t < NIY feeds the dY tile, else X.
@@ -286,8 +296,8 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
       const int row = L / RBY, pc = (L % RBY) >> 4;
       const int c = pc ^ swz(row, MY);
       s_row[i] = row;
-      s_ok[i] = (n0 + c * 8) < a.N;
-      s_off[i] = (uint32_t)(((long)(m_begin + row) * a.ldy + a.ycoff + n0 + c * 8) * 2);
+      s_ok[i] = (ny0 + c * 8) < ny_hi;
+      s_off[i] = (uint32_t)(((long)(m_begin + row) * a.ldy + a.ycoff + ny0 + c * 8) * 2);
     } else {
       const int L = (t - NIY) * 1024 + lane * 16;
       const int row = L / RBX, pc = (L % RBX) >> 4;
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         int n = n0 + (wn * RN + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-        if (n < a.N && k < a.Kp) slab[(size_t)n * a.Kp + k] = acc[i][jj][e];
+        if (n < n_hi && k < a.Kp) slab[(size_t)n * a.Kp + k] = acc[i][jj][e];
       }
     }
 }
@@ -723,7 +733,7 @@ __global__ __launch_bounds__(64 * WN * 3 * WC) void conv_wgrad_row3_kernel(Wgrad
 constexpr int RED_K = 32, RED_L = 8;    // measured: 16x16 0.65 ms, 32x8 0.45 ms, 64x4 0.50 ms, 128x2 0.71 ms per step
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* grad, int splits, int Nfull,
                                                            int N, int K, int Kp, int Cin, int KK, int stem,
-                                                           float scale) {
+                                                           float scale, float* grad2 = nullptr, int n_first = 1 << 30) {
   __shared__ float sm[RED_L][RED_K + 1];
   const int kx = threadIdx.x % RED_K, sl = threadIdx.x / RED_K;
   const long idx = (long)blockIdx.x * RED_K + kx;
@@ -760,7 +770,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     } else {
       int tap = k / Cin;
       int ci = k - tap * Cin;
-      grad[(size_t)n * Cin * KK + ci * KK + tap] = t * scale;
+      float* dst = n >= n_first ? grad2 : grad;          // dual form: slab rows n_first .. belong to the second layer
+      if (n >= n_first) n -= n_first;
+      dst[(size_t)n * Cin * KK + ci * KK + tap] = t * scale;
     }
   }
 }
@@ -840,7 +852,7 @@ constexpr int WGRAD_ROWS = WG_RS;        // reduction rows per ring stage
 template <int WN, int WK, int RN, int RK>
 int launch_cfg(WgradArgs a, hipStream_t stream) {
   constexpr int TNB = WN * RN * 32, TKB = WK * RK * 32;
-  a.tiles_n = cdiv(a.N, TNB);
+  a.tiles_n = a.n_half ? 2 * cdiv(a.n_half, TNB) : cdiv(a.N, TNB);
   a.tiles_k = cdiv(a.Kp, TKB);
   int grid = cdiv(a.splits, 8) * 8 * a.tiles_n * a.tiles_k;
   // LDS-DMA ring by default: +4-5 % on the whole training step over the register-staged kernel (in the network the
@@ -1211,6 +1223,76 @@ int kodhip_conv_wgrad_partial(const void* x, const void* dy, float* partials,
                               int ldy, int ycoff, hipStream_t stream) {
   WgradArgs a;
   return wgrad_partial(a, x, dy, partials, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, stream);
+}
+
+// Weight gradients of TWO pointwise (1x1 / stride 1) layers that read the same input - a CSP layer's main_conv and
+// short_conv (kod/nn/layers/csp.py:85-99) - in one launch + one reduction: N slab rows per layer, the second layer's n tiles
+// take dY from dy2.  Blocks of one split share an XCD, so the input tile a split streams is fetched from HBM once for
+// both layers (these launches are HBM-bound: 64 -> 32 @160 moves 315 MB per layer, 210 MB of it the shared input).
+// kodhip_conv_wgrad_dual_splits: slab count (partials: splits * 2N * Kp floats), 0 when the form does not apply (operands
+// beyond the 32-bit buffer range, KODHIP_WGRAD_DMA=none) - the caller then launches kodhip_conv_wgrad twice.
+static bool wgrad_dual_ok(long M, int B, int H, int W, int ldx, int ldy) {
+  static const char* mode = getenv("KODHIP_WGRAD_DMA");
+  const long xb = (long)B * H * W * ldx * 2, yb = M * ldy * 2;
+  return !(mode && mode[0] == 'n') && xb < (1l << 32) - 64 && yb < (1l << 32) - 64;
+}
+
+static int wgrad_rows_per_split_dual(long M, int N, int Kp) {
+  int tn, tk;
+  tile_shape(N, Kp, &tn, &tk);
+  const int tiles = 2 * cdiv(N, tn) * cdiv(Kp, tk);
+  static int slots = 0;
+  if (!slots) { const char* e = getenv("KODHIP_WGRAD_SLOTS"); slots = e ? atoi(e) : 512; if (slots < 8) slots = 512; }
+  int s = slots / tiles;
+  if (s < 1) s = 1;
+  const long maxs = (M + 255) / 256;
+  if (s > maxs) s = (int)maxs;
+  if (s < 1) s = 1;
+  return cdiv(cdiv(M, s), 32) * 32;
+}
+
+int kodhip_conv_wgrad_dual_splits(int B, int H, int W, int ldx, int Cin, int N, int Kp, int ldy) {
+  (void)Cin;
+  const long M = (long)B * H * W;
+  if (!wgrad_dual_ok(M, B, H, W, ldx, ldy)) return 0;
+  return (int)cdiv(M, (long)wgrad_rows_per_split_dual(M, N, Kp));
+}
+
+int kodhip_conv_wgrad_dual(const void* x, const void* dy1, const void* dy2, float* partials, float* grad1, float* grad2,
+                           int B, int H, int W, int ldx, int xcoff, int Cin, int N, int Kp, int ldy, int ycoff,
+                           float scale, hipStream_t stream) {
+  KOD_CHECK_ARG(x && dy1 && dy2 && partials && grad1 && grad2, "conv_wgrad_dual: null pointer");
+  KOD_CHECK_ARG(Cin % 8 == 0 && ldx % 8 == 0 && xcoff % 8 == 0 && xcoff + Cin <= ldx, "conv_wgrad_dual: bad input slice");
+  KOD_CHECK_ARG(N % 8 == 0 && ldy % 8 == 0 && ycoff % 8 == 0 && ycoff + N <= ldy, "conv_wgrad_dual: bad dy slice (N=%d ldy=%d)", N, ldy);
+  KOD_CHECK_ARG(Kp % 32 == 0 && Kp >= Cin, "conv_wgrad_dual: bad Kp");
+  const long M = (long)B * H * W;
+  KOD_CHECK_ARG(M < (1l << 31), "conv_wgrad_dual: pixel count overflows int32");
+  KOD_CHECK_ARG(wgrad_dual_ok(M, B, H, W, ldx, ldy), "conv_wgrad_dual: not available for this geometry (kodhip_conv_wgrad_dual_splits == 0)");
+  WgradArgs a = {};
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy1; a.dy2 = (const bf16_t*)dy2; a.part = partials;
+  a.B = B; a.Hs = H; a.Ws = W; a.ldx = ldx; a.xcoff = xcoff; a.Cin = Cin;
+  a.Ho = H; a.Wo = W; a.M = (int)M; a.N = 2 * N; a.n_half = N; a.K = Cin; a.Kp = Kp;
+  a.KH = a.KW = a.SH = a.SW = 1; a.PH = a.PW = 0; a.ldy = ldy; a.ycoff = ycoff;
+  a.magic_cin = magic_u32((uint32_t)Cin); a.magic_kw = magic_u32(1u);
+  a.magic_hwo = magic_u32((uint32_t)(H * W)); a.magic_wo = magic_u32((uint32_t)W);
+  a.m_per_split = wgrad_rows_per_split_dual(M, N, Kp);
+  a.splits = cdiv(M, a.m_per_split);
+  int tn, tk, rc;
+  tile_shape(N, Kp, &tn, &tk);
+  if (tn == 128 && tk == 128) rc = launch_cfg<2, 2, 2, 2>(a, stream);
+  else if (tn == 64 && tk == 128) rc = launch_cfg<2, 2, 1, 2>(a, stream);
+  else if (tn == 32 && tk == 128) rc = launch_cfg<1, 4, 1, 1>(a, stream);
+  else if (tn == 128 && tk == 64) rc = launch_cfg<2, 2, 2, 1>(a, stream);
+  else if (tn == 64 && tk == 64) rc = launch_cfg<2, 2, 1, 1>(a, stream);
+  else if (tn == 32 && tk == 64) rc = launch_cfg<1, 2, 1, 1>(a, stream);
+  else if (tn == 128 && tk == 32) rc = launch_cfg<4, 1, 1, 1>(a, stream);
+  else if (tn == 64 && tk == 32) rc = launch_cfg<2, 1, 1, 1>(a, stream);
+  else rc = launch_cfg<1, 1, 1, 1>(a, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(2 * N * a.K, RED_K)), dim3(256), 0, stream,
+                     (const float*)partials, grad1, a.splits, 2 * N, 2 * N, a.K, Kp, Cin, 1, 0, scale, grad2, N);
+  KOD_LAUNCH_CHECK("wgrad_reduce (dual)");
+  return KOD_OK;
 }
 
 // The stem's BatchNorm/SiLU backward + weight gradient as one kernel (conv_stem_bwd_fused_kernel) followed by the slab

@@ -94,6 +94,10 @@ class BackwardMixin:
                 fa = list(args[2:])
                 fa[9] += args[1]
                 chk(lib.kodhip_stem_bwd_fused(*fa, sid), name + ".bwd_fused")
+            elif args[0] == "dual":           # ("dual", region offset, kodhip_conv_wgrad_dual's arguments)
+                fa = list(args[2:])
+                fa[3] += args[1]
+                chk(lib.kodhip_conv_wgrad_dual(*fa, sid), name + ".wgrad2")
             elif batched:
                 chk(lib.kodhip_conv_wgrad_partial(*args[:3], *args[4:-3], sid), name + ".wgrad")
             else:
@@ -107,13 +111,16 @@ class BackwardMixin:
                 rr[0] += 1
                 if k:
                     args = list(args)
-                    args[1 if args[0] == "stem" else 2] += 4 * k * self._wg_region
+                    args[1 if isinstance(args[0], str) else 2] += 4 * k * self._wg_region
                 wgs[k].wait_event(ev)
                 launch_wgrad(name, nbytes, args, wgs[k])
             deferred.clear()
-            if due:
+            if due and not hold[0]:
                 self._launch_due()
         self._flush_wgrads = flush_wgrads
+        # a short_conv whose weight gradient waits for its main_conv's dual launch: no gradient bucket may be enqueued meanwhile
+        hold = [False]
+        self._wg_hold = hold
 
         def timed_wgrad(name, nbytes, *args):
             if defer:
@@ -220,7 +227,7 @@ class BackwardMixin:
             unit_i -= 1
             if (batched and unit_i in self.red_groups) or unit_i in buckets:
                 due.append(unit_i)
-                if not deferred:
+                if not deferred and not hold[0]:
                     launch_due()
 
         def bn_bwd_stats(group):
@@ -358,7 +365,8 @@ class BackwardMixin:
                 for u in group:
                     self._bwd_unit(u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad,
                                    dgrad="skip" if (dual and u is group[0]) else ("dual" if dual else "own"),
-                                   partner=group[0] if dual else None)
+                                   partner=group[0] if dual else None,
+                                   dual_w=dual and self.ustate[group[1].name].wg_dual > 0)
                     bucket_tick()
                 continue
             # gradient buckets complete from the arena's end toward its start
@@ -374,7 +382,7 @@ class BackwardMixin:
             return [self.gact[v.buf.name][..., v.coff:v.coff + v.C].permute(0, 3, 1, 2).float() if v.buf.name in touched
                     else torch.zeros((B, v.C, H // v.stride, W // v.stride), device=self.device) for v in self.g.inputs]
 
-    def _bwd_unit(self, u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad, dgrad="own", partner=None):
+    def _bwd_unit(self, u, B, H, W, s, gp, pa, dp, wgp, acc_flag, timed_wgrad, dgrad="own", partner=None, dual_w=False):
         """bn/silu backward apply -> data gradient -> weight gradient of one conv unit (coefficients already in st.coef).
         dgrad: "own" = this unit's launch; "skip" = none (a fused short_conv: its main_conv's launch covers it);
         "dual" = one launch for this unit and `partner` (kodhip_conv_dgrad_dual)."""
@@ -421,6 +429,9 @@ class BackwardMixin:
         else:
             geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p)
             fz = () if st.segs is None else (C.cast(st.segs, C.c_void_p), len(st.segs), st.seg_slots)
+            if dgrad == "skip" and dual_w:          # its weight gradient rides in the main_conv's dual launch
+                self._wg_hold[0] = True
+                return
             if dgrad == "skip":
                 timed_wgrad(u.name, 2.0 * (B * st.H * st.W * u.cin + st.M * C_),
                             self._ptr(u.src), st.raw.data_ptr(), wgp + 4 * st.wg_off, gp + 4 * st.w_off,
@@ -454,6 +465,15 @@ class BackwardMixin:
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
                        *geo, st.Kdp, C_, 0, acc_src, fptr, *fz, s), u.name + ".dgrad")
             self._t1(e0, "dgrad" if st.segs is None else "dgrad+bn_reduce", nb)
+        if dgrad == "dual" and dual_w:
+            ps = self.ustate[partner.name]
+            self._wg_hold[0] = False
+            timed_wgrad(u.name + "+" + partner.name, 2.0 * (B * st.H * st.W * u.cin + 2 * st.M * C_),
+                        "dual", 0, self._ptr(u.src), st.raw.data_ptr(), ps.raw.data_ptr(), wgp + 4 * st.wg_off,
+                        gp + 4 * st.w_off, gp + 4 * ps.w_off, B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, st.Kp,
+                        st.raw_ld, 0, 1.0)
+            self._flush_wgrads()
+            return
         cin_true = 3 if u.stem else u.cin
         in_px_w = B * H * W if u.stem else B * st.H * st.W
         timed_wgrad(u.name, 2.0 * (in_px_w * cin_true + st.M * C_),

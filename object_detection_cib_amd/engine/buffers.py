@@ -25,7 +25,7 @@ from .plan import backward_writes, plan_f32_accumulation, plan_dual_dgrads, plan
 class BufferMixin:
     # ------------------------------------------------------------------ activations
     _UNIT_FIELDS = ("stats", "T", "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho",
-                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld", "wg_splits", "wg_off", "stem_fused")
+                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld", "wg_splits", "wg_off", "stem_fused", "wg_dual")
     _HEAD_FIELDS = ("H", "W", "M", "dy", "ws", "wg_splits", "wg_off")
 
     def _export_set(self) -> dict:
@@ -121,6 +121,15 @@ class BufferMixin:
             st.wg_off = max_part if own else 0
             max_part = max_part + _pad(nslab) if own else max(max_part, nslab)
         self._plan_bn_fusion(B)
+        # a dual pair's weight gradients as one launch (kodhip_conv_wgrad_dual): slab rows for both layers
+        for u in self.exec_units:
+            self.ustate[u.name].wg_dual = 0
+        if self.opt.dual_wgrad and not own:
+            for mname in self._dual:
+                st = self.ustate[mname]
+                u = st.u
+                st.wg_dual = lib.kodhip_conv_wgrad_dual_splits(B, st.H, st.W, u.src.buf.C, u.cin, u.cout, st.Kp, st.raw_ld)
+                max_part = max(max_part, st.wg_dual * 2 * u.cout * st.Kp)
         self.gact32 = {}
         if self._f32plan is not None:
             for name in self._f32plan.shadow_bufs:

@@ -39,6 +39,7 @@ class EngineOptions:
     bn_reduce_fused: bool = True      # KODHIP_NO_BNRED=1 switches off
     bn_reduce_min_k: int = 0          # KODHIP_BNRED_MINK
     dx_accum_fp32: bool = False       # KODHIP_DX_FP32: multi-consumer activation gradients accumulated in fp32
+    dual_wgrad: bool = True           # KODHIP_NO_DUAL_WGRAD=1 switches off: a CSP layer's main + short weight gradients in one launch
     stem_bwd_fused: bool = True       # KODHIP_STEM_BWD_FUSED: the stem's BN/SiLU backward inside its weight gradient (dY never written)
     wgrad_reduce_batched: bool = False  # KODHIP_WGRAD_REDUCE=bucket: one slab-reduction launch per gradient bucket (slower: see DESIGN)
     debug_plan: bool = False          # KODHIP_DEBUG_PLAN
@@ -61,6 +62,7 @@ class EngineOptions:
             bn_reduce_fused=not _flag("KODHIP_NO_BNRED", False),
             bn_reduce_min_k=int(e.get("KODHIP_BNRED_MINK", "0")),
             dx_accum_fp32=_flag("KODHIP_DX_FP32", False),
+            dual_wgrad=not _flag("KODHIP_NO_DUAL_WGRAD", False),
             stem_bwd_fused=_flag("KODHIP_STEM_BWD_FUSED", True),
             wgrad_reduce_batched=e.get("KODHIP_WGRAD_REDUCE", "layer") == "bucket",
             debug_plan=_flag("KODHIP_DEBUG_PLAN", False),

@@ -688,12 +688,13 @@ def test_schedule_switches_keep_the_gradients():
       DESIGN 4) - same kernels, same slabs: bit-identical gradients;
     * EngineOptions.stem_bwd_fused = False (the stem's BatchNorm/SiLU backward as its own pass + the generic weight gradient
       instead of kodhip_stem_bwd_fused) and the fused kernel on the weight-gradient stream instead of the main stream: only
-      the stem's weight gradient may differ, by fp32 summation order (same bf16 dY)."""
+      the stem's weight gradient may differ, by fp32 summation order (same bf16 dY);
+    * EngineOptions.dual_wgrad = False: see the end of the test."""
     from object_detection_cib_amd.engine.options import EngineOptions
     widen, deepen, nc, B, size, seed = 0.5, 0.33, 10, 4, 320, 11
     x, tg = synth.batch(B, size, nc, seed)
     got = {}
-    for tag in ("default", "streams2", "unfused", "fused_wg"):
+    for tag in ("default", "streams2", "unfused", "fused_wg", "single_wgrads"):
         torch.manual_seed(seed)
         net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen)
         opts = EngineOptions.from_env()
@@ -703,11 +704,15 @@ def test_schedule_switches_keep_the_gradients():
             opts.stem_bwd_fused = False
         if tag == "fused_wg":
             opts.native = dict(opts.native, KODHIP_STEM_BWD_STREAM="wg")
+        if tag == "single_wgrads":
+            opts.dual_wgrad = False
         net.engine_options = opts
         net = net.cuda().train()
         _step(net, x.cuda(), tg, size, B)
         eng = net.engine()
         assert eng.ustate["backbone.stem"].stem_fused == (tag != "unfused")
+        n_dual = sum(1 for st in eng.ustate.values() if st.wg_dual > 0)
+        assert n_dual == (0 if tag == "single_wgrads" else 8), n_dual
         got[tag] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
     for k, g in got["default"].items():
         assert torch.isfinite(g).all()
@@ -718,6 +723,13 @@ def test_schedule_switches_keep_the_gradients():
             assert top > 0 and (got["unfused"][k] - g).abs().max().item() <= 1e-4 * top, k
         else:
             assert torch.equal(got["unfused"][k], g), k
+        # EngineOptions.dual_wgrad = False: a CSP layer's main_conv / short_conv weight gradients as two launches instead
+        # of kodhip_conv_wgrad_dual - other split-K boundaries for those sixteen tensors, everything else untouched
+        if k.endswith(("main_conv.0.weight", "short_conv.0.weight")):
+            top = g.abs().max().item()
+            assert (got["single_wgrads"][k] - g).abs().max().item() <= 1e-4 * top + 1e-7, k
+        else:
+            assert torch.equal(got["single_wgrads"][k], g), k
 
 
 def test_yv5m_bench_geometry_b64_640_deterministic_and_teacher_forced():

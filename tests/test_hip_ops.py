@@ -216,6 +216,39 @@ def test_stem_backward_fused(case):
     _close(gw.cpu(), wr.grad, 2e-3, 2e-3 * wr.grad.abs().max().item(), "fused vs torch")
 
 
+@pytest.mark.parametrize("case", [(2, 64, 40, 40, 32), (3, 128, 20, 12, 64), (2, 256, 16, 16, 128), (1, 512, 8, 8, 256),
+                                  (2, 96, 12, 10, 48), (4, 64, 160, 160, 32)])
+def test_conv_wgrad_dual(case):
+    """kodhip_conv_wgrad_dual (a CSP layer's main_conv + short_conv weight gradients in one launch over the shared input)
+    against fp32 torch and against two kodhip_conv_wgrad launches; x as a channel slice of a wider buffer; every n-tile
+    shape (32 / 64 / 128 columns per layer, two tiles per layer for 256), a 48-channel pair (n tiles wider than a layer:
+    the first layer's tile must not write into the second layer's slab rows)."""
+    B, Cin, H, W, N = case
+    g = torch.Generator().manual_seed(sum(case))
+    lib = _lib.lib()
+    ldx, xcoff = Cin + 32, 16
+    xb = torch.randn(B, H, W, ldx, generator=g).to(torch.bfloat16).cuda()
+    dy = [torch.randn(B * H * W, N, generator=g).to(torch.bfloat16).cuda() for _ in range(2)]
+    Kp = pad(Cin, 32)
+    sp = lib.kodhip_conv_wgrad_dual_splits(B, H, W, ldx, Cin, N, Kp, N)
+    assert sp > 0
+    part = torch.full((sp * 2 * N * Kp,), float("nan"), dtype=torch.float32, device="cuda")
+    gw = [torch.zeros(N, Cin, dtype=torch.float32, device="cuda") for _ in range(2)]
+    _lib.check(lib.kodhip_conv_wgrad_dual(xb.data_ptr(), dy[0].data_ptr(), dy[1].data_ptr(), part.data_ptr(), gw[0].data_ptr(),
+                                          gw[1].data_ptr(), B, H, W, ldx, xcoff, Cin, N, Kp, N, 0, 1.0, stream()), "wgrad_dual")
+    torch.cuda.synchronize()
+    X = xb[..., xcoff:xcoff + Cin].float().reshape(-1, Cin).cpu().double()
+    for i in range(2):
+        want = (dy[i].float().cpu().double().t() @ X).float()
+        _close(gw[i].cpu(), want, 2e-3, 2e-3 * want.abs().max().item(), f"dual wgrad layer {i} vs torch")
+        sp1 = lib.kodhip_conv_wgrad_splits_geo(B, H, W, ldx, Cin, N, 1, 1, 1, 1, 0, 0, Kp, N)
+        p1 = torch.zeros(sp1 * N * Kp, dtype=torch.float32, device="cuda")
+        g1 = torch.zeros(N, Cin, dtype=torch.float32, device="cuda")
+        _lib.check(lib.kodhip_conv_wgrad(xb.data_ptr(), dy[i].data_ptr(), p1.data_ptr(), g1.data_ptr(), B, H, W, ldx, xcoff, Cin,
+                                         N, 1, 1, 1, 1, 0, 0, Kp, N, 0, N, 0, 1.0, stream()), "wgrad")
+        _close(gw[i].cpu(), g1.cpu(), 1e-4, 2e-5 * want.abs().max().item(), f"dual wgrad layer {i} vs single launch")
+
+
 def test_head_conv_fwd_bwd():
     g = torch.Generator().manual_seed(3)
     B, C, H, W, A, nc = 2, 128, 8, 8, 3, 10
