@@ -24,6 +24,42 @@ __device__ __forceinline__ double wave_sum_partials(const float* p, int T, int l
   return wave_sum_d((a0 + a1) + (a2 + a3));
 }
 
+// Two such sums (a channel's two moments) with ALL loads issued before the first add: called one after the other, the
+// second sum's loads would start behind the first sum's shuffle reduction - a second memory round trip in a kernel that
+// is nothing but latency.  Same order of additions as wave_sum_partials (bit-identical results).
+__device__ __forceinline__ void wave_sum_partials2(const float* p, const float* q, int T, int lane, double& sp, double& sq) {
+  const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+  if (!al || T > 4 * 256) {               // unaligned rows / more than the four unrolled passes (1024 slots): the plain form
+    sp = wave_sum_partials(p, T, lane);
+    sq = wave_sum_partials(q, T, lane);
+    return;
+  }
+  const int T4 = T & ~3;
+  const int t0 = lane * 4, t1 = t0 + 256 * 1, t2 = t0 + 256 * 2, t3 = t0 + 256 * 3;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pv[4], qv[4];
+  const int ts[4] = {t0, t1, t2, t3};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pv[i] = ts[i] < T4 ? *reinterpret_cast<const f32x4*>(p + ts[i]) : z;
+    qv[i] = ts[i] < T4 ? *reinterpret_cast<const f32x4*>(q + ts[i]) : z;
+  }
+  float pt = 0.f, qt = 0.f;
+  const bool tail = T4 + lane < T;
+  if (tail) { pt = p[T4 + lane]; qt = q[T4 + lane]; }
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (ts[i] < T4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] += (double)pv[i][e]; b[e] += (double)qv[i][e]; }
+    }
+  }
+  if (tail) { a[0] += (double)pt; b[0] += (double)qt; }
+  sp = wave_sum_d((a[0] + a[1]) + (a[2] + a[3]));
+  sq = wave_sum_d((b[0] + b[1]) + (b[2] + b[3]));
+}
+
 // ---------------------------------------------------------------- SyncBN over peer buffers
 // One wave per channel holds the rank's two fp64 sums (s0, s1) in lane 0: publish them as four granules in the rank's
 // own exchange buffer, then poll the same four granules of EVERY rank (lane = 4 * rank + granule) and add the ranks'
@@ -117,7 +153,8 @@ __global__ void bn_finalize_fused_kernel(const float* part, int T, double count,
   // trip in a kernel that is nothing but latency (one wave per channel, 57 launches on the critical chain)
   const float g = gamma[c], b = beta[c];
   const float rm0 = update_running ? running_mean[c] : 0.f, rv0 = update_running ? running_var[c] : 0.f;
-  double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
+  double s0, s1;
+  wave_sum_partials2(p0, p1, T, lane, s0, s1);
   if constexpr (PEER) peer_allreduce2(pv, slot, c, C + c, lane, s0, s1);
   if (lane != 0) return;
   double mean = s0 / count;
@@ -146,7 +183,8 @@ __device__ __forceinline__ void bn_bwd_coeffs_channel(const float* part, int T, 
   const float* p0 = part + (size_t)c * T;
   const float* p1 = part + (size_t)(C + c) * T;
   const float g_ = gamma[c], rs_ = rstd[c], mu_ = mean[c];      // up front: not a second round trip behind the reduction
-  double s0 = wave_sum_partials(p0, T, lane), s1 = wave_sum_partials(p1, T, lane);
+  double s0, s1;
+  wave_sum_partials2(p0, p1, T, lane, s0, s1);
   if (raw_moment) s1 = (double)rs_ * (s1 - (double)mu_ * s0);      // (linear in the sums: ranks may add converted values)
   if (lane == 0) {          // parameter gradients keep the rank's own sums (the gradient all-reduce adds the ranks later)
     dbeta[c] = (float)s0;
