@@ -173,7 +173,8 @@ def test_first_epoch_map_vs_cpu_trainer(golden):
     batches (the device compositing kernel is bit-exact against the CPU protocol), bf16 activation storage.
     The two trajectories decorrelate after a few hundred steps (chaos, not error), so the bars are epoch-level:
       * per-step total loss within 1e-2 rel over the first 5 steps, 5e-2 over the first 50;
-      * mean total loss of each fifth of the epoch within 3e-2 rel;
+      * mean total loss of each fifth of the epoch: 2e-2 rel for the first three, 3e-2 / 5e-2 for the last two, 3e-2 for the
+        mean of the three runs' last fifths (see the comment at the check);
       * mAP / mAP30 / mAP50: first-epoch mAP is a NOISY statistic of a chaotic trajectory.  The fixture holds TWELVE CPU
         runs of this very epoch (seven fp32 runs under different torch thread counts = summation orders, five runs of the
         bf16-storage emulation): mAP50 0.064 .. 0.094, mean 0.076, sigma 0.011.  The HIP trainer is run THREE times here,
@@ -181,8 +182,8 @@ def test_first_epoch_map_vs_cpu_trainer(golden):
         separate BatchNorm-backward reduce pass - EngineOptions, no other difference), and the MEAN of the three must lie
         within mean +- 2 sigma of the CPU samples, every single run within +- 4 sigma.  (Round 3, 16 HIP epochs over
         eight kernel variants x {bf16, fp32} accumulation of multi-producer activation gradients,
-        profiles/r03_first_epoch_samples.txt: HIP mean mAP50 0.072 vs CPU 0.076 - z = -1.0, no detectable deficit - and
-        fp32 accumulation changes nothing, 0.0722 vs 0.0724.  Evaluating HIP-trained weights with the CPU oracle's eval
+        profiles/r03_first_epoch_samples.txt: HIP mean mAP50 0.072 vs CPU 0.076 - z = -0.8, no detectable deficit - and
+        fp32 accumulation does not help: 0.0724 vs 0.0722 in one sample of eight pairs, 0.0595 vs 0.0723 in the other.  Evaluating HIP-trained weights with the CPU oracle's eval
         pipeline reproduces the HIP mAP to 1e-4: validation itself is exact - DESIGN section 5.)"""
     from oracle import first_epoch as FE
     from object_detection_cib_amd.data.detection import DetectionTarget
@@ -224,7 +225,7 @@ def test_first_epoch_map_vs_cpu_trainer(golden):
         rel = np.abs(hip - cpu) / np.abs(cpu)
         assert rel[:5].max() < 1e-2 and rel[:50].max() < 5e-2, (switches, rel[:5], rel[:50].max())
         # per-fifth means of the loss: the trajectories separate as the epoch goes on (chaotic dynamics; the eight HIP
-        # summation-order variants of profiles/r03_first_epoch_samples.txt end between 2.745 and 2.859, the three CPU
+        # summation-order variants of profiles/r03_first_epoch_samples.txt end between 2.69 and 2.85, the three CPU
         # trajectories of the fixture between 2.755 and 2.781), so a single run is held to 2 % over the first three fifths,
         # 3 % in the fourth, 5 % in the last - and the MEAN of the three runs' last fifths to 3 % below
         fifth = n_batches // 5
