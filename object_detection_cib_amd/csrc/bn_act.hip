@@ -232,14 +232,6 @@ __global__ void bn_bwd_coeffs_fused2_kernel(CoefJob j0, CoefJob j1) {
 // HBM latency (measured 3.5-4.5 TB/s; Little's law wants >= 12 MB outstanding for 8 TB/s).
 constexpr int U = 4;
 
-// sigmoid on the hardware reciprocal + one Newton step (<= 1 ulp of the correctly rounded quotient, a third of the
-// instructions of an IEEE division; worth 2 % of the training step, these passes being VALU-co-limited)
-__device__ __forceinline__ float fast_sigmoid(float z) {
-  const float d = 1.0f + __expf(-z);
-  const float r = __builtin_amdgcn_rcpf(d);
-  return r * (2.0f - d * r);
-}
-
 // ---------------------------------------------------------------- forward apply
 // out[m][ocoff + c] = silu(y[m][c]*scale[c] + shift[c]) (+ res[m][rcoff + c])
 __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, int ldy, const float* scale, const float* shift,
@@ -273,14 +265,17 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, int
         // is materialised, so add before the single rounding.
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float z = (float)v[u][e] * sc[e] + sh[e];
-          o[e] = (bf16_t)(z * fast_sigmoid(z) + (float)r[u][e]);
+          const float yv = (float)v[u][e];
+          const float z = __builtin_fmaf(yv, sc[e], sh[e]);
+          const float sg = kod_sigmoid_l2(KOD_NEG_LOG2E * z);
+          o[e] = (bf16_t)__builtin_fmaf(z, sg, (float)r[u][e]);
         }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float z = (float)v[u][e] * sc[e] + sh[e];
-          o[e] = (bf16_t)(z * fast_sigmoid(z));
+          const float yv = (float)v[u][e];
+          const float z = __builtin_fmaf(yv, sc[e], sh[e]);
+          o[e] = (bf16_t)(z * kod_sigmoid_l2(KOD_NEG_LOG2E * z));
         }
       }
       *reinterpret_cast<bf16x8*>(out + m * ldo + ocoff + cc * 8) = o;
@@ -323,10 +318,10 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const bf16_t* d
         if (m0 + u * stride >= M) break;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float yv = (float)v[u][e];
-          float z = yv * sc[e] + sh[e];
-          float sg = fast_sigmoid(z);
-          float dz = (float)g[u][e] * sg * (1.f + z * (1.f - sg));
+          const float yv = (float)v[u][e];
+          const float z = __builtin_fmaf(yv, sc[e], sh[e]);
+          const float sg = kod_sigmoid_l2(KOD_NEG_LOG2E * z);
+          const float dz = kod_silu_bwd((float)g[u][e], z, sg);
           s0[e] += dz;
           s1[e] += dz * (yv - mu[e]) * rs[e];
         }
@@ -402,11 +397,11 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float yv = (float)v[u][e];
-        float z = yv * sc[e] + sh[e];
-        float sg = fast_sigmoid(z);
-        float dz = (float)g[u][e] * sg * (1.f + z * (1.f - sg));
-        o[e] = (bf16_t)(k1[e] * dz + k2[e] * yv + k3[e]);
+        const float yv = (float)v[u][e];
+        const float z = __builtin_fmaf(yv, sc[e], sh[e]);
+        const float sg = kod_sigmoid_l2(KOD_NEG_LOG2E * z);
+        const float dz = kod_silu_bwd((float)g[u][e], z, sg);
+        o[e] = (bf16_t)__builtin_fmaf(k1[e], dz, __builtin_fmaf(k2[e], yv, k3[e]));
       }
       *reinterpret_cast<bf16x8*>(y + m * ldy + cc * 8) = o;
       if (dI) {

@@ -820,14 +820,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 bf16x8 yv = *reinterpret_cast<const bf16x8*>(sg_raw + opix * sg_ldr);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
+                  // kodhip_common.h; the exponent's scale as one more multiply here: sixteen more per-channel constants
+                  // would spill in the 128-register tiles
                   const float y = (float)yv[e];
-                  const float z = y * sg_sc[e] + sg_sh[e];
-                  const float d = 1.0f + __expf(-z);
-                  float r = __builtin_amdgcn_rcpf(d);
-                  r = r * (2.0f - d * r);
-                  const float dz = (float)v[e] * r * (1.f + z * (1.f - r));
+                  const float z = __builtin_fmaf(y, sg_sc[e], sg_sh[e]);
+                  const float r = kod_sigmoid_l2(KOD_NEG_LOG2E * z);
+                  const float dz = kod_silu_bwd((float)v[e], z, r);
                   ssum[e] += dz;
-                  ssq[e] += dz * y;
+                  ssq[e] = __builtin_fmaf(dz, y, ssq[e]);
                 }
               }
             }

@@ -887,12 +887,6 @@ int launch_cfg(WgradArgs a, hipStream_t stream) {
 // [m][n] operand; wave w owns k columns 32 w .. 32 w + 31 of the 160-column slab.  dY never exists in HBM.
 // Every LDS access is inline asm: with compiler-visible LDS writes or register loads next to the DMA the compiler's own
 // waits drain the prefetch in front of them (measured: movement 256 us + transform 98 us + MFMA 80 us ran back to back).
-__device__ __forceinline__ float stem_sigmoid(float z) {      // = bn_act.hip fast_sigmoid
-  const float d = 1.0f + __expf(-z);
-  const float r = __builtin_amdgcn_rcpf(d);
-  return r * (2.0f - d * r);
-}
-
 struct StemBwdArgs {
   const bf16_t* x;            // pixel pairs [B][Hs][Wp][8]
   const bf16_t* dA; int lda, dacoff;
@@ -1019,11 +1013,11 @@ __global__ __launch_bounds__(320, TW == 160 ? 3 : 5) void conv_stem_bwd_fused_ke
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float yv = (float)y8[e];
-        const float z = yv * sc[e] + sh[e];
-        const float sg = stem_sigmoid(z);
-        const float dz = (float)g8[e] * sg * (1.f + z * (1.f - sg));
-        o[e] = (bf16_t)(k1[e] * dz + k2[e] * yv + k3[e]);
+        const float yv = (float)y8[e];                       // = bn_silu_bwd_apply_kernel's arithmetic
+        const float z = __builtin_fmaf(yv, sc[e], sh[e]);
+        const float sg = kod_sigmoid_l2(KOD_NEG_LOG2E * z);
+        const float dz = kod_silu_bwd((float)g8[e], z, sg);
+        o[e] = (bf16_t)__builtin_fmaf(k1[e], dz, __builtin_fmaf(k2[e], yv, k3[e]));
       }
       if (!(ch_ok && ox0 + p < a.Wo)) o = bf16x8{};        // ragged last tile of a row / channels past N: zero rows
       const u32x4 ov = __builtin_bit_cast(u32x4, o);

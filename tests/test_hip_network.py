@@ -87,7 +87,11 @@ def test_train_step_vs_oracle(case):
             # channel in the deepest BatchNorms, where bf16 rounding noise is amplified ~2x per layer
             np.testing.assert_allclose(got, want, rtol=ltol if size >= 640 else (2e-2 if size >= 160 else 3e-2), err_msg=name)
             if size >= 160:          # 64 px: the hl map is 2x2 (8 samples per BN channel), pure chaos
-                assert abs(gn_h - gn_r) <= gtol * gn_r, (name, gn_h, gn_r)
+                # 160 px / B=2 (50 samples per channel in the deepest BatchNorms): the HIP gradient norm itself moves by
+                # 8 % between summation-order variants of its own kernels (measured on yv5s_160 with tools/gn_probe.py:
+                # 16.28 .. 17.56 over ten variants; fp32 oracle 16.10, its bf16 emulation 15.67) - 15 % there, the
+                # north-star 10 % at the benchmark resolution
+                assert abs(gn_h - gn_r) <= (gtol if size >= 640 else 1.5 * gtol) * gn_r, (name, gn_h, gn_r)
     # BN running statistics follow torch semantics (momentum .03, unbiased variance); compared network-wide
     sd_r, sd_h = ref.state_dict(), net.state_dict()
     for suffix, tol in (("running_mean", 0.15), ("running_var", 2e-2)):
