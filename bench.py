@@ -183,6 +183,77 @@ def loop_leg(net, loss_fn, B, S, nc, device, steps, mixup_prob=0.0):
                         "host RNG protocol) -> hipGraph replay of the training step", "final_loss": float(total)}
 
 
+def validation_leg(net, loss_fn, B, S, nc, device, batches=12):
+    """The validation loop of the same experiment (DefaultYolov5Experiment.validate: device resize / letter-box -> eval
+    forward -> decode -> NMS -> mAP matching) on a u8 pool of original-size images, random-init weights (worst-case box
+    counts).  Reported beside the step rate, never as `value`."""
+    from object_detection_cib_amd import _lib
+    from object_detection_cib_amd.core.anchors.info import voc_anchor_info
+    from object_detection_cib_amd.data.device_pipeline import DeviceValPipeline
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.exp import DefaultYolov5Experiment
+    from object_detection_cib_amd.lightning.experiments.yv5_baseline.type_defs import LayerwiseAnchorInfo
+    _lib.limit_host_threads()
+    imgs, boxes, labels = synth_pool(256, 500, nc, 3)         # longest side 500 -> resized to S
+    pipe = DeviceValPipeline(imgs, boxes, labels, S, device)
+    exp = DefaultYolov5Experiment(net, loss_fn, LayerwiseAnchorInfo(voc_anchor_info(8), voc_anchor_info(16), voc_anchor_info(32)))
+
+    def feed(n):
+        for i in range(n):
+            img, _, t = pipe.make_batch([(i * B + k) % 256 for k in range(B)])
+            yield (img, t, None)
+    exp.validate(feed(6), nc)              # warm-up: allocator pools, pinned staging rings, graph capture
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    exp.validate(feed(batches), nc)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / batches
+    return {"value": round(B / dt, 1), "unit": "images/sec", "ms_per_batch": round(1e3 * dt, 3), "batches": batches,
+            "workload": "DeviceValPipeline (resize + letter-box of a u8 pool) -> eval forward -> decode -> NMS -> mAP matching, "
+                        "random-init weights"}
+
+
+def variant_leg(variant, B, S, nc, device, steps=12):
+    """Another network scale through the same engine (yv5m = BASELINE configs[4]'s network), one GPU, hipGraph replay of
+    train_step + fused SGD on a resident synthetic batch - measured like `value`, reported beside it."""
+    from object_detection_cib_amd.core.types import FeatureShape
+    widen, deepen = VARIANTS[variant]
+    net, loss_fn = build(nc, device, widen=widen, deepen=deepen)
+    eng = net.engine()
+    x, targets = synth_batch(B, S, nc, 2023, device)
+    shape = FeatureShape(width=S, height=S)
+    eng.sgd_step((0.1, 1e-4, 1e-4), (0.8, 0.8, 0.8), (0.0, 5e-4, 0.0), 1.0)
+    params = list(net.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        total, _ = net.train_step(x, loss_fn, shape, targets, float(B))
+        eng.wait_grads()
+        eng.sgd_step_device()
+        return total
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        last = step()
+    graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    algo_bytes, _ = algorithmic_work(widen, deepen, nc, S)
+    return {"value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
+            "step_roofline_frac": round(B / dt * algo_bytes / 8e12, 4), "final_loss": float(last),
+            "workload": f"{variant}, B={B}, {S}px, hipGraph replay of train_step + fused SGD, resident synthetic batch"}
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N FRESH child processes (one per GPU, the env contract of
     torch.distributed.run) from this parent, which never touches a GPU, wait for them with a deadline, and hand rank
@@ -314,6 +385,7 @@ def main():
                     help="auto: with WORLD_SIZE unset and --gpus > 1 this process starts the N ranks itself; self: always")
     ap.add_argument("--timeout", type=float, default=900.0, help="self-launch: seconds before a hung job is stopped")
     ap.add_argument("--no-loop", action="store_true", help="skip the training-loop leg (device data pipeline -> captured step)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the validation-loop and yv5m legs")
     ap.add_argument("--loop-steps", type=int, default=20)
     args = ap.parse_args()
 
@@ -466,6 +538,17 @@ def main():
     loop = None
     if world == 1 and not use_dist and not args.no_loop and not args.autograd and use_graph:
         loop = loop_leg(net, loss_fn, B, S, nc, device, args.loop_steps)
+    # further legs of the default single-GPU run (each reported beside `value`, none inside the timed region; a leg that
+    # fails is reported as its error, the line itself stands): the validation loop and the yv5m scale
+    extra = {}
+    if world == 1 and not use_dist and not (args.no_extra or args.no_loop) and not args.autograd and use_graph and args.variant == "yv5s":
+        for name, fn in (("validation", lambda: validation_leg(net, loss_fn, B, S, nc, device)),
+                         ("yv5m", lambda: variant_leg("yv5m", B, S, nc, device))):
+            try:
+                extra[name] = fn()
+            except Exception as e:          # noqa: BLE001 - the leg's failure must not take the measured line with it
+                extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize()
 
     if rank == 0:
         ips = world * B * args.steps / dt
@@ -506,6 +589,7 @@ def main():
         }
         if loop is not None:
             out["loop"] = loop
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
