@@ -180,10 +180,11 @@ def test_first_epoch_map_vs_cpu_trainer(golden):
         bf16-storage emulation): mAP50 0.064 .. 0.094, mean 0.076, sigma 0.011.  The HIP trainer is run THREE times here,
         under three summation orders of its own kernels (default; CSP main / short data gradients as two launches;
         separate BatchNorm-backward reduce pass - EngineOptions, no other difference), and the MEAN of the three must lie
-        within mean +- 2 sigma of the CPU samples, every single run within +- 4 sigma.  (Round 3, 16 HIP epochs over
-        eight kernel variants x {bf16, fp32} accumulation of multi-producer activation gradients,
-        profiles/r03_first_epoch_samples.txt: HIP mean mAP50 0.072 vs CPU 0.076 - z = -0.8, no detectable deficit - and
-        fp32 accumulation does not help: 0.0724 vs 0.0722 in one sample of eight pairs, 0.0595 vs 0.0723 in the other.  Evaluating HIP-trained weights with the CPU oracle's eval
+        within mean +- 2 sigma of the CPU samples, every single run within +- 4 sigma.  (Round 3, 48 HIP epochs in three
+        samples of eight kernel variants x {bf16, fp32} accumulation of multi-producer activation gradients,
+        profiles/r03_first_epoch_samples.txt: the 24 bf16 trajectories pooled give mAP50 0.071 vs 0.076 for the CPU runs,
+        z = -1.3, and 0.073 for the CPU trainer's own bf16-storage emulation, z = -0.4; fp32 accumulation does not help.
+        Evaluating HIP-trained weights with the CPU oracle's eval
         pipeline reproduces the HIP mAP to 1e-4: validation itself is exact - DESIGN section 5.)"""
     from oracle import first_epoch as FE
     from object_detection_cib_amd.data.detection import DetectionTarget
