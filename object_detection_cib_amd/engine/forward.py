@@ -68,14 +68,24 @@ class ForwardMixin:
                     outs[k].copy_(t)
                     t = outs[k]
                 torch.distributed.all_reduce(t, group=self.process_group)
+    def image_buffer(self, B: int, H: int, W: int) -> torch.Tensor:
+        """The network's input buffer for this shape: bf16 pixel pairs [B, H, W/2, 8] (channels r, g, b, 0 of two
+        neighbouring pixels).  Fill it and call forward(..., image_ready=True)."""
+        assert not self.g.inputs
+        self.allocate(B, H, W)
+        return self.act["image"]
+
     # ------------------------------------------------------------------ forward
-    def forward(self, x, training: bool = True, after_first_layer=None):
+    def forward(self, x, training: bool = True, after_first_layer=None, image_ready: bool = False):
         """Whole network / backbone: x = [B,3,H,W] fp32 NCHW on this device.  Sub-network graphs (Graph.inputs): x = a
         sequence of NCHW tensors, one per input view (copied into the channels-last bf16 buffers; torch does the layout
         change, the arithmetic stays in libkodhip).  Returns the head tensors [B,A,h,w,5+nc] fp32 (ll, ml, hl) followed
         by the Graph.outputs views as NCHW fp32 tensors.
         after_first_layer: called once after the first layer's kernels are launched (a hook for side-stream work that only
-        depends on the step's inputs: it is then captured behind the forward chain's head, see Yolov5Network.train_step)."""
+        depends on the step's inputs: it is then captured behind the forward chain's head, see Yolov5Network.train_step).
+        image_ready: the caller has already put the batch into the engine's own input buffer (`image_buffer()`: bf16 pixel
+        pairs [B, H, W/2, 8], what kodhip_nchw_to_nhwc4 produces and kodhip_compose_batch can write directly) - x then only
+        carries the shape, and the layout-change pass is skipped (the training loop of bench.py / DeviceTrainPipeline)."""
         lib, chk = self.lib, _lib.check
         if self.g.inputs:
             xs = list(x)
@@ -93,7 +103,7 @@ class ForwardMixin:
         s = self._stream()
         if self._packed_version != self.param_version:
             self.pack_weights()
-        if not self.g.inputs:
+        if not self.g.inputs and not image_ready:
             chk(lib.kodhip_nchw_to_nhwc4(x.data_ptr(), self.act["image"].data_ptr(), B, 3, H, W, s), "nchw_to_nhwc4")
         A, nc = self.g.num_anchors, self.g.num_classes
         outs = []

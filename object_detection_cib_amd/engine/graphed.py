@@ -23,8 +23,11 @@ from ..core.types import FeatureShape
 
 class GraphedTrainStep:
     def __init__(self, net, loss, batch_size: int, height: int, width: int, max_targets: int = 4096,
-                 loss_scale: Optional[float] = None):
+                 loss_scale: Optional[float] = None, input_pairs: bool = False):
+        """input_pairs: batches arrive as bf16 pixel pairs [B, H, W/2, 8] (DeviceTrainPipeline.make_batch(out_pairs=True)) and
+        are copied straight into the network's input buffer - no fp32 NCHW batch, no layout-change pass in the step."""
         self.net, self.loss = net, loss
+        self.input_pairs = bool(input_pairs)
         self.eng = net.engine()
         dev = self.eng.device
         self.B, self.H, self.W = batch_size, height, width
@@ -48,14 +51,19 @@ class GraphedTrainStep:
     def _step(self):
         for p in self.params:
             p.grad = None
-        total, lr = self.net.train_step(self.x, self.loss, self.shape, self.targets, self.scale)
+        total, lr = self.net.train_step(self.x, self.loss, self.shape, self.targets, self.scale, image_ready=self.input_pairs)
         self.eng.wait_grads()
         self.eng.sgd_step_device()
         return total, (lr.localization.detach(), lr.objectness.detach(), lr.classification.detach())
 
     def _load(self, images: torch.Tensor, targets):
-        assert tuple(images.shape) == tuple(self.x.shape), (images.shape, self.x.shape)
-        self.x.copy_(images, non_blocking=True)
+        if self.input_pairs:
+            buf = self.eng.image_buffer(self.B, self.H, self.W)
+            assert tuple(images.shape) == tuple(buf.shape) and images.dtype == buf.dtype, (images.shape, images.dtype, buf.shape)
+            buf.copy_(images, non_blocking=True)
+        else:
+            assert tuple(images.shape) == tuple(self.x.shape), (images.shape, self.x.shape)
+            self.x.copy_(images, non_blocking=True)
         if isinstance(targets, BatchedTargets):
             n = targets.n
             if n > self.cap:

@@ -205,13 +205,14 @@ class Yolov5Network(nn.Module):
         with torch.no_grad():
             return tuple(eng.forward(x, training=self.training))
 
-    def train_step(self, x: torch.Tensor, loss, image_feature_shape, targets, scale: float):
+    def train_step(self, x: torch.Tensor, loss, image_feature_shape, targets, scale: float, image_ready: bool = False):
         """forward -> assigner + loss -> backward of `scale * (localization + classification + objectness)` (the
         reference's training_step, exp.py:104-121) as straight calls into the engine: no autograd graph, and the loss
         kernels run once (value and gradient together, `Yolov5Loss.value_and_grad`) instead of once per direction.
         Leaves the parameter gradients in `.grad` exactly like `total.backward()` does; returns (total, LossResult).
         The autograd route (`net(x)` -> `loss(...)` -> `.backward()`) stays available and gives the same numbers bit for
-        bit; this is the route the captured step (engine/graphed.py) and bench.py take."""
+        bit; this is the route the captured step (engine/graphed.py) and bench.py take.
+        image_ready: the batch already sits in the engine's input buffer (Engine.image_buffer), x carries only the shape."""
         eng = self.engine()
         assert self.training, "train_step() needs train mode"
         if x.dtype != torch.float32:
@@ -242,7 +243,7 @@ class Yolov5Network(nn.Module):
                 # branches, or the loss would wait for it at the end of the forward pass).
                 eng.aux_stream.wait_event(fork)
                 asg.append(loss.assigner.assign_device(image_feature_shape, targets, eng.device, stream=eng.aux_stream))
-            outs = eng.forward(x.contiguous(), training=True, after_first_layer=launch_assignment)
+            outs = eng.forward(x.contiguous(), training=True, after_first_layer=launch_assignment, image_ready=image_ready)
             cur.wait_stream(eng.aux_stream)
             asg = asg[0]
             lr, grads = loss.value_and_grad(image_feature_shape, outs, targets, (scale, scale, scale), assignment=asg)

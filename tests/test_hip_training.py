@@ -130,6 +130,55 @@ def test_graphed_training_loop_equals_eager_loop():
     assert torch.equal(runs[True][2], runs[False][2])
 
 
+def test_graphed_step_from_pixel_pairs_equals_fp32_input():
+    """GraphedTrainStep(input_pairs=True): the batch arrives as bf16 pixel pairs (DeviceTrainPipeline.make_batch(out_pairs=
+    True), the layout the first layer reads) and goes straight into the network's input buffer - no fp32 NCHW batch, no
+    layout-change pass in the captured step; the next batch composited on a side stream while the step runs (bench.py's
+    loop leg).  Same losses and parameters, bit for bit, as the fp32-input step on the same batches."""
+    from object_detection_cib_amd.engine.graphed import GraphedTrainStep
+    from bench import build
+    S, nc, B, steps, seed = 160, 10, 8, 5, 6
+    cache = synth.coco_zipf_like(64, S, seed, nc)
+    runs = {}
+    for pairs_mode in (False, True):
+        pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda")
+        random.seed(seed); np.random.seed(seed)
+        torch.manual_seed(seed)
+        net, loss_fn = build(nc, torch.device("cuda", 0), seed=seed, widen=0.25)
+        net.engine().sgd_step((0.01, 0.01, 0.01), (0.9,) * 3, (0.0, 5e-4, 0.0), 1.0)
+        main, prep = torch.cuda.current_stream(), torch.cuda.Stream()
+
+        def produce(i):
+            idx = [(i * B + k) % len(cache) for k in range(B)]
+            if not pairs_mode:
+                img, _, tg = pipe.make_batch(idx)
+                return img, tg, None
+            prep.wait_stream(main)
+            with torch.cuda.stream(prep):
+                _, pr, tg = pipe.make_batch(idx, out_f32=False, out_pairs=True)
+                ev = torch.cuda.Event()
+                ev.record(prep)
+            pr.record_stream(main)
+            return pr, tg, ev
+        first = produce(0)
+        if first[2] is not None:
+            main.wait_event(first[2])
+        gs = GraphedTrainStep(net, loss_fn, B, S, S, max_targets=512, input_pairs=pairs_mode).capture(first[0], first[1])
+        losses, nxt = [], first
+        for i in range(steps):
+            x, tg, ev = nxt
+            nxt = produce(i + 1)
+            if ev is not None:
+                main.wait_event(ev)
+            total, _ = gs(x, tg)
+            losses.append(float(total))
+        torch.cuda.synchronize()
+        runs[pairs_mode] = (losses, torch.cat([p.detach().flatten() for p in net.parameters()]).cpu())
+    assert np.isfinite(runs[False][0]).all()
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
+    assert torch.equal(runs[True][1], runs[False][1])
+
+
 def test_graphed_loop_survives_validation_at_other_shapes():
     """A captured hipGraph bakes the engine's buffer addresses in.  A validation forward at another batch size /
     resolution between replays must not free or reuse them (Engine.allocate keeps one buffer set per shape):
