@@ -226,6 +226,17 @@ def test_engine_options_from_env(monkeypatch):
     o = EngineOptions.from_env()
     assert not o.comm_overlap and not o.dual_dgrad and o.native == {"KODHIP_FORCE_BM": "256"}
     assert o.as_dict()["native"]["KODHIP_FORCE_BM"] == "256"
+    # the round-3 schedule switches: defaults and their environment spellings
+    for k in ("KODHIP_NO_DUAL_WGRAD", "KODHIP_STEM_BWD_FUSED", "KODHIP_WGRAD_STREAMS", "KODHIP_STEM_BWD_STREAM"):
+        monkeypatch.delenv(k, raising=False)
+    o = EngineOptions.from_env()
+    assert o.dual_wgrad and o.stem_bwd_fused and o.wgrad_streams == 1 and not o.wgrad_reduce_batched
+    monkeypatch.setenv("KODHIP_NO_DUAL_WGRAD", "1")
+    monkeypatch.setenv("KODHIP_STEM_BWD_FUSED", "0")
+    monkeypatch.setenv("KODHIP_WGRAD_STREAMS", "2")
+    monkeypatch.setenv("KODHIP_STEM_BWD_STREAM", "wg")
+    o = EngineOptions.from_env()
+    assert not o.dual_wgrad and not o.stem_bwd_fused and o.wgrad_streams == 2 and o.native["KODHIP_STEM_BWD_STREAM"] == "wg"
 
 
 def test_backward_write_plan_and_fp32_accumulation_modes():
