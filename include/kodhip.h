@@ -156,8 +156,9 @@ int kodhip_conv_wgrad_dual(const void* x, const void* dy1, const void* dy2, floa
  * / pad 2 on the image - has no data gradient, so the weight gradient is dY's only reader).  Replaces
  * kodhip_bn_silu_bwd_apply + kodhip_conv_wgrad(stem = 1) for that unit.  x: pixel pairs [B][H][Wp][8] bf16 (Wp = width / 2);
  * dA: [B * H/2 * Wp][lda] (+dacoff), y: [..][ldy] pre-BatchNorm output (left untouched); coef = k1[N] | k2[N] | k3[N] from
- * kodhip_bn_bwd_coeffs*; partials: kodhip_stem_bwd_fused_blocks(B, H, Wp) * 32 * 160 floats; grad: fp32 [N][3][6][6].  N <= 32. */
-int kodhip_stem_bwd_fused_blocks(int B, int H, int Wp);
+ * kodhip_bn_bwd_coeffs*; partials: kodhip_stem_bwd_fused_blocks(B, H, Wp, N) * (N <= 32 ? 32 : 64) * 160 floats; grad: fp32
+ * [N][3][6][6].  N <= 64 (two 32-channel tiles per block above 32). */
+int kodhip_stem_bwd_fused_blocks(int B, int H, int Wp, int N);
 int kodhip_stem_bwd_fused(const void* x, const void* dA, int lda, int dacoff, const void* y, int ldy,
                           const float* scale, const float* shift, const float* coef, float* partials, float* grad,
                           int B, int H, int Wp, int N, float gscale, kodStream_t stream);

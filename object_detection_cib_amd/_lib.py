@@ -59,7 +59,7 @@ SIGNATURES = {
     "kodhip_conv_wgrad_partial": (i32, [vp, vp, vp] + [i32] * 16 + [vp]),
     "kodhip_conv_wgrad_dual_splits": (i32, [i32] * 8),
     "kodhip_conv_wgrad_dual": (i32, [vp] * 6 + [i32] * 10 + [f32, vp]),
-    "kodhip_stem_bwd_fused_blocks": (i32, [i32, i32, i32]),
+    "kodhip_stem_bwd_fused_blocks": (i32, [i32, i32, i32, i32]),
     "kodhip_stem_bwd_fused": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     "kodhip_wgrad_reduce_desc_bytes": (i32, []),
     "kodhip_wgrad_reduce_blocks": (i32, [i32, i32]),

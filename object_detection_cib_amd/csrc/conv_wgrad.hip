@@ -903,14 +903,18 @@ struct StemBwdArgs {
 __host__ __device__ constexpr int stem_prw(int TW) { return TW == 160 ? 168 : 88; }
 __host__ __device__ constexpr int stem_xb(int TW) { return (6 * stem_prw(TW) * 16 + 1023) / 1024 * 1024; }
 
-template <int TW>
-__global__ __launch_bounds__(320, TW == 160 ? 3 : 5) void conv_stem_bwd_fused_kernel(StemBwdArgs a) {
+// NT = 32-channel output tiles per block: 1 for N <= 32 (yv5n / yv5s), 2 for N <= 64 (yv5m: 48, yv5l: 64) - the dA / y
+// tile rows are then 128 B (two-way bank conflicts in the transposing reads of dY, accepted) and every wave runs two MFMAs
+// per staged X fragment.
+template <int TW, int NT>
+__global__ __launch_bounds__(320, NT == 2 ? 3 : (TW == 160 ? 3 : 5)) void conv_stem_bwd_fused_kernel(StemBwdArgs a) {
   constexpr int PRW = stem_prw(TW), NW = 5;
-  constexpr int XB = stem_xb(TW), GB = TW * 64;          // X runs | dA tile (becomes dY) | y tile
+  constexpr int CH = 4 * NT, RBG = 64 * NT;              // 16-byte chunks / bytes per dA (dY) / y tile row
+  constexpr int XB = stem_xb(TW), GB = TW * RBG;         // X runs | dA tile (becomes dY) | y tile
   constexpr int STAGE = XB + 2 * GB;
   constexpr int NIX = XB / 1024, NIG = GB / 1024, NI = NIX + 2 * NIG;     // DMA instructions per tile (1 KB each)
-  constexpr int ITEMS = TW * 4 / 320;                    // 16-byte (pixel, 8-channel chunk) items per thread
-  static_assert(GB % 1024 == 0 && TW * 4 % 320 == 0, "tile must fill whole DMA instructions / thread items");
+  constexpr int ITEMS = TW * CH / 320;                   // 16-byte (pixel, 8-channel chunk) items per thread
+  static_assert(GB % 1024 == 0 && TW * CH % 320 == 0 && 320 % CH == 0, "tile must fill whole DMA instructions / thread items");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -924,8 +928,9 @@ __global__ __launch_bounds__(320, TW == 160 ? 3 : 5) void conv_stem_bwd_fused_ke
   __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
 #endif
 
-  // per-thread constants of the dY arithmetic: this thread's items are (pixel q >> 2, channel chunk q & 3), q = tid + 320 j
-  const int cc = tid & 3;
+  // per-thread constants of the dY arithmetic: this thread's items are (pixel q / CH, channel chunk q % CH), q = tid + 320 j
+  // (320 is a multiple of CH: the chunk is the same for all of a thread's items)
+  const int cc = tid % CH;
   float sc[8], sh[8], k1[8], k2[8], k3[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(320, TW == 160 ? 3 : 5) void conv_stem_bwd_fused_ke
   const bool ch_ok = cc * 8 < a.N;
 
   // one tile's DMA: instruction i = wave + 5 k; i < NIX: pair-row runs (LDS slot 64 i + lane = kh * PRW + r), then the dA
-  // tile, then the y tile (slot = 4 * pixel + chunk)
+  // tile, then the y tile (slot = CH * pixel + chunk)
   auto stage = [&](int t, int buf) {
     const int row = t / a.tiles_per_row;                  // b * Ho + oy
     const int ox0 = (t - row * a.tiles_per_row) * TW;
@@ -957,7 +962,7 @@ __global__ __launch_bounds__(320, TW == 160 ? 3 : 5) void conv_stem_bwd_fused_ke
       } else {
         const bool is_g = i < NIX + NIG;
         const int q = (i - NIX - (is_g ? 0 : NIG)) * 64 + lane;
-        const int p = q >> 2, c = q & 3;
+        const int p = q / CH, c = q % CH;
         const long m = (long)row * a.Wo + ox0 + p;
         if (ox0 + p < a.Wo && c * 8 < a.N)
           vo = is_g ? (uint32_t)((m * a.lda + a.dacoff + c * 8) * 2) : (uint32_t)((m * a.ldy + c * 8) * 2);
@@ -975,15 +980,17 @@ __global__ __launch_bounds__(320, TW == 160 ? 3 : 5) void conv_stem_bwd_fused_ke
     }
   };
 
-  f32x16 acc;
+  f32x16 acc[NT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[n][e] = 0.f;
 
   // fragment addresses (transposing reads, lane geometry of conv_wgrad_dma_kernel): rows = reduction index m
   const int tr_row = 8 * (lane >> 5) + ((lane & 15) >> 2);
   const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  const uint32_t yoff = (uint32_t)(XB + tr_row * 64 + tr_col * 2);
+  const uint32_t yoff = (uint32_t)(XB + tr_row * RBG + tr_col * 2);
   int tap = wave * 4 + (tr_col >> 3);
   if (tap > 17) tap = 17;                                   // slab columns 144 .. 159 are padding (never reduced)
   const int tkh = tap / 3, tkw = tap - tkh * 3;
@@ -1001,7 +1008,7 @@ __global__ __launch_bounds__(320, TW == 160 ? 3 : 5) void conv_stem_bwd_fused_ke
     const int ox0 = (t % a.tiles_per_row) * TW;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-      const int q = tid + 320 * j, p = q >> 2;
+      const int q = tid + 320 * j, p = q / CH;
       const uint32_t ga = sb + XB + (uint32_t)q * 16, ya = ga + GB;
       u32x4 gr, yr;
       asm volatile("ds_read_b128 %0, %1" : "=v"(gr) : "v"(ga) : "memory");
@@ -1028,31 +1035,40 @@ __global__ __launch_bounds__(320, TW == 160 ? 3 : 5) void conv_stem_bwd_fused_ke
 
 #pragma unroll 2
     for (int ks = 0; ks < TW / 16; ++ks) {
-      s16x4 ylo, yhi, xlo, xhi;
-      const uint32_t py = sb + yoff + (uint32_t)(ks * 16 * 64);
+      s16x4 ylo[NT], yhi[NT], xlo, xhi;
       const uint32_t px = sb + xoff + (uint32_t)(ks * 16 * 16);
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo) : "v"(py) : "memory");
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(yhi) : "v"(py + 4 * 64) : "memory");
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const uint32_t py = sb + yoff + (uint32_t)(ks * 16 * RBG + n * 64);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ylo[n]) : "v"(py) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(yhi[n]) : "v"(py + 4 * RBG) : "memory");
+      }
       asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xlo) : "v"(px) : "memory");
       asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xhi) : "v"(px + 4 * 16) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      asm volatile("" : "+v"(ylo), "+v"(yhi), "+v"(xlo), "+v"(xhi));
+      asm volatile("" : "+v"(xlo), "+v"(xhi));
       typedef short s16x8 __attribute__((ext_vector_type(8)));
-      const s16x8 ty = {ylo[0], ylo[1], ylo[2], ylo[3], yhi[0], yhi[1], yhi[2], yhi[3]};
       const s16x8 tx = {xlo[0], xlo[1], xlo[2], xlo[3], xhi[0], xhi[1], xhi[2], xhi[3]};
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ty), __builtin_bit_cast(bf16x8, tx), acc, 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        asm volatile("" : "+v"(ylo[n]), "+v"(yhi[n]));
+        const s16x8 ty = {ylo[n][0], ylo[n][1], ylo[n][2], ylo[n][3], yhi[n][0], yhi[n][1], yhi[n][2], yhi[n][3]};
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ty), __builtin_bit_cast(bf16x8, tx), acc[n], 0, 0, 0);
+      }
     }
     buf ^= 1;
   }
 
-  // D[n][k]: k = 32 wave + (lane & 31), n = 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
-  float* slab = a.part + (size_t)blockIdx.x * 32 * 160;
+  // D[n][k]: k = 32 wave + (lane & 31), n = 32 tile + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)
+  float* slab = a.part + (size_t)blockIdx.x * (32 * NT) * 160;
   const int k = wave * 32 + (lane & 31);
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int n = 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-    slab[(size_t)n * 160 + k] = acc[e];
-  }
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = nt * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+      slab[(size_t)n * 160 + k] = acc[nt][e];
+    }
 }
 
 // ROW3 form (conv_wgrad_row3_kernel): 3x3 / stride 1 / pad 1 with whole 32-channel chunks.
@@ -1293,8 +1309,8 @@ int kodhip_conv_wgrad_dual(const void* x, const void* dy1, const void* dy2, floa
 // reduction: replaces kodhip_bn_silu_bwd_apply + kodhip_conv_wgrad(stem = 1) for the unit that has no data gradient
 // (kod/nn/backbones/yolov5.py:44-52: the 6x6 / stride 2 / pad 2 stem; aten::native_batch_norm_backward + silu_backward +
 // convolution_backward dW).  x: pixel pairs [B][H][Wp][8] bf16 (Wp = image width / 2), dA / y: [B * H/2 * Wp][N] slices,
-// coef = kodhip_bn_bwd_coeffs*'s k1 | k2 | k3; partials: kodhip_stem_bwd_fused_blocks(B, H, Wp) * 32 * 160 floats; grad: fp32
-// [N][3][6][6].  y is left untouched (dY is never materialised).  N <= 32.
+// coef = kodhip_bn_bwd_coeffs*'s k1 | k2 | k3; partials: kodhip_stem_bwd_fused_blocks(B, H, Wp, N) * (N <= 32 ? 32 : 64) * 160
+// floats; grad: fp32 [N][3][6][6].  y is left untouched (dY is never materialised).  N <= 64.
 // tile width: 80 pixels (four 5-wave blocks per CU; measured 336 us at B = 64 / 640 px against 443 us for 160-pixel tiles
 // with two blocks per CU); KODHIP_STEM_BWD_TW = 80 | 160 is the A/B knob
 static int stem_bwd_tw(int Wp) {
@@ -1303,12 +1319,12 @@ static int stem_bwd_tw(int Wp) {
   return Wp <= 80 ? 80 : tw;
 }
 
-int kodhip_stem_bwd_fused_blocks(int B, int H, int Wp) {
-  const int TW = stem_bwd_tw(Wp);
+int kodhip_stem_bwd_fused_blocks(int B, int H, int Wp, int N) {
+  const int TW = N > 32 ? 80 : stem_bwd_tw(Wp);
   const long tiles = (long)B * (H / 2) * cdiv(Wp, TW);
   static int slots = 0;                  // KODHIP_STEM_BWD_BLOCKS: A/B knob (default: every resident slot of the chip)
   if (!slots) { const char* e = getenv("KODHIP_STEM_BWD_BLOCKS"); slots = e ? atoi(e) : 0; if (slots < 1) slots = 0; }
-  const int want = slots ? slots : (TW == 160 ? 512 : 1024);
+  const int want = slots ? slots : (N > 32 ? 512 : (TW == 160 ? 512 : 1024));      // resident blocks: 2 / 2 / 4 per CU
   const int tpb = cdiv(tiles, want);
   return cdiv(tiles, tpb);
 }
@@ -1317,7 +1333,7 @@ int kodhip_stem_bwd_fused(const void* x, const void* dA, int lda, int dacoff, co
                           const float* scale, const float* shift, const float* coef, float* partials, float* grad,
                           int B, int H, int Wp, int N, float gscale, hipStream_t stream) {
   KOD_CHECK_ARG(x && dA && y && scale && shift && coef && partials && grad, "stem_bwd_fused: null pointer");
-  KOD_CHECK_ARG(B > 0 && H >= 2 && H % 2 == 0 && Wp > 0 && N > 0 && N <= 32 && N % 8 == 0, "stem_bwd_fused: bad geometry");
+  KOD_CHECK_ARG(B > 0 && H >= 2 && H % 2 == 0 && Wp > 0 && N > 0 && N <= 64 && N % 8 == 0, "stem_bwd_fused: bad geometry");
   KOD_CHECK_ARG(lda % 8 == 0 && dacoff % 8 == 0 && dacoff + N <= lda && ldy % 8 == 0 && ldy >= N, "stem_bwd_fused: bad slices");
   StemBwdArgs a = {};
   a.x = (const bf16_t*)x; a.dA = (const bf16_t*)dA; a.lda = lda; a.dacoff = dacoff; a.y = (const bf16_t*)y; a.ldy = ldy;
@@ -1327,16 +1343,17 @@ int kodhip_stem_bwd_fused(const void* x, const void* dA, int lda, int dacoff, co
   const long xb = (long)B * H * Wp * 16, gb = M * lda * 2, yb = M * ldy * 2;
   KOD_CHECK_ARG(xb < (1l << 32) - 64 && gb < (1l << 32) - 64 && yb < (1l << 32) - 64, "stem_bwd_fused: tensor beyond the 32-bit buffer range");
   a.x_bytes = (uint32_t)xb; a.da_bytes = (uint32_t)gb; a.y_bytes = (uint32_t)yb;
-  const int TW = stem_bwd_tw(Wp);
+  const int TW = N > 32 ? 80 : stem_bwd_tw(Wp);                 // (the two-tile form exists for 80-pixel tiles only)
   a.tiles_per_row = cdiv(a.Wo, TW);
   a.tiles = B * a.Ho * a.tiles_per_row;
-  const int blocks = kodhip_stem_bwd_fused_blocks(B, H, Wp);
+  const int blocks = kodhip_stem_bwd_fused_blocks(B, H, Wp, N);
   a.tiles_per_block = cdiv(a.tiles, blocks);
-  if (TW == 160) hipLaunchKernelGGL(conv_stem_bwd_fused_kernel<160>, dim3(blocks), dim3(320), 0, stream, a);
-  else hipLaunchKernelGGL(conv_stem_bwd_fused_kernel<80>, dim3(blocks), dim3(320), 0, stream, a);
+  if (N > 32) hipLaunchKernelGGL((conv_stem_bwd_fused_kernel<80, 2>), dim3(blocks), dim3(320), 0, stream, a);
+  else if (TW == 160) hipLaunchKernelGGL((conv_stem_bwd_fused_kernel<160, 1>), dim3(blocks), dim3(320), 0, stream, a);
+  else hipLaunchKernelGGL((conv_stem_bwd_fused_kernel<80, 1>), dim3(blocks), dim3(320), 0, stream, a);
   KOD_LAUNCH_CHECK("stem_bwd_fused");
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(N * 144, RED_K)), dim3(256), 0, stream,
-                     (const float*)partials, grad, blocks, 32, N, 144, 160, 8, 18, 1, gscale);
+                     (const float*)partials, grad, blocks, N > 32 ? 64 : 32, N, 144, 160, 8, 18, 1, gscale);
   KOD_LAUNCH_CHECK("stem_bwd_fused reduce");
   return KOD_OK;
 }

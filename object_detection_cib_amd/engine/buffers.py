@@ -110,11 +110,11 @@ class BufferMixin:
                 (B, st.H, st.W, u.src.buf.C, u.cin, u.cout, u.k, u.k, u.s, u.s, u.p, u.p)
             st.wg_splits = lib.kodhip_conv_wgrad_splits_geo(*wgeo, st.Kp, u.cout)
             nslab = st.wg_splits * u.cout * st.Kp
-            # the stem's backward as one kernel (kodhip_stem_bwd_fused): a slab per block, 32 rows whatever cout is
-            st.stem_fused = bool(u.stem and u.cout <= 32 and self.opt.stem_bwd_fused and not own)
+            # the stem's backward as one kernel (kodhip_stem_bwd_fused): a slab per block, 32 (cout <= 32) or 64 rows
+            st.stem_fused = bool(u.stem and u.cout <= 64 and self.opt.stem_bwd_fused and not own)
             if st.stem_fused:
-                st.wg_splits = lib.kodhip_stem_bwd_fused_blocks(B, st.H, st.W)
-                nslab = st.wg_splits * 32 * 160
+                st.wg_splits = lib.kodhip_stem_bwd_fused_blocks(B, st.H, st.W, u.cout)
+                nslab = st.wg_splits * (32 if u.cout <= 32 else 64) * 160
                 self.stem_part = torch.empty(nslab, dtype=torch.float32, device=dev)    # (it runs on the main stream)
             # slab region [splits][cout][Kp] (floats): ONE scratch shared by all layers (reduced right after each weight
             # gradient, while it is still in the 256 MB Infinity Cache) - or, for the per-bucket reduction, a region each

@@ -778,7 +778,7 @@ def test_yv5m_bench_geometry_b64_640_deterministic_and_teacher_forced():
         X = eng.act[u.src.buf.name][..., u.src.coff:u.src.coff + u.src.C].float().permute(0, 3, 1, 2).cpu()
         W = bf(params[u.name + ".0.weight"]).requires_grad_(True)
         y = F.conv2d(X, W, None, u.s, u.p)
-        y.backward(st.raw.float().permute(0, 3, 1, 2).cpu())          # st.raw holds dY after backward
+        y.backward(_dY(eng, u).float().permute(0, 3, 1, 2).cpu())     # (st.raw holds dY after backward; fused stem: _dY)
         e = _rel(grads[u.name + ".0.weight"], W.grad)
         worst["dW"] = max(worst.get("dW", 0.0), e)
         assert e <= 5e-3, ("dW", u.name, e)

@@ -167,12 +167,14 @@ def test_stem_conv():
     _close(gw.cpu(), wr.grad, 2e-3, 2e-3 * wr.grad.abs().max().item(), "stem wgrad")
 
 
-@pytest.mark.parametrize("case", [(2, 32, 72, 32, 32, 0), (1, 16, 640, 32, 32, 0), (3, 12, 400, 16, 16, 0), (2, 8, 416, 32, 64, 16)])
+@pytest.mark.parametrize("case", [(2, 32, 72, 32, 32, 0), (1, 16, 640, 32, 32, 0), (3, 12, 400, 16, 16, 0), (2, 8, 416, 32, 64, 16),
+                                  (2, 16, 400, 48, 48, 0), (1, 12, 640, 64, 96, 24), (2, 8, 72, 40, 40, 0)])
 def test_stem_backward_fused(case):
     """kodhip_stem_bwd_fused (BatchNorm/SiLU backward formed inside the stem's weight gradient, dY never written) against
     the two launches it replaces (kodhip_bn_silu_bwd_apply + kodhip_conv_wgrad stem form - same dY rounding, other
     summation order) and against torch on the dY those produce.  Rows of 36 / 320 / 200 / 208 pixel pairs: one ragged
-    tile, two full tiles, a full + a ragged tile; 16 output channels; dA as a channel slice of a wider buffer."""
+    tile, two full tiles, a full + a ragged tile; 16 output channels; dA as a channel slice of a wider buffer; 48 / 64 / 40
+    output channels (yv5m / yv5l stems: two 32-channel tiles per block, the second ragged)."""
     B, H, W, Cout, lda, dacoff = case
     g = torch.Generator().manual_seed(11 + H)
     lib = _lib.lib()
@@ -188,8 +190,8 @@ def test_stem_backward_fused(case):
     coef = torch.cat([torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.05,
                       torch.randn(Cout, generator=g) * 0.05]).cuda()
     # the fused kernel
-    blocks = lib.kodhip_stem_bwd_fused_blocks(B, H, Wo)
-    part = torch.full((blocks * 32 * 160,), float("nan"), dtype=torch.float32, device="cuda")
+    blocks = lib.kodhip_stem_bwd_fused_blocks(B, H, Wo, Cout)
+    part = torch.full((blocks * (32 if Cout <= 32 else 64) * 160,), float("nan"), dtype=torch.float32, device="cuda")
     gw = torch.zeros((Cout, 3, 6, 6), dtype=torch.float32, device="cuda")
     y_before = y.clone()
     _lib.check(lib.kodhip_stem_bwd_fused(img.data_ptr(), dA.data_ptr(), lda, dacoff, y.data_ptr(), Cout,

@@ -12,7 +12,7 @@ y = torch.randn(M, N, device="cuda").to(torch.bfloat16)
 dA = torch.randn(M, N, device="cuda").to(torch.bfloat16)
 scale, shift = torch.rand(N, device="cuda") + 0.5, torch.randn(N, device="cuda") * 0.3
 coef = torch.cat([torch.rand(N) + 0.5, torch.randn(N) * 0.05, torch.randn(N) * 0.05]).cuda()
-blocks = lib.kodhip_stem_bwd_fused_blocks(B, H, Wp)
+blocks = lib.kodhip_stem_bwd_fused_blocks(B, H, Wp, N)
 part = torch.empty(blocks * 32 * 160, device="cuda")
 gw = torch.zeros(N, 3, 6, 6, device="cuda")
 splits = lib.kodhip_conv_wgrad_splits_geo(B, H, Wp, 8, 8, N, 6, 3, 2, 1, 2, 1, 160, N)
