@@ -346,7 +346,7 @@ def self_launch(args) -> int:
     return 0
 
 
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def pmc_traffic(family, B, S):

@@ -313,9 +313,11 @@ typedef struct KodPeerView {                       /* passed BY VALUE to the *_p
   unsigned long long* peers[KODHIP_PEER_MAX];
   int world, rank;
   const unsigned int* seq;
-  int* timeout_flag;
+  int* timeout_flag;                               /* device: 1 = a poll gave up, 2 = the ranks' step counters diverged */
+  int* host_flag;                                  /* the same verdict mirrored into pinned host memory */
   long max_spins;                                  /* polls before a wait gives up and raises the flag */
 } KodPeerView;
+/* fails (no coarse-grained fallback) when fine-grained device memory cannot be had: the caller keeps the RCCL exchanges */
 int kodhip_peer_create(void** peer, int rank, int world, long granules /* 8-byte granules: 4 per channel per exchange site */);
 int kodhip_peer_export(void* peer, void* handle64 /* host, 64 bytes out: hipIpcMemHandle_t */);
 int kodhip_peer_connect(void* peer, const void* handles /* host, world x 64 bytes in rank order */);
@@ -323,7 +325,10 @@ int kodhip_peer_view_bytes(void);
 int kodhip_peer_view(void* peer, void* view_out /* host KodPeerView */);
 int kodhip_peer_step_begin(void* peer, kodStream_t stream);      /* once per step, before its first exchange */
 int kodhip_peer_allreduce_f64(void* peer, const double* in, double* out, int n, unsigned int slot, kodStream_t stream);
-int kodhip_peer_timed_out(void* peer, int* flag /* host out; synchronises */);
+int kodhip_peer_timed_out(void* peer, int* flag /* host out; synchronises, resets the flag */);
+/* the verdict without a device synchronisation (pinned host mirror): 0 ok, 1 a poll gave up, 2 step counters diverged.
+ * A failed exchange never folds a stale payload into the statistics: its sums become NaN. */
+int kodhip_peer_status(void* peer, int* flag /* host out */);
 int kodhip_peer_destroy(void* peer);
 
 #ifdef __cplusplus

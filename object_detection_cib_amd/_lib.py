@@ -98,6 +98,7 @@ SIGNATURES = {
     "kodhip_peer_step_begin": (i32, [vp, vp]),
     "kodhip_peer_allreduce_f64": (i32, [vp, vp, vp, i32, u32, vp]),
     "kodhip_peer_timed_out": (i32, [vp, C.POINTER(i32)]),
+    "kodhip_peer_status": (i32, [vp, C.POINTER(i32)]),
     "kodhip_peer_destroy": (i32, [vp]),
     "kodhip_comm_group_start": (i32, []),
     "kodhip_comm_group_end": (i32, []),

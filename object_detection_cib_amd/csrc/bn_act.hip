@@ -65,7 +65,8 @@ __device__ __forceinline__ void wave_sum_partials2(const float* p, const float* 
 // own exchange buffer, then poll the same four granules of EVERY rank (lane = 4 * rank + granule) and add the ranks'
 // values in rank order - every rank gets bit-identical totals.  Publishing precedes polling in every wave and waves
 // do not depend on each other, so ranks can arrive in any order; a poll that never sees its tag gives up after
-// max_spins polls (about a minute) and raises the timeout flag instead of hanging the GPU.
+// max_spins polls (about a minute), raises the flag (device + pinned host copy) and turns the sums into NaN instead of
+// hanging the GPU or folding the previous step's payload into the statistics (kod_peer_poll, kodhip_common.h).
 __device__ __forceinline__ void peer_allreduce2(const KodPeerView& pv, unsigned int slot, int idx0, int idx1, int lane,
                                                 double& s0, double& s1) {
   const unsigned int seq = *pv.seq;
@@ -80,19 +81,9 @@ __device__ __forceinline__ void peer_allreduce2(const KodPeerView& pv, unsigned 
     __hip_atomic_store(pv.peers[pv.rank] + gi, ((unsigned long long)seq << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   unsigned int got = 0;
+  bool bad = false;
   const int r = lane >> 2;
-  if (r < pv.world) {
-    const unsigned long long* src = pv.peers[r] + gi;
-    unsigned long long v = 0;
-    long spins = 0;
-    for (;;) {
-      v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((unsigned int)(v >> 32) == seq) break;
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > pv.max_spins) { *pv.timeout_flag = 1; break; }          // a peer is gone
-    }
-    got = (unsigned int)v;
-  }
+  if (r < pv.world) got = (unsigned int)kod_peer_poll(pv, pv.peers[r] + gi, seq, bad);
   double t0 = 0.0, t1 = 0.0;
   for (int q = 0; q < pv.world; ++q) {                   // fixed rank order
     const unsigned long long lo0 = __shfl(got, 4 * q + 0, 64), hi0 = __shfl(got, 4 * q + 1, 64);
@@ -100,6 +91,7 @@ __device__ __forceinline__ void peer_allreduce2(const KodPeerView& pv, unsigned 
     t0 += __longlong_as_double((long long)((hi0 << 32) | lo0));
     t1 += __longlong_as_double((long long)((hi1 << 32) | lo1));
   }
+  if (__ballot(bad) != 0ull) t0 = t1 = __longlong_as_double(0x7ff8000000000000ll);     // never a stale payload in the sums
   s0 = t0; s1 = t1;
 }
 

@@ -155,12 +155,31 @@ struct PeerComm {
   int rank = 0, world = 1;
   long granules = 0;
   unsigned char* local = nullptr;               // [256 B header: seq, timeout flag][granules * 8 B]
+  int* host_flag = nullptr;                     // pinned host copy of the verdict (read without synchronising the device)
   void* mapped[KOD_PEER_MAX] = {};
   KodPeerView view = {};
 };
 constexpr long PEER_HEADER = 256;
 
-__global__ void peer_step_begin_kernel(unsigned int* seq) { *seq += 1u; }
+// bumps this rank's step number (published in the buffer header) and compares it with every peer's: when this rank
+// begins step s a peer is at s - 1 (still finishing: its last exchanges needed this rank's step s - 1 publishes) or
+// already at s - anything else means the ranks' step counters diverged (one extra training forward on one rank, uneven
+// batch counts) and the run is condemned at once instead of after a minute of polling.
+__global__ void peer_step_begin_kernel(unsigned int* seq, KodPeerView pv) {
+  const int r = threadIdx.x;
+  unsigned int mine = 0;
+  if (r == 0) { mine = *seq + 1u; __hip_atomic_store(seq, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+  mine = __shfl(mine, 0, 64);
+  if (r < pv.world && r != pv.rank) {
+    const unsigned int* ps = (const unsigned int*)((const unsigned char*)pv.peers[r] - 256);
+    const unsigned int theirs = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int d = (int)(theirs - mine);
+    if (d > 0 || d < -1) {
+      __hip_atomic_store(pv.timeout_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pv.host_flag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 
 // transport self-test / generic form: out[i] = sum over ranks of in[i] (pairs of values per wave, like the BN kernels)
 __global__ void peer_allreduce_f64_kernel(const double* in, double* out, int n, KodPeerView pv, unsigned int slot) {
@@ -180,19 +199,9 @@ __global__ void peer_allreduce_f64_kernel(const double* in, double* out, int n, 
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   unsigned int got = 0;
+  bool bad = false;
   const int r = lane >> 2;
-  if (r < pv.world && (g < 2 || second_ok)) {
-    const unsigned long long* src = pv.peers[r] + gi;
-    unsigned long long v = 0;
-    long spins = 0;
-    for (;;) {
-      v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((unsigned int)(v >> 32) == seq) break;
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > pv.max_spins) { *pv.timeout_flag = 1; break; }
-    }
-    got = (unsigned int)v;
-  }
+  if (r < pv.world && (g < 2 || second_ok)) got = (unsigned int)kod_peer_poll(pv, pv.peers[r] + gi, seq, bad);
   double t0 = 0.0, t1 = 0.0;
   for (int q = 0; q < pv.world; ++q) {
     const unsigned long long lo0 = __shfl(got, 4 * q + 0, 64), hi0 = __shfl(got, 4 * q + 1, 64);
@@ -200,6 +209,7 @@ __global__ void peer_allreduce_f64_kernel(const double* in, double* out, int n, 
     t0 += __longlong_as_double((long long)((hi0 << 32) | lo0));
     t1 += __longlong_as_double((long long)((hi1 << 32) | lo1));
   }
+  if (__ballot(bad) != 0ull) t0 = t1 = __longlong_as_double(0x7ff8000000000000ll);
   if (lane == 0) {
     out[i0] = t0;
     if (second_ok) out[i1] = t1;
@@ -227,16 +237,25 @@ int kodhip_peer_create(void** peer, int rank, int world, long granules) {
   c->rank = rank; c->world = world; c->granules = granules;
   const size_t bytes = PEER_HEADER + (size_t)granules * 8;
   void* p = nullptr;
+  // fine-grained or nothing: relaxed system-scope polling across GPUs is only coherent on fine-grained memory, so a
+  // failed allocation is an error the caller answers by keeping the RCCL exchanges (no coarse-grained fallback)
   hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    e = hipMalloc(&p, bytes);
+    delete c;
+    kodhip_set_error("peer_create: fine-grained device memory for the exchange buffer: %s", hipGetErrorString(e));
+    return (int)e;
   }
-  if (e != hipSuccess) { delete c; kodhip_set_error("peer_create: %s", hipGetErrorString(e)); return (int)e; }
   c->local = (unsigned char*)p;
   e = hipMemset(p, 0, bytes);
-  if (e == hipSuccess) e = hipDeviceSynchronize();
-  if (e != hipSuccess) { (void)hipFree(p); delete c; kodhip_set_error("peer_create: %s", hipGetErrorString(e)); return (int)e; }
+  void* hf = nullptr;
+  if (e == hipSuccess) e = hipHostMalloc(&hf, 64, hipHostMallocMapped);
+  if (e == hipSuccess) { memset(hf, 0, 64); c->host_flag = (int*)hf; e = hipDeviceSynchronize(); }
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    if (hf) (void)hipHostFree(hf);
+    delete c; kodhip_set_error("peer_create: %s", hipGetErrorString(e)); return (int)e;
+  }
   *peer = c;
   return KOD_OK;
 }
@@ -269,6 +288,9 @@ int kodhip_peer_connect(void* peer, const void* handles) {
   c->view.world = c->world; c->view.rank = c->rank;
   c->view.seq = (const unsigned int*)c->local;
   c->view.timeout_flag = (int*)(c->local + 64);
+  void* hfd = nullptr;
+  KOD_HIP(hipHostGetDevicePointer(&hfd, c->host_flag, 0), "peer_connect");
+  c->view.host_flag = (int*)hfd;
   c->view.max_spins = 1l << 26;              // inside a training step: about a minute
   return KOD_OK;
 }
@@ -288,7 +310,8 @@ int kodhip_peer_view(void* peer, void* view_out) {
 int kodhip_peer_step_begin(void* peer, hipStream_t stream) {
   KOD_CHECK_ARG(peer, "peer_step_begin: null");
   PeerComm* c = (PeerComm*)peer;
-  hipLaunchKernelGGL(peer_step_begin_kernel, dim3(1), dim3(1), 0, stream, (unsigned int*)c->local);
+  KOD_CHECK_ARG(c->view.world == c->world, "peer_step_begin: call kodhip_peer_connect first");
+  hipLaunchKernelGGL(peer_step_begin_kernel, dim3(1), dim3(64), 0, stream, (unsigned int*)c->local, c->view);
   KOD_LAUNCH_CHECK("peer_step_begin");
   return KOD_OK;
 }
@@ -307,14 +330,25 @@ int kodhip_peer_allreduce_f64(void* peer, const double* in, double* out, int n, 
   return KOD_OK;
 }
 
-// 1 when a poll gave up since the last call (synchronises the device); resets the flag
+// non-zero when an exchange failed since the last call (1: a poll gave up, 2: the ranks' step counters diverged);
+// synchronises the device and resets the flag
 int kodhip_peer_timed_out(void* peer, int* flag) {
   KOD_CHECK_ARG(peer && flag, "peer_timed_out: null");
   PeerComm* c = (PeerComm*)peer;
   int v = 0;
   KOD_HIP(hipMemcpy(&v, c->local + 64, sizeof(int), hipMemcpyDeviceToHost), "peer_timed_out");
   if (v) { int z = 0; KOD_HIP(hipMemcpy(c->local + 64, &z, sizeof(int), hipMemcpyHostToDevice), "peer_timed_out"); }
+  if (c->host_flag) *(volatile int*)c->host_flag = 0;
   *flag = v;
+  return KOD_OK;
+}
+
+// the same verdict WITHOUT touching the device: the kernels mirror it into pinned host memory, so the training loop
+// can look at it once per step (engine: before every step / replay) and raise instead of training on NaN statistics
+int kodhip_peer_status(void* peer, int* flag) {
+  KOD_CHECK_ARG(peer && flag, "peer_status: null");
+  PeerComm* c = (PeerComm*)peer;
+  *flag = c->host_flag ? *(volatile int*)c->host_flag : 0;
   return KOD_OK;
 }
 
@@ -325,6 +359,7 @@ int kodhip_peer_destroy(void* peer) {
   for (int r = 0; r < c->world; ++r)
     if (r != c->rank && c->mapped[r]) (void)hipIpcCloseMemHandle(c->mapped[r]);
   if (c->local) (void)hipFree(c->local);
+  if (c->host_flag) (void)hipHostFree(c->host_flag);
   delete c;
   return KOD_OK;
 }

@@ -76,10 +76,44 @@ struct KodPeerView {
   unsigned long long* peers[KOD_PEER_MAX];   // device-visible base of rank r's granule area (own rank: the local buffer)
   int world, rank;
   const unsigned int* seq;                   // device: sequence number of the current step (kodhip_peer_step_begin)
-  int* timeout_flag;                         // device: set when a poll gave up (a peer never published)
+  int* timeout_flag;                         // device: 1 when a poll gave up (a peer never published), 2 when a peer's tag or
+                                             // step number ran AHEAD of this rank's (the ranks' step counters diverged)
+  int* host_flag;                            // the same verdict in pinned host memory: the training loop reads it without a
+                                             // device synchronisation (kodhip_peer_status)
   long max_spins;                            // polls before giving up: ~a minute inside a training step (ranks may reach their
                                              // first exchange seconds apart), seconds in the start-up self-test
 };
+
+// One granule poll of the exchange: returns the granule once its tag is this step's.  A poll that gives up, a tag
+// from the future (no rank can be a step ahead at a slot this rank has not read yet: its later exchanges of the step
+// need this rank's later publishes) or a verdict already raised earlier in the run (every later exchange then leaves at
+// once instead of spinning for a minute each) sets `bad`: the caller turns the sums into NaN, so that the statistics
+// are never built from a stale payload and the loss trips.
+__device__ __forceinline__ unsigned long long kod_peer_poll(const KodPeerView& pv, const unsigned long long* src,
+                                                            unsigned int seq, bool& bad) {
+  const int raised = __hip_atomic_load(pv.timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long v = 0;
+  long spins = 0;
+  for (;;) {
+    v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned int tag = (unsigned int)(v >> 32);
+    if (tag == seq) break;
+    int why = 0;
+    if ((int)(tag - seq) > 0) why = 2;                 // desynchronised step counters
+    else if (raised) why = raised;                     // the run is already condemned
+    else if (++spins > pv.max_spins) why = 1;          // a peer is gone
+    if (why) {
+      bad = true;
+      if (!raised) {
+        __hip_atomic_store(pv.timeout_flag, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pv.host_flag, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  return v;
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline uint32_t magic_u32(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }

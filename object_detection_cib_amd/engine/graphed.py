@@ -134,6 +134,8 @@ class GraphedTrainStep:
             raise RuntimeError("call capture() first")
         if lr is not None:
             self.eng.set_hyper(lr, momentum, weight_decay, grad_scale)
+        if self.eng.peer is not None:
+            self.eng.peer.check()             # a failed SyncBN exchange of an earlier replay: raise, do not train on NaN
         self._load(images, targets)
         self.graph.replay()
         self.eng.param_version += 1           # the replayed SGD changed the parameters

@@ -68,9 +68,12 @@ class DefaultYolov5Experiment:
         # arithmetic, no per-launch Python; batches must keep one shape and at most max_targets boxes
         self.graphed, self.max_targets, self._gstep = graphed, max_targets, None
         self._geval = {}              # input shape -> GraphedEvalForward
-        # cross-rank validation is opt-in: None = every rank reports its own shard (a rank-0-only validation never
-        # meets a collective); a process group + "mean" / "global" = DeviceMAPEvaluator.get_report's two DDP modes
-        self.val_process_group, self.val_sync = None, "mean"
+        # cross-rank validation: "auto" (default) = the group the network was made data-parallel over
+        # (Yolov5Network.configure_distributed) with sync "mean", i.e. what the reference logs under DDP
+        # (`log_dict(results, sync_dist=True)`, pycoco_map_eval.py:139-142); without such a group every rank reports its
+        # own shard.  None = never a collective (rank-0-only validation cannot hang on its peers); an explicit process
+        # group + "mean" / "global" = DeviceMAPEvaluator.get_report's two DDP modes
+        self.val_process_group, self.val_sync = "auto", "mean"
 
     # exp.py:156-162
     def configure_optimizers(self):
@@ -177,4 +180,14 @@ class DefaultYolov5Experiment:
             for b in batches:
                 targets, dets = self.validation_step(b)
                 ev.add_batch(targets, dets)
-        return ev.get_report(self.val_process_group, self.val_sync)
+        return ev.get_report(self._val_group(), self.val_sync)
+
+    def _val_group(self):
+        pg = self.val_process_group
+        if isinstance(pg, str) and pg == "auto":
+            eng = getattr(self.net, "_engine", None)
+            if eng is None or getattr(eng, "world_size", 1) <= 1:
+                return None
+            import torch.distributed as dist
+            return eng.process_group if eng.process_group is not None else dist.group.WORLD
+        return pg
