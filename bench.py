@@ -233,6 +233,14 @@ def validation_leg(net, loss_fn, B, S, nc, device, batches=12):
                         "random-init weights"}
 
 
+def profile_step(eng, step):
+    """Per-kernel durations of every family: eager steps with HIP events around each launch on its launch stream (events
+    cannot be read back from inside a replayed graph); weight gradients on the main stream for these steps so that the
+    families do not overlap each other.  Returns the engine's raw profile list for family_table()."""
+    prof = profile_step(eng, step)
+    return prof
+
+
 def variant_leg(variant, B, S, nc, device, steps=12):
     """Another network scale through the same engine (yv5m = BASELINE configs[4]'s network), one GPU, hipGraph replay of
     train_step + fused SGD on a resident synthetic batch - measured like `value`, reported beside it."""
@@ -270,9 +278,11 @@ def variant_leg(variant, B, S, nc, device, steps=12):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     algo_bytes, _ = algorithmic_work(widen, deepen, nc, S)
+    fams = [{k: r[k] for k in ("family", "launches", "ms", "share_of_step", "GB/s", "frac")} for r in family_table(profile_step(eng, step))]
     return {"value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
             "step_roofline_frac": round(B / dt * algo_bytes / 8e12, 4), "final_loss": float(last),
-            "workload": f"{variant}, B={B}, {S}px, hipGraph replay of train_step + fused SGD, resident synthetic batch"}
+            "workload": f"{variant}, B={B}, {S}px, hipGraph replay of train_step + fused SGD, resident synthetic batch",
+            "families": fams}
 
 
 def self_launch(args) -> int:
@@ -347,6 +357,26 @@ def self_launch(args) -> int:
 
 
 PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+
+
+def stamp_report(eng, graph, step, file=sys.stderr):
+    """KODHIP_DEBUG_STAMPS=1: device clock stamps (kodhip_debug_stamp, 100 MHz) taken inside the step - also a replayed
+    hipGraph, without a profiler attached: when each weight gradient starts relative to the main chain's stamp of the same
+    unit, and when the two streams end."""
+    for rep in range(3):
+        graph.replay() if graph is not None else step()
+        torch.cuda.synchronize()
+        v = eng.stamp_buf.cpu().numpy()
+        t = {n: (int(v[i]) - int(v[eng.stamp_names.index("fwd_begin")])) / 100.0 for i, n in enumerate(eng.stamp_names)}
+        print("[stamps rep %d, us from fwd_begin] fwd_end %.0f bwd_begin %.0f main_end %.0f wg_end %.0f bwd_end %.0f" % (
+            rep, t["fwd_end"], t["bwd_begin"], t["main_end"], t.get("wg_end", -1), t["bwd_end"]), file=file)
+    rows = []
+    for n in eng.stamp_names:
+        if n.startswith("wg:"):
+            base = n[3:].split("+")[0]
+            m = t.get("m:" + base)
+            rows.append("%-44s wgrad at %8.0f   main chain reached the unit at %s" % (n[3:][-44:], t[n], "%8.0f (lag %6.0f)" % (m, t[n] - m) if m is not None else "-"))
+    print("\n".join(rows), file=file)
 
 
 def pmc_traffic(family, B, S):
@@ -536,6 +566,8 @@ def main():
             last = step()
     barrier()
     dt = time.perf_counter() - t0
+    if eng.stamps_on:          # KODHIP_DEBUG_STAMPS=1: where the step's time goes, from device clock stamps
+        stamp_report(eng, graph, step)
     # per-kernel durations of every family: one extra eager step with HIP events around each launch on its launch
     # stream, outside the timed region (events cannot be read back from inside a replayed graph); weight gradients
     # on the main stream for this step so that the families do not overlap each other

@@ -175,6 +175,15 @@ int kodhip_bn_finalize_partials(const float* partials, int T, double count, cons
                                 float* running_mean, float* running_var, float momentum, float eps,
                                 float* scale, float* shift, float* mean, float* rstd, int C, int update_running,
                                 kodStream_t stream);
+/* two units whose convolution ran as ONE launch with N = 2 * Ch columns - a CSP layer's main_conv + short_conv
+ * (kod/nn/layers/csp.py:87-88: same input): partials [2][2 * Ch][T], unit h owns channels [h * Ch, (h + 1) * Ch); aff* =
+ * scale | shift | mean | rstd.  view != NULL: SyncBN over the peer buffers (slot0 / slot1, count = pixels of all ranks) */
+int kodhip_bn_finalize_partials_pair(const float* partials, int T, double count, int Ch, float momentum, float eps,
+                                     int update_running,
+                                     const float* gamma0, const float* beta0, float* running_mean0, float* running_var0, float* aff0,
+                                     const float* gamma1, const float* beta1, float* running_mean1, float* running_var1, float* aff1,
+                                     const void* view /* host KodPeerView or NULL */, unsigned int slot0, unsigned int slot1,
+                                     kodStream_t stream);
 /* SyncBN forms of the two single launches: the rank's sums are exchanged through the peer buffers (kodhip_peer_*, below)
  * inside the kernel.  count = pixels of ALL ranks; view = host KodPeerView (copied into the launch); slot = first granule
  * of this exchange (it uses 4 * C).  Parameter gradients (dgamma, dbeta) keep the rank's own sums. */
@@ -198,6 +207,12 @@ int kodhip_bn_bwd_coeffs_partials(const float* partials, int T, double count, co
 int kodhip_bn_silu_apply(const void* y, int ldy /* row stride of y (>= C: y may be a channel slice) */, const float* scale, const float* shift,
                          const void* residual, int ldr, int rcoff,
                          void* out, int ldo, int ocoff, long M, int C, kodStream_t stream);
+/* the apply passes of two units whose pre-BN outputs are the channel halves of one tensor y[m][2 * Ch] (one convolution
+ * launch for a CSP layer's main_conv + short_conv, csp.py:87-88), each half to its own destination slice */
+int kodhip_bn_silu_apply_pair(const void* y, int ldy, int Ch,
+                              const float* scale0, const float* shift0, void* out0, int ldo0, int ocoff0,
+                              const float* scale1, const float* shift1, void* out1, int ldo1, int ocoff1,
+                              long M, kodStream_t stream);
 int kodhip_bn_bwd_slots(long M, int C);
 int kodhip_bn_silu_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, int ldy, const float* scale,
                               const float* shift, const float* mean, const float* rstd, float* partials,
@@ -229,6 +244,8 @@ int kodhip_sgd_nesterov(float* params, const float* grads, float* momentum_buf, 
                         long n, const float* hyper /* device, 10 floats: lr[3] momentum[3] wd[3] grad_scale */,
                         kodStream_t stream);
 int kodhip_fill_u32(void* p, uint32_t value, long n, kodStream_t stream);
+/* debug: *dst = the device's constant-rate wall clock (100 MHz), stream-ordered - time stamps inside a replayed hipGraph */
+int kodhip_debug_stamp(unsigned long long* dst, kodStream_t stream);
 
 /* ---- target assignment + loss (kod/core/label_assignment/yv5.py:45-319,
  *      kod/lightning/experiments/yv5_baseline/loss.py:65-248, kod/core/bbox/iou.py:200-246) ---------- */

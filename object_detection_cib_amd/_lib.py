@@ -67,6 +67,8 @@ SIGNATURES = {
     "kodhip_bn_reduce_partials": (i32, [vp, vp, i32, i32, vp]),
     "kodhip_bn_finalize": (i32, [vp, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_finalize_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp]),
+    "kodhip_bn_finalize_partials_pair": (i32, [vp, i32, f64, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp]),
+    "kodhip_bn_silu_apply_pair": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i64, vp]),
     "kodhip_bn_bwd_coeffs_partials": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_bwd_coeffs_partials2": (i32, [vp, i32, f64, vp, vp, vp, vp, vp, vp, i32, i32] * 2 + [vp]),
     "kodhip_bn_finalize_partials_peer": (i32, [vp, i32, f64, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, i32, i32, vp, u32, vp]),
@@ -83,6 +85,7 @@ SIGNATURES = {
     "kodhip_head_bwd_prep": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "kodhip_sgd_nesterov": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "kodhip_fill_u32": (i32, [vp, u32, i64, vp]),
+    "kodhip_debug_stamp": (i32, [vp, vp]),
     "kodhip_comm_load": (i32, [C.c_char_p]),
     "kodhip_comm_unique_id": (i32, [vp]),
     "kodhip_comm_init": (i32, [C.POINTER(vp), vp, i32, i32]),

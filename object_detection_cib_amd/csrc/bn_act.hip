@@ -165,6 +165,46 @@ __global__ void bn_finalize_fused_kernel(const float* part, int T, double count,
   }
 }
 
+// Two units whose convolution ran as ONE launch (a CSP layer's main_conv + short_conv as N = 2 * Ch columns,
+// kod/nn/layers/csp.py:87-88): the statistic slots are [2][2 * Ch][T]; blockIdx.y picks the unit (channels
+// [half * Ch, (half + 1) * Ch) of both moments), each with its own parameters, running statistics and constants.
+struct FinJob {
+  const float* gamma; const float* beta; float* running_mean; float* running_var;
+  float* scale; float* shift; float* mean; float* rstd;
+  unsigned int slot;
+};
+template <bool PEER>
+__global__ void bn_finalize_pair_kernel(const float* part, int T, double count, float momentum, float eps, int Ch,
+                                        int update_running, FinJob j0, FinJob j1, KodPeerView pv) {
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (c >= Ch) return;
+  const int half = blockIdx.y;
+  const FinJob j = half ? j1 : j0;
+  const int lane = threadIdx.x & 63;
+  const float* p0 = part + (size_t)(half * Ch + c) * T;
+  const float* p1 = part + (size_t)(2 * Ch + half * Ch + c) * T;
+  const float g = j.gamma[c], b = j.beta[c];
+  const float rm0 = update_running ? j.running_mean[c] : 0.f, rv0 = update_running ? j.running_var[c] : 0.f;
+  double s0, s1;
+  wave_sum_partials2(p0, p1, T, lane, s0, s1);
+  if constexpr (PEER) peer_allreduce2(pv, j.slot, c, Ch + c, lane, s0, s1);
+  if (lane != 0) return;
+  double mean = s0 / count;
+  double var = s1 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float sc = g * rstd;
+  j.scale[c] = sc;
+  j.shift[c] = b - (float)mean * sc;
+  j.mean[c] = (float)mean;
+  j.rstd[c] = rstd;
+  if (update_running) {
+    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    j.running_mean[c] = (1.f - momentum) * rm0 + momentum * (float)mean;
+    j.running_var[c] = (1.f - momentum) * rv0 + momentum * (float)unbiased;
+  }
+}
+
 // raw_moment: the second partial is sum dz*y (produced by the data-gradient epilogue, conv_igemm.hip MODE_PLAIN_BN)
 // instead of sum dz*xhat; xhat = (y - mean)*rstd  =>  sum dz*xhat = rstd * (sum dz*y - mean * sum dz), in fp64.
 template <bool PEER = false>
@@ -271,6 +311,49 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, int
         }
       }
       *reinterpret_cast<bf16x8*>(out + m * ldo + ocoff + cc * 8) = o;
+    }
+  }
+}
+
+// Two units whose pre-BN outputs are the two channel halves of ONE tensor y[m][2 * Ch] (a CSP layer's main_conv +
+// short_conv computed by one convolution launch): one pass over y, each half to its own destination slice.
+__global__ __launch_bounds__(256) void bn_silu_apply_pair_kernel(const bf16_t* y, int ldy,
+                                     const float* scale0, const float* shift0, bf16_t* out0, int ldo0, int ocoff0,
+                                     const float* scale1, const float* shift1, bf16_t* out1, int ldo1, int ocoff1,
+                                     long M, int Ch, int rows_per_block_iter) {
+  const int CC = Ch >> 2;                     // 16-byte chunks of a row of y (2 * Ch channels)
+  const int cc = threadIdx.x % CC;
+  const int rl = threadIdx.x / CC;
+  if (rl >= rows_per_block_iter) return;
+  const bool second = cc >= (CC >> 1);
+  const int c0 = (second ? cc - (CC >> 1) : cc) * 8;          // first channel of this chunk inside its unit
+  const float* scale = second ? scale1 : scale0;
+  const float* shift = second ? shift1 : shift0;
+  bf16_t* out = second ? out1 + ocoff1 : out0 + ocoff0;
+  const int ldo = second ? ldo1 : ldo0;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
+  const long stride = (long)gridDim.x * rows_per_block_iter;
+  for (long m0 = (long)blockIdx.x * rows_per_block_iter + rl; m0 < M; m0 += stride * U) {
+    bf16x8 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long m = m0 + u * stride;
+      if (m < M) v[u] = *reinterpret_cast<const bf16x8*>(y + m * ldy + cc * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long m = m0 + u * stride;
+      if (m >= M) break;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yv = (float)v[u][e];
+        const float z = __builtin_fmaf(yv, sc[e], sh[e]);
+        o[e] = (bf16_t)(z * kod_sigmoid_l2(KOD_NEG_LOG2E * z));
+      }
+      *reinterpret_cast<bf16x8*>(out + m * ldo + c0) = o;
     }
   }
 }
@@ -458,6 +541,34 @@ int kodhip_bn_finalize_partials(const float* partials, int T, double count, cons
   return KOD_OK;
 }
 
+// Batch statistics -> BatchNorm constants of TWO units whose convolution was one launch with N = 2 * Ch columns
+// (partials [2][2 * Ch][T], unit h owns channels [h * Ch, (h + 1) * Ch)): one launch for both.  aff0 / aff1 =
+// scale | shift | mean | rstd (4 * Ch floats each).  view != NULL: SyncBN over the peer buffers (slot0 / slot1 = first
+// granule of each unit's exchange, count = pixels of ALL ranks).
+int kodhip_bn_finalize_partials_pair(const float* partials, int T, double count, int Ch, float momentum, float eps,
+                                     int update_running,
+                                     const float* gamma0, const float* beta0, float* running_mean0, float* running_var0, float* aff0,
+                                     const float* gamma1, const float* beta1, float* running_mean1, float* running_var1, float* aff1,
+                                     const void* view, unsigned int slot0, unsigned int slot1, hipStream_t stream) {
+  KOD_CHECK_ARG(partials && gamma0 && beta0 && aff0 && gamma1 && beta1 && aff1 && Ch > 0 && T > 0 && count > 0,
+                "bn_finalize_partials_pair: bad args");
+  KOD_CHECK_ARG(!update_running || (running_mean0 && running_var0 && running_mean1 && running_var1),
+                "bn_finalize_partials_pair: running stats missing");
+  FinJob j0 = {gamma0, beta0, running_mean0, running_var0, aff0, aff0 + Ch, aff0 + 2 * Ch, aff0 + 3 * Ch, slot0};
+  FinJob j1 = {gamma1, beta1, running_mean1, running_var1, aff1, aff1 + Ch, aff1 + 2 * Ch, aff1 + 3 * Ch, slot1};
+  if (view) {
+    const KodPeerView pv = *(const KodPeerView*)view;
+    KOD_CHECK_ARG(pv.world >= 1 && pv.world <= KOD_PEER_MAX && pv.world * 4 <= 64, "bn_finalize_partials_pair: bad peer view");
+    hipLaunchKernelGGL(bn_finalize_pair_kernel<true>, dim3(cdiv(Ch, 4), 2), dim3(256), 0, stream, partials, T, count, momentum,
+                       eps, Ch, update_running, j0, j1, pv);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_pair_kernel<false>, dim3(cdiv(Ch, 4), 2), dim3(256), 0, stream, partials, T, count, momentum,
+                       eps, Ch, update_running, j0, j1, KodPeerView{});
+  }
+  KOD_LAUNCH_CHECK("bn_finalize_partials_pair");
+  return KOD_OK;
+}
+
 // SyncBN forms (kod/configs/trainer/ddp.yaml:9 sync_batchnorm): the same single launches, with the rank's two sums
 // per channel exchanged through the peer buffers of kodhip_peer_* inside the kernel.  count = pixels of ALL ranks;
 // slot = first granule of this exchange in the buffers (4 * C granules); view = kodhip_peer_view's struct.
@@ -526,6 +637,23 @@ int kodhip_bn_silu_apply(const void* y, int ldy, const float* scale, const float
   hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, ldy, scale, shift,
                      (const bf16_t*)residual, ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb);
   KOD_LAUNCH_CHECK("bn_silu_apply");
+  return KOD_OK;
+}
+
+// y[m][2 * Ch] (row stride ldy) -> silu(bn(.)) of channels [0, Ch) into out0's slice and of [Ch, 2 * Ch) into out1's:
+// the two apply passes of a CSP layer's main_conv / short_conv pair as one launch (same arithmetic as kodhip_bn_silu_apply)
+int kodhip_bn_silu_apply_pair(const void* y, int ldy, int Ch,
+                              const float* scale0, const float* shift0, void* out0, int ldo0, int ocoff0,
+                              const float* scale1, const float* shift1, void* out1, int ldo1, int ocoff1,
+                              long M, hipStream_t stream) {
+  KOD_CHECK_ARG(y && scale0 && shift0 && out0 && scale1 && shift1 && out1 && M > 0, "bn_silu_apply_pair: bad args");
+  KOD_CHECK_ARG(Ch % 8 == 0 && Ch > 0 && 2 * Ch <= 2048 && ldy % 8 == 0 && ldy >= 2 * Ch, "bn_silu_apply_pair: bad channel geometry");
+  KOD_CHECK_ARG(ldo0 % 8 == 0 && ocoff0 % 8 == 0 && ocoff0 + Ch <= ldo0 && ldo1 % 8 == 0 && ocoff1 % 8 == 0 && ocoff1 + Ch <= ldo1,
+                "bn_silu_apply_pair: bad destination slice");
+  Geo g = geo(M, 2 * Ch, 4096);
+  hipLaunchKernelGGL(bn_silu_apply_pair_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, ldy,
+                     scale0, shift0, (bf16_t*)out0, ldo0, ocoff0, scale1, shift1, (bf16_t*)out1, ldo1, ocoff1, M, Ch, g.rpb);
+  KOD_LAUNCH_CHECK("bn_silu_apply_pair");
   return KOD_OK;
 }
 

@@ -396,6 +396,8 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n) {
   if (i < n) p[i] = v;
 }
 
+__global__ void stamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
+
 }  // namespace
 
 extern "C" {
@@ -495,6 +497,15 @@ int kodhip_sgd_nesterov(float* params, const float* grads, float* momentum_buf, 
   hipLaunchKernelGGL(sgd_nesterov_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, params, grads, momentum_buf,
                      (const unsigned char*)group_ids, n, hyper);
   KOD_LAUNCH_CHECK("sgd_nesterov");
+  return KOD_OK;
+}
+
+// debug: the device's constant-rate clock (100 MHz) written by a one-lane kernel - a time stamp INSIDE a captured,
+// replayed step, where HIP events cannot be read back and a profiler changes the schedule (bench.py stamp_report)
+int kodhip_debug_stamp(unsigned long long* dst, hipStream_t stream) {
+  KOD_CHECK_ARG(dst, "debug_stamp: null");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, stream, dst);
+  KOD_LAUNCH_CHECK("debug_stamp");
   return KOD_OK;
 }
 

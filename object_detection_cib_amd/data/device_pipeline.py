@@ -25,108 +25,8 @@ from .. import _lib
 from .detection import DetectionTarget
 
 
-class AffineParams(NamedTuple):            # default.py:31-58 / configs/data/augmentations/aug_params.yaml
-    degrees: float = 0.0
-    translate: float = 0.1
-    scale: float = 0.5
-    shear: float = 0.0
-    perspective: float = 0.0
-
-
-class HSVParams(NamedTuple):               # default.py:61-77
-    hue: float = 0.015
-    saturation: float = 0.7
-    value: float = 0.4
-
-
-class AugParams(NamedTuple):               # default.py:80-108
-    affine_params: AffineParams = AffineParams()
-    hsv_params: HSVParams = HSVParams()
-    flip_lr_prob: float = 0.5
-    image_color_transforms: bool = False
-
-
-# ----------------------------------------------------------------------------- host box / matrix math (numpy f64)
-def _box_candidates(orig, proc, eps, wh_thr=2.0, ar_thr=20.0, area_thr=0.1):
-    w1, h1 = orig[2] - orig[0], orig[3] - orig[1]
-    w2, h2 = proc[2] - proc[0], proc[3] - proc[1]
-    ar = np.maximum(w2 / (h2 + eps), h2 / (w2 + eps))
-    return (w2 > wh_thr) & (h2 > wh_thr) & (w2 * h2 / (w1 * h1 + eps) > area_thr) & (ar < ar_thr)
-
-
-def mosaic_layout(shapes: Sequence[Tuple[int, int]], xc: int, yc: int, S: int):
-    """Destination / source rectangles of the four tiles (mosaic.py:71-130)."""
-    rects = []
-    for i, (h, w) in enumerate(shapes):
-        if i == 0:
-            a = (max(xc - w, 0), max(yc - h, 0), xc, yc)
-            b = (w - (a[2] - a[0]), h - (a[3] - a[1]))
-        elif i == 1:
-            a = (xc, max(yc - h, 0), min(xc + w, 2 * S), yc)
-            b = (0, h - (a[3] - a[1]))
-        elif i == 2:
-            a = (max(xc - w, 0), yc, xc, min(2 * S, yc + h))
-            b = (w - (a[2] - a[0]), 0)
-        else:
-            a = (xc, yc, min(xc + w, 2 * S), min(2 * S, yc + h))
-            b = (0, 0)
-        rects.append((a, b))
-    return rects
-
-
-def mosaic_boxes(samples, rects, S: int):
-    """Shift / filter / clip of mosaic.py:134-153 (including the stale-box quirk on box-less tiles)."""
-    bbs, lbs = [], []
-    shifted = None
-    for (_, boxes, labels), (a, b) in zip(samples, rects):
-        if len(boxes) > 0:
-            shifted = boxes.copy()
-            shifted[:, [0, 2]] += a[0] - b[0]
-            shifted[:, [1, 3]] += a[1] - b[1]
-        bbs.append(shifted)
-        lbs.append(labels)
-    bb, lb = np.concatenate(bbs, 0), np.concatenate(lbs, 0)
-    keep = _box_candidates(bb.T, np.clip(bb, 0, 2 * S).T, 1e-7)
-    return np.clip(bb[keep], 0, 2 * S - 1), lb[keep]
-
-
-def affine_matrix(draws, w_in: int, h_in: int, border):
-    px, py, deg, sc, shx, shy, tx, ty = draws
-    w_out, h_out = w_in + 2 * border[1], h_in + 2 * border[0]
-    C = np.eye(3); C[0, 2] = -w_in / 2; C[1, 2] = -h_in / 2
-    P = np.eye(3); P[2, 0] = px; P[2, 1] = py
-    a = math.radians(deg)
-    R = np.eye(3)
-    R[0, 0] = R[1, 1] = sc * math.cos(a)
-    R[0, 1] = sc * math.sin(a); R[1, 0] = -sc * math.sin(a)
-    Sh = np.eye(3); Sh[0, 1] = math.tan(shx * math.pi / 180); Sh[1, 0] = math.tan(shy * math.pi / 180)
-    T = np.eye(3); T[0, 2] = tx * w_out; T[1, 2] = ty * h_out
-    return T @ Sh @ R @ P @ C, w_out, h_out
-
-
-def invert_affine(M):
-    """The inverse OpenCV's warpAffine builds from the forward 2x3 matrix (imgwarp.cpp)."""
-    m = np.array(M[:2], dtype=np.float64).copy()
-    D = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
-    D = 1.0 / D if D != 0 else 0.0
-    A11, A22 = m[1, 1] * D, m[0, 0] * D
-    m[0, 0] = A11; m[0, 1] *= -D; m[1, 0] *= -D; m[1, 1] = A22
-    b1 = -m[0, 0] * m[0, 2] - m[0, 1] * m[1, 2]
-    b2 = -m[1, 0] * m[0, 2] - m[1, 1] * m[1, 2]
-    m[0, 2], m[1, 2] = b1, b2
-    return m
-
-
-def affine_boxes(boxes, M, w_out, h_out, scale):
-    n = len(boxes)
-    xy = np.ones((n * 4, 3))
-    xy[:, :2] = boxes[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)
-    xy = (xy @ M.T)[:, :2].reshape(n, 8)
-    x, y = xy[:, [0, 2, 4, 6]], xy[:, [1, 3, 5, 7]]
-    nb = np.concatenate((x.min(1), y.min(1), x.max(1), y.max(1))).reshape(4, n).T
-    nb[:, [0, 2]] = nb[:, [0, 2]].clip(0, w_out - 1)
-    nb[:, [1, 3]] = nb[:, [1, 3]].clip(0, h_out - 1)
-    return nb, _box_candidates(boxes.T * scale, nb.T, 1e-16)
+from .host_protocol import (AffineParams, HSVParams, AugParams, SAMPLE_DESC, HostProtocol, PackedTargets, pack_targets,   # noqa: F401
+                            mosaic_layout, mosaic_boxes, affine_matrix, invert_affine, affine_boxes, augment_into, _box_candidates)
 
 
 def bilinear_table() -> np.ndarray:
@@ -142,12 +42,6 @@ def bilinear_table() -> np.ndarray:
             f = (t1[i][:, None] * t1[j][None, :]).astype(np.float32).reshape(-1)
             tab[i, j] = np.clip(np.rint(f.astype(np.float64) * 32768), -32768, 32767).astype(np.int16)
     return tab.reshape(n * n, 4)
-
-
-_TILE = np.dtype([("off", "<i8"), ("h", "<i4"), ("w", "<i4"), ("x1a", "<i4"), ("y1a", "<i4"), ("x2a", "<i4"),
-                  ("y2a", "<i4"), ("x1b", "<i4"), ("y1b", "<i4")], align=True)
-SAMPLE_DESC = np.dtype([("tile", _TILE, (4,)), ("im", "<f8", (6,)), ("lut_h", "u1", (256,)), ("lut_s", "u1", (256,)),
-                        ("lut_v", "u1", (256,)), ("hsv_on", "<i4"), ("flip", "<i4"), ("canvas", "<i4")], align=True)
 
 
 class _Stager:
@@ -175,49 +69,6 @@ class _Stager:
         ev.record()
         self.events[k] = ev
         return dev
-
-
-def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas: int, border, always_warp: bool = False):
-    """TrainSampleAugmentor.__call__ (default.py:440-488) for one sample: consumes the augmentor's generator in the
-    reference's order (8 affine draws, 3 HSV draws, 1 flip draw), writes the pixel-side parameters (inverse affine
-    matrix, HSV LUTs, flip flag) into the compositing descriptor and returns the transformed boxes / labels and the
-    output image side."""
-    ap = aug.affine_params
-    if ap.perspective != 0.0:
-        raise NotImplementedError("perspective warps are not on the HIP path (reference default is 0)")
-    if not always_warp and ap.degrees == 0.0 and ap.translate == 0.0 and ap.scale == 0.0 and ap.shear == 0.0:
-        # AffineParams.should_aug() is False (default.py:38-48,445-457): no draws, no warp, the image keeps its size
-        wo = ho = canvas
-        desc["im"] = np.array([1.0, 0.0, 0.0, 0.0, 1.0, 0.0])
-    else:
-        draws = (rng.uniform(-ap.perspective, ap.perspective), rng.uniform(-ap.perspective, ap.perspective),
-                 rng.uniform(-ap.degrees, ap.degrees), rng.uniform(1 - ap.scale, 1 + ap.scale),
-                 rng.uniform(-ap.shear, ap.shear), rng.uniform(-ap.shear, ap.shear),
-                 rng.uniform(0.5 - ap.translate, 0.5 + ap.translate), rng.uniform(0.5 - ap.translate, 0.5 + ap.translate))
-        M, wo, ho = affine_matrix(draws, canvas, canvas, border)
-        desc["im"] = invert_affine(M).reshape(-1)
-        if len(lb):
-            nb, keep = affine_boxes(bb, M, wo, ho, draws[3])
-            bb, lb = nb[keep], lb[keep]
-    hp = aug.hsv_params
-    if hp.hue == 0.0 and hp.saturation == 0.0 and hp.value == 0.0:
-        desc["hsv_on"] = 0
-    else:
-        r = rng.uniform(-1, 1, 3) * [hp.hue, hp.saturation, hp.value] + 1               # default.py:365-369
-        x = np.arange(0, 256, dtype=np.int16)
-        desc["lut_h"] = ((x * r[0]) % 180).astype(np.uint8)
-        desc["lut_s"] = np.clip(x * r[1], 0, 255).astype(np.uint8)
-        desc["lut_v"] = np.clip(x * r[2], 0, 255).astype(np.uint8)
-        desc["hsv_on"] = 1
-    flip = aug.flip_lr_prob > 0.0 and rng.random() < aug.flip_lr_prob
-    desc["flip"] = int(flip)
-    if flip and len(bb):
-        f = bb.copy()
-        f[:, 2] = wo - 1 - bb[:, 0]
-        f[:, 0] = wo - 1 - bb[:, 2]
-        bb = f
-    desc["canvas"] = canvas
-    return bb, lb, wo
 
 
 def compose(pool: torch.Tensor, descs: np.ndarray, mix: np.ndarray, tab: torch.Tensor, S: int, stager: "_Stager",
@@ -257,54 +108,37 @@ class DeviceTrainPipeline:
         self.S = int(target_image_size)
         self.device = torch.device(device)
         self.pool = ImagePool(images, self.device)
-        self.boxes, self.labels = list(boxes), list(labels)
-        self.aug = aug_params
-        self.mixup_prob = mixup_prob
-        self.rng = np.random.default_rng(rng_seed)            # default.py:415
-        self.weights = image_repeat_factors
-        self.sampler_indices = sampler_indices if sampler_indices is not None else range(len(images))
+        self.host = HostProtocol(self.pool.shapes, self.pool.offsets, boxes, labels, target_image_size, aug_params,
+                                 mixup_prob, rng_seed, image_repeat_factors, sampler_indices)
         self.tab = torch.from_numpy(bilinear_table()).to(self.device)
         self._stager = _Stager(self.device)
 
-    # -- one composite (mosaic + augment): fills a descriptor, returns boxes / labels --------------------
-    def _composite(self, indices: List[int], desc):
-        S = self.S
-        border = (-S // 2, -S // 2)
-        yc, xc = (int(_random.uniform(-x, 2 * S + x)) for x in border)          # mosaic.py:58-62
-        shapes = [self.pool.shapes[i] for i in indices]
-        rects = mosaic_layout(shapes, xc, yc, S)
-        samples = [(None, self.boxes[i], self.labels[i]) for i in indices]
-        bb, lb = mosaic_boxes(samples, rects, S)
-        for t, (i, (a, b)) in enumerate(zip(indices, rects)):
-            d = desc["tile"][t]
-            d["off"], d["h"], d["w"] = self.pool.offsets[i], shapes[t][0], shapes[t][1]
-            d["x1a"], d["y1a"], d["x2a"], d["y2a"] = a
-            d["x1b"], d["y1b"] = b
-        # always_warp: a batch is S x S, so the affine stage (which crops the 2S canvas to S) runs even when no jitter
-        # is configured (the reference would hand 2S x 2S images to the collate function in that case)
-        bb, lb, _ = augment_into(desc, self.aug, self.rng, bb, lb, 2 * S, border, always_warp=True)
-        return bb, lb
+    # (the protocol state lives in self.host; these stay assignable for tests that reset the augmentor's generator)
+    @property
+    def rng(self):
+        return self.host.rng
+
+    @rng.setter
+    def rng(self, g):
+        self.host.rng = g
+
+    def host_args(self) -> dict:
+        """Constructor arguments of an equivalent HostProtocol (picklable): what data/producer.py starts its worker with."""
+        h = self.host
+        return dict(shapes=h.shapes, offsets=h.offsets, boxes=h.boxes, labels=h.labels, target_image_size=h.S,
+                    aug_params=h.aug, mixup_prob=h.mixup_prob, image_repeat_factors=h.weights, sampler_indices=h.sampler_indices)
+
+    def compose_host_batch(self, descs: np.ndarray, mix: np.ndarray, out_f32: bool = True, out_pairs: bool = False):
+        """The device half alone: descriptors (from this process or from a producer process) -> (f32 | None, pairs | None)."""
+        img, pairs, self._keep = compose(self.pool.data, descs, mix, self.tab, self.S, self._stager, out_f32, out_pairs)
+        return img, pairs
 
     def make_batch(self, batch_indices: Sequence[int], out_f32: bool = True, out_pairs: bool = False):
         """Returns (images f32 [B,3,S,S] or None, pairs bf16 [B,S,S/2,8] or None, tuple of DetectionTarget)."""
-        B, S = len(batch_indices), self.S
-        descs = np.zeros((B, 2), dtype=SAMPLE_DESC)
-        mix = np.zeros((B, 2), dtype=np.float32)
-        mix[:, 0] = -1.0
-        targets = []
-        for k, idx in enumerate(batch_indices):
-            indices = [idx] + _random.choices(self.sampler_indices, k=3, weights=self.weights)   # detection.py:119-123
-            _random.shuffle(indices)
-            bb, lb = self._composite(indices, descs[k, 0])
-            if _random.random() < self.mixup_prob:                                               # detection.py:134-145
-                m_idx = _random.choices(self.sampler_indices, k=4, weights=self.weights)
-                bb2, lb2 = self._composite(m_idx, descs[k, 1])
-                r = np.random.beta(32.0, 32.0)                                                   # default.py:403
-                mix[k] = (np.float32(r), np.float32(1 - r))
-                bb, lb = np.concatenate((bb, bb2), 0), np.concatenate((lb, lb2), 0)
-            targets.append(DetectionTarget(torch.from_numpy(np.ascontiguousarray(bb)), torch.from_numpy(np.ascontiguousarray(lb))))
-        img, pairs, self._keep = compose(self.pool.data, descs, mix, self.tab, S, self._stager, out_f32, out_pairs)
-        return img, pairs, tuple(targets)
+        descs, mix, per_sample = self.host.batch(batch_indices)
+        targets = tuple(DetectionTarget(torch.from_numpy(bb), torch.from_numpy(lb)) for bb, lb in per_sample)
+        img, pairs = self.compose_host_batch(descs, mix, out_f32, out_pairs)
+        return img, pairs, targets
 
 
 def desc_bytes() -> int:

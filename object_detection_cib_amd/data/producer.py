@@ -1,0 +1,139 @@
+"""DescriptorProducer - the host side of the training data protocol in a worker PROCESS.
+
+The reference feeds its trainer from DataLoader worker processes (kod/lightning/data_module.py:135-144: `num_workers`,
+`persistent_workers`): the per-sample Python of DetectionDataset.__getitem__ (kod/data/detection.py:102-156) never runs
+in the process that launches the training step.  Here the pixel work is a GPU kernel, so what is left for a worker is
+small - index choice, the reference's RNG draw order, box arithmetic: HostProtocol (data/host_protocol.py), 8 - 9 ms
+of single-core numpy per batch of 64 - but in-process it sat next to the 11 ms step and bound the loop at 0.90 of the
+step rate (a producer THREAD was slower still: the GIL).  The worker owns the three generators of the protocol (`random`,
+`numpy.random`, the augmentor's `default_rng(51)`) for its whole stream of batches, so the stream is bit-identical to the
+in-process one, and it emits only descriptors + boxes through a shared-memory ring: no pixels, no torch, no GPU.
+
+It is started with the `spawn` method - a fresh interpreter, safe before or after this process has initialised the GPU
+(a fork after HIP initialisation is not) - and never touches a GPU itself.  One producer per rank: every rank's stream has
+its own generators, as every DataLoader worker of the reference has.
+"""
+from __future__ import annotations
+
+import multiprocessing as mp
+from multiprocessing import shared_memory
+from typing import List, Sequence
+
+import numpy as np
+
+from .host_protocol import SAMPLE_DESC, PackedTargets
+
+
+def _layout(B: int, cap: int):
+    """byte offsets of one ring slot: header | descs | mix | boxes | labels | samples | counts"""
+    off, out = 0, {}
+    for name, nbytes in (("header", 64), ("descs", B * 2 * SAMPLE_DESC.itemsize), ("mix", B * 2 * 4), ("boxes", cap * 32),
+                         ("labels", cap * 8), ("samples", cap * 4), ("counts", B * 4)):
+        out[name] = off
+        off += (nbytes + 63) // 64 * 64
+    out["size"] = off
+    return out
+
+
+def _views(buf, base: int, lay: dict, B: int, cap: int):
+    f = lambda name, dtype, count: np.frombuffer(buf, dtype=dtype, count=count, offset=base + lay[name])
+    return dict(header=f("header", np.int64, 8), descs=f("descs", SAMPLE_DESC, B * 2).reshape(B, 2),
+                mix=f("mix", np.float32, B * 2).reshape(B, 2), boxes=f("boxes", np.float64, cap * 4).reshape(cap, 4),
+                labels=f("labels", np.int64, cap), samples=f("samples", np.int32, cap), counts=f("counts", np.int32, B))
+
+
+def _worker(shm_name: str, slots: int, B: int, cap: int, host_args: dict, rng_seed: int, py_seed, np_seed,
+            schedule: List[List[int]], free, filled, stop):
+    import random
+    from .host_protocol import HostProtocol, pack_targets
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        if py_seed is not None:
+            random.seed(py_seed)
+        if np_seed is not None:
+            np.random.seed(np_seed)
+        host = HostProtocol(rng_seed=rng_seed, **host_args)
+        lay = _layout(B, cap)
+        for seq, idx in enumerate(schedule):
+            descs, mix, per_sample = host.batch(idx)
+            pt = pack_targets(per_sample)
+            while not free.acquire(timeout=0.2):
+                if stop.is_set():
+                    return
+            v = _views(shm.buf, (seq % slots) * lay["size"], lay, B, cap)
+            n = len(pt.labels)
+            v["header"][0], v["header"][1], v["header"][2] = seq, n, 1 if n > cap else 0
+            n = min(n, cap)
+            v["descs"].view(np.uint8)[...] = descs.view(np.uint8)          # (bytes, padding included: the record the kernel reads)
+            v["mix"][...] = mix
+            v["boxes"][:n], v["labels"][:n], v["samples"][:n] = pt.boxes[:n], pt.labels[:n], pt.samples[:n]
+            v["counts"][...] = pt.counts
+            del v
+            filled.release()
+    finally:
+        shm.close()
+
+
+class DescriptorProducer:
+    """Runs HostProtocol.batch() for `schedule` (a list of per-batch sample-index lists) in a worker process and hands the
+    results over in order.  py_seed / np_seed: what the worker seeds `random` / `numpy.random` with before its first batch
+    (the in-process loop seeds the same generators in the trainer's process).  max_boxes: capacity of a slot's box arrays
+    (a batch with more boxes raises here, like GraphedTrainStep's own capacity check)."""
+
+    def __init__(self, host_args: dict, batch_size: int, schedule: Sequence[Sequence[int]], rng_seed: int = 51, py_seed=None,
+                 np_seed=None, max_boxes: int = 16384, slots: int = 4):
+        assert all(len(b) == batch_size for b in schedule)
+        self.B, self.cap, self.slots = int(batch_size), int(max_boxes), int(slots)
+        self.lay = _layout(self.B, self.cap)
+        self.shm = shared_memory.SharedMemory(create=True, size=self.lay["size"] * self.slots)
+        ctx = mp.get_context("spawn")
+        self.free, self.filled, self.stop = ctx.Semaphore(self.slots), ctx.Semaphore(0), ctx.Event()
+        self.n, self.seq = len(schedule), 0
+        self.proc = ctx.Process(target=_worker, daemon=True,
+                                args=(self.shm.name, self.slots, self.B, self.cap, host_args, rng_seed, py_seed, np_seed,
+                                      [list(map(int, b)) for b in schedule], self.free, self.filled, self.stop))
+        self.proc.start()
+
+    def next(self, timeout: float = 120.0):
+        """(descs [B][2], mix [B][2], PackedTargets) of the next batch of the schedule - copies, the slot is free again."""
+        if self.seq >= self.n:
+            raise StopIteration
+        waited = 0.0
+        while not self.filled.acquire(timeout=0.5):
+            waited += 0.5
+            if not self.proc.is_alive():
+                raise RuntimeError(f"the descriptor producer died (exit code {self.proc.exitcode}) before batch {self.seq}")
+            if waited >= timeout:
+                raise RuntimeError(f"no batch from the descriptor producer for {timeout:.0f} s")
+        v = _views(self.shm.buf, (self.seq % self.slots) * self.lay["size"], self.lay, self.B, self.cap)
+        seq, n, overflow = (int(x) for x in v["header"][:3])
+        if seq != self.seq:
+            raise RuntimeError(f"descriptor ring out of order: slot holds batch {seq}, expected {self.seq}")
+        if overflow:
+            raise ValueError(f"{n} target boxes in batch {seq} exceed the ring's capacity {self.cap}")
+        descs = v["descs"].view(np.uint8).copy().view(SAMPLE_DESC).reshape(self.B, 2)      # (a structured copy would skip the padding)
+        out = (descs, v["mix"].copy(),
+               PackedTargets(v["boxes"][:n].copy(), v["labels"][:n].copy(), v["samples"][:n].copy(), v["counts"].copy()))
+        del v
+        self.seq += 1
+        self.free.release()
+        return out
+
+    def close(self):
+        if self.shm is None:
+            return
+        self.stop.set()
+        self.free.release()
+        self.proc.join(5.0)
+        if self.proc.is_alive():
+            self.proc.terminate()
+            self.proc.join(5.0)
+        self.shm.close()
+        self.shm.unlink()
+        self.shm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # noqa: BLE001 - interpreter shutdown
+            pass

@@ -27,7 +27,8 @@ class _UnitState:
     """Per conv unit: arena offsets (set once) and the current shape set's buffers / launch state."""
     __slots__ = ("u", "w_off", "g_off", "b_off", "f_off", "d_off", "Kp", "Kdp", "rs_off", "stats", "T",
                  "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho", "Wo",
-                 "fused_red", "segs", "seg_slots", "Kp_f", "raw_ld", "s2_fold", "wg_splits", "wg_off", "stem_fused", "wg_dual")
+                 "fused_red", "segs", "seg_slots", "Kp_f", "raw_ld", "s2_fold", "wg_splits", "wg_off", "stem_fused", "wg_dual",
+                 "pair", "pair_raw")
 
 
 class ArenaMixin:

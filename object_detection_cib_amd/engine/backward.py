@@ -90,6 +90,7 @@ class BackwardMixin:
             ("stem", region offset in bytes, kodhip_stem_bwd_fused's arguments with the region base in place 9)"""
             e0 = self._t0(stream_obj)
             sid = stream_obj.cuda_stream if stream_obj is not None else s
+            self._stamp("wg:" + name, stream_obj)
             if args[0] == "stem":
                 fa = list(args[2:])
                 fa[9] += args[1]
@@ -291,6 +292,7 @@ class BackwardMixin:
         # (with every collective on the main stream - KODHIP_COMM_OVERLAP=0, RCCL SyncBN - the head chains stay there too)
         heads_side = (wg is not None and defer and self.branch_overlap and self.profile is None and
                       (not self.collectives or (self._comm_stream() is not None and not rccl_sync)))
+        self._stamp("bwd_begin")
         bwd_start = torch.cuda.Event()
         if heads_side:
             bwd_start.record(main)
@@ -373,10 +375,14 @@ class BackwardMixin:
             if op.kind == "head":
                 bucket_tick()
         flush_wgrads()
+        self._stamp("main_end")
+        if wg is not None:
+            self._stamp("wg_end", wg)
         for name in list(grad_events):
             sync_grad(name)
         for o in wgs:
             main.wait_stream(o)
+        self._stamp("bwd_end")
         self._publish_grads()
         if self.g.inputs:
             return [self.gact[v.buf.name][..., v.coff:v.coff + v.C].permute(0, 3, 1, 2).float() if v.buf.name in touched
@@ -392,6 +398,7 @@ class BackwardMixin:
         aff = st.aff.data_ptr()
         dA = u.dst
         res = u.residual
+        self._stamp("m:" + u.name)
         if st.stem_fused and res is None:
             # the stem has no data gradient: dY = f(dA, y) is formed inside its weight gradient and never written
             # (csrc/conv_wgrad.hip conv_stem_bwd_fused_kernel); the launch joins the weight-gradient stream behind the
@@ -435,7 +442,7 @@ class BackwardMixin:
             if dgrad == "skip":
                 timed_wgrad(u.name, 2.0 * (B * st.H * st.W * u.cin + st.M * C_),
                             self._ptr(u.src), st.raw.data_ptr(), wgp + 4 * st.wg_off, gp + 4 * st.w_off,
-                            *geo, st.Kp, C_, 0, C_, 0, 1.0)
+                            *geo, st.Kp, st.raw_ld, 0, C_, 0, 1.0)
                 return
             fm, fptr = self._f32("dgrad", u.name, u.src)
             acc_src = acc_flag(u.src) | fm
@@ -451,19 +458,19 @@ class BackwardMixin:
                 nb += 2.0 * ps.M * partner.cout
                 fn = lib.kodhip_conv_dgrad_dual if st.segs is None else lib.kodhip_conv_dgrad_dual_bnred
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, ps.raw.data_ptr(), dp + 2 * ps.d_off, self._ptr(u.src, True),
-                       B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, st.Kdp, C_, 0, acc_src, fptr, *fz, s), u.name + ".dgrad2")
+                       B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, st.Kdp, st.raw_ld, 0, acc_src, fptr, *fz, s), u.name + ".dgrad2")
             elif u.k == 3 and u.s == 2 and u.p == 1:
                 if st.s2_fold:
                     fn = lib.kodhip_conv_dgrad_s2f if st.segs is None else lib.kodhip_conv_dgrad_s2f_bnred
                 else:
                     fn = lib.kodhip_conv_dgrad_s2 if st.segs is None else lib.kodhip_conv_dgrad_s2_bnred
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
-                       B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, C_, 0,
+                       B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, st.raw_ld, 0,
                        acc_src, fptr, *fz, s), u.name + ".dgrad")
             else:
                 fn = lib.kodhip_conv_dgrad if st.segs is None else lib.kodhip_conv_dgrad_bnred
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
-                       *geo, st.Kdp, C_, 0, acc_src, fptr, *fz, s), u.name + ".dgrad")
+                       *geo, st.Kdp, st.raw_ld, 0, acc_src, fptr, *fz, s), u.name + ".dgrad")
             self._t1(e0, "dgrad" if st.segs is None else "dgrad+bn_reduce", nb)
         if dgrad == "dual" and dual_w:
             ps = self.ustate[partner.name]
@@ -478,7 +485,7 @@ class BackwardMixin:
         in_px_w = B * H * W if u.stem else B * st.H * st.W
         timed_wgrad(u.name, 2.0 * (in_px_w * cin_true + st.M * C_),
                     self._ptr(u.src), st.raw.data_ptr(), wgp + 4 * st.wg_off, gp + 4 * st.w_off,
-                    *geo, st.Kp, C_, 0, C_, 1 if u.stem else 0, 1.0)
+                    *geo, st.Kp, st.raw_ld, 0, C_, 1 if u.stem else 0, 1.0)
         self._flush_wgrads()           # this unit's - and a fused short_conv partner's - weight gradients: after the dgrad
 
 

@@ -25,7 +25,7 @@ from .plan import backward_writes, plan_f32_accumulation, plan_dual_dgrads, plan
 class BufferMixin:
     # ------------------------------------------------------------------ activations
     _UNIT_FIELDS = ("stats", "T", "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho",
-                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld", "wg_splits", "wg_off", "stem_fused", "wg_dual")
+                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld", "wg_splits", "wg_off", "stem_fused", "wg_dual", "pair", "pair_raw")
     _HEAD_FIELDS = ("H", "W", "M", "dy", "ws", "wg_splits", "wg_off")
 
     def _export_set(self) -> dict:
@@ -120,6 +120,40 @@ class BufferMixin:
             # gradient, while it is still in the 256 MB Infinity Cache) - or, for the per-bucket reduction, a region each
             st.wg_off = max_part if own else 0
             max_part = max_part + _pad(nslab) if own else max(max_part, nslab)
+        # A CSP layer's main_conv and short_conv (kod/nn/layers/csp.py:87-88: the same input through two pointwise convs)
+        # run forward as ONE convolution with N = 2 * mid columns: their packed weights are adjacent (arena order = forward
+        # order), their pre-BN outputs are the two channel halves of one tensor (row stride 2 * mid: every later kernel takes
+        # the half as a (pointer, row stride) slice) and their statistic slots are one [2][2 * mid][T] block.
+        units_by_name = {u.name: u for u in self.exec_units}
+        for u in self.exec_units:
+            self.ustate[u.name].pair, self.ustate[u.name].pair_raw = None, None
+        if self.opt.pair_fwd:
+            from .plan import plan_dual_dgrads as _pairs
+            for mname, sname in _pairs(self.g).items():
+                mu, su = units_by_name[mname], units_by_name[sname]
+                mst, sst = self.ustate[mname], self.ustate[sname]
+                if mu.residual is not None or su.residual is not None or sst.f_off != mst.f_off + mu.cout * mst.Kp_f:
+                    continue
+                mid = mu.cout
+                # + a zeroed tail that nobody writes: a data gradient whose channel count is not a multiple of 32 reads up to 16
+                # channels past its slice against zero weights (padded-tap K axis); for the short_conv
+                # half of the LAST row that is past the tensor, and the launcher's buffer range (rows x row stride from the
+                # half's own base pointer) no longer ends where the allocation does
+                flat = torch.empty(mst.M * 2 * mid + 512, dtype=torch.bfloat16, device=dev)
+                flat[mst.M * 2 * mid:].zero_()
+                both = flat[:mst.M * 2 * mid].view(B, mst.Ho, mst.Wo, 2 * mid)
+                mst.pair_raw = sst.pair_raw = both
+                mst.raw, sst.raw = both[..., :mid], both[..., mid:]
+                mst.raw_ld = sst.raw_ld = 2 * mid
+                mst.T = sst.T = lib.kodhip_conv_stats_slots(mst.M, 2 * mid)
+                # (the short_conv keeps its own slots for the two-launch form: RCCL SyncBN, KODHIP_NO_PAIR_FWD)
+                mst.stats = torch.empty(2 * 2 * mid * mst.T, dtype=torch.float32, device=dev)
+                mst.pair, sst.pair = ("main", sname), ("short", mname)
+                for st_, u_ in ((mst, mu), (sst, su)):          # (the row stride enters the launcher's 32-bit range test)
+                    st_.wg_splits = lib.kodhip_conv_wgrad_splits_geo(B, st_.H, st_.W, u_.src.buf.C, u_.cin, u_.cout, 1, 1, 1, 1, 0, 0,
+                                                                     st_.Kp, st_.raw_ld)
+                    if not own:
+                        max_part = max(max_part, st_.wg_splits * u_.cout * st_.Kp)
         self._plan_bn_fusion(B)
         # a dual pair's weight gradients as one launch (kodhip_conv_wgrad_dual): slab rows for both layers
         for u in self.exec_units:
@@ -237,11 +271,11 @@ class BufferMixin:
             if w.k * w.k * w.cout < self.opt.bn_reduce_min_k:
                 continue
             if wname in self._dual:
-                slots = lib.kodhip_conv_dgrad_dual_bnred_slots(B, wst.H, wst.W, w.cin, w.cout, w.cout)
+                slots = lib.kodhip_conv_dgrad_dual_bnred_slots(B, wst.H, wst.W, w.cin, w.cout, wst.raw_ld)
             elif s2 and wst.s2_fold:
                 slots = lib.kodhip_conv_dgrad_s2f_bnred_slots(B, wst.H, wst.W, w.cin, w.cout, w.cout)
             else:
-                slots = lib.kodhip_conv_dgrad_bnred_slots(B, wst.H, wst.W, w.cin, w.cout, w.k, w.k, w.s, w.s, w.p, w.p, w.cout, s2)
+                slots = lib.kodhip_conv_dgrad_bnred_slots(B, wst.H, wst.W, w.cin, w.cout, w.k, w.k, w.s, w.s, w.p, w.p, wst.raw_ld, s2)
             if slots <= 0:
                 continue
             segs = (_lib.KodBnRedSeg * len(prods))()
@@ -250,7 +284,7 @@ class BufferMixin:
                 st.fused_red, st.T2 = True, slots
                 st.bpart = torch.empty(2 * u.cout * slots, dtype=torch.float32, device=self.device)
                 segs[i].ch_begin, segs[i].ch_count = ch0, u.cout
-                segs[i].raw, segs[i].ldr = st.raw.data_ptr(), u.cout
+                segs[i].raw, segs[i].ldr = st.raw.data_ptr(), st.raw_ld
                 segs[i].aff, segs[i].partials = st.aff.data_ptr(), st.bpart.data_ptr()
             wst.segs, wst.seg_slots = segs, slots
         if self.opt.debug_plan:

@@ -10,6 +10,8 @@ PyTorch is used for device memory, streams and torch.distributed only.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional
 
 
@@ -75,3 +77,7 @@ class Engine(ArenaMixin, BufferMixin, ForwardMixin, BackwardMixin):
         self.aux_stream = None        # side stream of work that only depends on the step's inputs (label assignment)
         self.branch_overlap = self.opt.branch_overlap
         self.profile = None           # list of (family, start_event, end_event, algorithmic bytes), see _t0 / _t1
+        # KODHIP_DEBUG_STAMPS=1: device clock stamps at named points of the step, also inside a replayed hipGraph
+        # (bench.py stamp_report): stamp_names[i] <-> stamp_buf[i]
+        self.stamp_buf, self.stamp_names = None, []
+        self.stamps_on = os.environ.get("KODHIP_DEBUG_STAMPS", "0") == "1"

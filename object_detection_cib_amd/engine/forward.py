@@ -43,6 +43,21 @@ class ForwardMixin:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record(stream) if stream is not None else e1.record()
         self.profile.append((family, e0, e1, nbytes))
+
+    def _stamp(self, name: str, stream=None):
+        """(debug) device time stamp `name` on `stream` (a torch stream; default: the current one)"""
+        if not self.stamps_on:
+            return
+        if self.stamp_buf is None:
+            assert torch.device(self.device).type == "cuda"
+            self.stamp_buf = torch.zeros(1024, dtype=torch.int64, device=self.device)
+        assert self.stamp_buf.is_cuda and len(self.stamp_names) < 1000
+        if name not in self.stamp_names:
+            self.stamp_names.append(name)
+        i = self.stamp_names.index(name)
+        sid = stream.cuda_stream if stream is not None else self._stream()
+        _lib.check(self.lib.kodhip_debug_stamp(self.stamp_buf.data_ptr() + 8 * i, sid), "stamp")
+
     def _allreduce(self, t):
         if self.collectives:
             if self.comm is not None:
@@ -105,6 +120,7 @@ class ForwardMixin:
             self.pack_weights()
         if not self.g.inputs and not image_ready:
             chk(lib.kodhip_nchw_to_nhwc4(x.data_ptr(), self.act["image"].data_ptr(), B, 3, H, W, s), "nchw_to_nhwc4")
+        self._stamp("fwd_begin")
         A, nc = self.g.num_anchors, self.g.num_classes
         outs = []
         pool_i = 0
@@ -123,10 +139,54 @@ class ForwardMixin:
                 geo = (B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p, st.Kp_f)
             e0 = self._t0()
             chk(lib.kodhip_conv_fwd_raw(self._ptr(u.src), fp + 2 * st.f_off, st.raw.data_ptr(),
-                                        st.stats.data_ptr(), *geo, C_, 0, s), u.name)
+                                        st.stats.data_ptr(), *geo, st.raw_ld, 0, s), u.name)
             cin_true = 3 if u.stem else u.cin
             in_px = B * H * W if u.stem else B * st.H * st.W
             self._t1(e0, "conv_fwd", 2 * (in_px * cin_true + st.M * C_))
+
+        def pair_stage(mu: ConvUnit, su: ConvUnit, s=s):
+            """A CSP layer's main_conv + short_conv (same input): one convolution with N = 2 * mid columns, one launch for
+            both units' BatchNorm constants, one apply pass writing each half to its own destination slice."""
+            mst, sst, mid = self.ustate[mu.name], self.ustate[su.name], mu.cout
+            geo = (B, mst.H, mst.W, mu.src.buf.C, mu.src.coff, mu.cin, 2 * mid, 1, 1, 1, 1, 0, 0, mst.Kp_f)
+            e0 = self._t0()
+            chk(lib.kodhip_conv_fwd_raw(self._ptr(mu.src), fp + 2 * mst.f_off, mst.pair_raw.data_ptr(),
+                                        mst.stats.data_ptr(), *geo, 2 * mid, 0, s), mu.name + "+short")
+            self._t1(e0, "conv_fwd", 2 * (B * mst.H * mst.W * mu.cin + mst.M * 2 * mid))
+            ma, sa = mst.aff.data_ptr(), sst.aff.data_ptr()
+            if training:
+                e0 = self._t0()
+                peer = sync and self.peer is not None
+                chk(lib.kodhip_bn_finalize_partials_pair(
+                    mst.stats.data_ptr(), mst.T, float(mst.M) * (self.world_size if sync else 1), mid, BN_MOMENTUM, BN_EPS, 1,
+                    pa + 4 * mst.g_off, pa + 4 * mst.b_off, rm + 4 * mst.rs_off, rv + 4 * mst.rs_off, ma,
+                    pa + 4 * sst.g_off, pa + 4 * sst.b_off, rm + 4 * sst.rs_off, rv + 4 * sst.rs_off, sa,
+                    self.peer.view_ptr() if peer else None,
+                    self.peer_slots[(mu.name, "f")] if peer else 0, self.peer_slots[(su.name, "f")] if peer else 0, s),
+                    mu.name + "+short")
+                self._t1(e0, "bn_finalize", 8.0 * 2 * mid * mst.T)
+            (msc, msh), (ssc, ssh) = ((ma, ma + 4 * mid), (sa, sa + 4 * mid)) if training else (eval_aff[mu.name], eval_aff[su.name])
+            if self.opt.pair_fwd == 2 and branch:
+                # the short half feeds only last_conv: its apply pass leaves the main chain (side stream, joined there)
+                if self.br_stream is None:
+                    self.br_stream = torch.cuda.Stream(device=self.device)
+                fork = torch.cuda.Event()
+                fork.record(main_stream)
+                e0 = self._t0()
+                chk(lib.kodhip_bn_silu_apply(mst.raw.data_ptr(), 2 * mid, msc, msh, None, 0, 0,
+                                             self._ptr(mu.dst), mu.dst.buf.C, mu.dst.coff, mst.M, mid, s), mu.name)
+                self._t1(e0, "bn_silu_apply", 4.0 * mst.M * mid)
+                self.br_stream.wait_event(fork)
+                chk(lib.kodhip_bn_silu_apply(sst.raw.data_ptr(), 2 * mid, ssc, ssh, None, 0, 0,
+                                             self._ptr(su.dst), su.dst.buf.C, su.dst.coff, mst.M, mid,
+                                             self.br_stream.cuda_stream), su.name)
+                return su.dst.buf.name
+            e0 = self._t0()
+            chk(lib.kodhip_bn_silu_apply_pair(mst.pair_raw.data_ptr(), 2 * mid, mid,
+                                              msc, msh, self._ptr(mu.dst), mu.dst.buf.C, mu.dst.coff,
+                                              ssc, ssh, self._ptr(su.dst), su.dst.buf.C, su.dst.coff, mst.M, s), mu.name + "+short")
+            self._t1(e0, "bn_silu_apply", 4.0 * mst.M * 2 * mid)
+            return None
 
         def stats_stage(group, s=s):
             """Batch statistics -> BatchNorm constants.  Under SyncBN the [sum, sum of squares] vectors of the group's
@@ -198,6 +258,14 @@ class ForwardMixin:
             if op.kind == "conv" and joined_buf is not None and op.unit.src.buf.name == joined_buf:
                 main_stream.wait_stream(self.br_stream)
                 joined_buf = None
+            if op.kind == "conv" and op.unit.sibling is not None and i < len(ops) and ops[i].unit is op.unit.sibling and \
+                    self.ustate[op.unit.name].pair is not None and not (sync and self.peer is None):
+                # (RCCL SyncBN keeps the two-launch form: its statistic exchange works on per-unit sum vectors)
+                if joined_buf is not None:
+                    main_stream.wait_stream(self.br_stream)
+                joined_buf = pair_stage(op.unit, ops[i].unit)
+                i += 1
+                continue
             if op.kind == "conv" and branch and op.unit.sibling is not None and i < len(ops) and \
                     ops[i].unit is op.unit.sibling and joined_buf is None:
                 short = ops[i].unit
@@ -272,6 +340,7 @@ class ForwardMixin:
             main_stream.wait_stream(self.br_stream)
         if heads_on_aux:
             main_stream.wait_stream(self.head_stream)
+        self._stamp("fwd_end")
         if training:
             self.nbt_arena += 1
             self.stats_version += 1              # running statistics moved

@@ -74,10 +74,12 @@ class GraphedTrainStep:
                 self.labels[:n].copy_(targets.labels)
                 self.samples[:n].copy_(targets.samples)
             return
-        # host-side targets (tuple of DetectionTarget on the CPU): pack them into one pinned block and upload it
-        # without stalling the host behind the previous step (a pageable copy would)
-        lens = [int(t.boxes.shape[0]) for t in targets]
-        n = sum(lens)
+        # host-side targets (tuple of DetectionTarget on the CPU, or the flat arrays of data.device_pipeline.PackedTargets):
+        # pack them into one pinned block and upload it without stalling the host behind the previous step (a pageable
+        # copy would)
+        packed = hasattr(targets, "samples") and hasattr(targets, "counts")
+        lens = None if packed else [int(t.boxes.shape[0]) for t in targets]
+        n = int(len(targets.labels)) if packed else sum(lens)
         if n > self.cap:
             raise ValueError(f"{n} target boxes in the batch exceed the graph's capacity {self.cap}")
         k = self._slot
@@ -86,6 +88,12 @@ class GraphedTrainStep:
             self._events[k].synchronize()
         hb, hl, hs = self._host[k]
         hb.zero_(); hl.zero_(); hs.zero_()
+        if packed:
+            if n:
+                hb.numpy()[:n] = targets.boxes
+                hl.numpy()[:n] = targets.labels
+                hs.numpy()[:n] = targets.samples
+            targets = ()
         o = 0
         for i, t in enumerate(targets):
             m = lens[i]

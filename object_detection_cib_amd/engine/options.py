@@ -40,6 +40,9 @@ class EngineOptions:
     bn_reduce_min_k: int = 0          # KODHIP_BNRED_MINK
     dx_accum_fp32: bool = False       # KODHIP_DX_FP32: multi-consumer activation gradients accumulated in fp32
     dual_wgrad: bool = True           # KODHIP_NO_DUAL_WGRAD=1 switches off: a CSP layer's main + short weight gradients in one launch
+    pair_fwd: int = 0                 # KODHIP_PAIR_FWD: a CSP layer's main_conv + short_conv forward as ONE conv launch (N = 2 * mid):
+                                      # 0 off (default: measured 1.5 % slower) | 1 one apply launch for both
+                                      # halves | 2 the short half's apply on the side stream
     stem_bwd_fused: bool = True       # KODHIP_STEM_BWD_FUSED: the stem's BN/SiLU backward inside its weight gradient (dY never written)
     wgrad_reduce_batched: bool = False  # KODHIP_WGRAD_REDUCE=bucket: one slab-reduction launch per gradient bucket (slower: see DESIGN)
     debug_plan: bool = False          # KODHIP_DEBUG_PLAN
@@ -63,6 +66,7 @@ class EngineOptions:
             bn_reduce_min_k=int(e.get("KODHIP_BNRED_MINK", "0")),
             dx_accum_fp32=_flag("KODHIP_DX_FP32", False),
             dual_wgrad=not _flag("KODHIP_NO_DUAL_WGRAD", False),
+            pair_fwd=int(e.get("KODHIP_PAIR_FWD", "0")),
             stem_bwd_fused=_flag("KODHIP_STEM_BWD_FUSED", True),
             wgrad_reduce_batched=e.get("KODHIP_WGRAD_REDUCE", "layer") == "bucket",
             debug_plan=_flag("KODHIP_DEBUG_PLAN", False),

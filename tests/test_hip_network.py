@@ -736,6 +736,55 @@ def test_schedule_switches_keep_the_gradients():
             assert torch.equal(got["single_wgrads"][k], g), k
 
 
+def test_pair_forward_switch_matches_two_launch_form():
+    """EngineOptions.pair_fwd (KODHIP_PAIR_FWD=1 | 2; off by default - measured slower): a CSP layer's main_conv +
+    short_conv (kod/nn/layers/csp.py:87-88, the same input) as ONE convolution launch with N = 2 * mid columns, their
+    pre-BN outputs the two channel halves of one tensor, one launch for both units' BatchNorm constants
+    (kodhip_bn_finalize_partials_pair) and one apply pass (kodhip_bn_silu_apply_pair; 2: the short half's apply on the side
+    stream).  The first pair of the network sees identical inputs in every form: its pre-BN outputs must be bit-identical
+    (the K order of an output element does not depend on the n tile), its batch statistics equal to fp32 rounding of a
+    different partial grouping; the loss and the weight gradients of the step stay within the bars of a changed summation
+    order; yv5m widths (mid = 48: slices at 96-byte offsets, padded-tap over-read into the zeroed tail) included."""
+    from object_detection_cib_amd.engine.options import EngineOptions
+    for widen, deepen in ((0.5, 0.33), (0.75, 0.67)):
+        nc, B, size, seed = 10, 4, 256, 13
+        x, tg = synth.batch(B, size, nc, seed)
+        got = {}
+        for mode in (0, 1, 2):
+            torch.manual_seed(seed)
+            net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=deepen)
+            opts = EngineOptions.from_env()
+            opts.pair_fwd = mode
+            net.engine_options = opts
+            net = net.cuda().train()
+            with torch.no_grad():
+                net.forward_raw(x.cuda())
+            eng = net.engine()
+            first = next(u for u in eng.exec_units if u.sibling is not None)
+            pair = (first, first.sibling)
+            assert (eng.ustate[first.name].pair is not None) == (mode != 0)
+            rec = {"raw": [eng.ustate[u.name].raw.float().cpu().clone() for u in pair],
+                   "aff": [eng.ustate[u.name].aff.cpu().clone() for u in pair],
+                   "act": [eng.act[u.dst.buf.name][..., u.dst.coff:u.dst.coff + u.cout].float().cpu().clone() for u in pair]}
+            for p in net.parameters():
+                p.grad = None
+            _, lr, tot = _step(net, x.cuda(), tg, size, B)
+            rec["loss"] = tot.item()
+            rec["grads"] = torch.cat([p.grad.flatten() for p in net.parameters()]).cpu()
+            rec["first_w"] = [dict(net.named_parameters())[u.name + ".0.weight"].grad.cpu().clone() for u in pair]
+            got[mode] = rec
+        ref = got[0]
+        for mode in (1, 2):
+            g = got[mode]
+            for k in range(2):
+                assert torch.equal(g["raw"][k], ref["raw"][k]), (widen, mode, k)
+                assert _rel(g["aff"][k], ref["aff"][k]) <= 1e-6, (widen, mode, k, _rel(g["aff"][k], ref["aff"][k]))
+                assert _rel(g["act"][k], ref["act"][k]) <= 1e-3, (widen, mode, k)
+            assert np.isfinite(g["loss"]) and abs(g["loss"] - ref["loss"]) <= 2e-2 * abs(ref["loss"]), (widen, mode, g["loss"], ref["loss"])
+            assert torch.isfinite(g["grads"]).all()
+        assert torch.equal(got[1]["grads"], got[2]["grads"])          # the same kernels on another stream
+
+
 def test_yv5m_bench_geometry_b64_640_deterministic_and_teacher_forced():
     """BASELINE configs[4] at its per-GPU batch: yv5m (widen .75, deepen .67: 48 / 96 / 192 / 384 / 768 channels, 88 convs),
     B=64, 640 px - the 256-pixel-tile / split-K / padded-tap geometry of those widths.  (1) two steps on the same batch give

@@ -321,3 +321,56 @@ def test_submodule_classes_mirror_reference_parameters_and_refuse_cpu():
         CSPLayer(64, 64)(torch.zeros(1, 64, 8, 8))
     with pytest.raises(ValueError):
         CSPBlock(32, 32, norm_layer=torch.nn.BatchNorm2d)
+
+
+def test_descriptor_producer_process_equals_in_process_protocol():
+    """data/producer.py: the host side of the training data protocol (reference: DetectionDataset.__getitem__ in DataLoader
+    worker processes, kod/data/detection.py:102-156, kod/lightning/data_module.py:135-144) in a worker process must emit
+    the very stream the in-process HostProtocol emits - compositing descriptors byte for byte, mixup ratios, boxes, labels,
+    sample ids - for the same seeds of the three generators it owns (`random`, `numpy.random`, default_rng(51)); a batch
+    over the box capacity is refused, not truncated."""
+    import random
+    import sys
+    from object_detection_cib_amd.data.host_protocol import HostProtocol, pack_targets
+    from object_detection_cib_amd.data.producer import DescriptorProducer
+    rs = np.random.default_rng(3)
+    n, S, B = 40, 96, 6
+    shapes = [(int(rs.integers(40, S + 1)), int(rs.integers(40, S + 1))) for _ in range(n)]
+    offsets = np.concatenate(([0], np.cumsum([h * w * 3 for h, w in shapes])[:-1]))
+    boxes, labels = [], []
+    for h, w in shapes:
+        m = int(rs.integers(1, 5))
+        c = rs.uniform(0.2, 0.8, (m, 2)) * [w, h]
+        wh = rs.uniform(6, 30, (m, 2))
+        boxes.append(np.concatenate((c - wh / 2, c + wh / 2), 1).astype(np.float64))
+        labels.append(rs.integers(0, 10, m).astype(np.int64))
+    args = dict(shapes=shapes, offsets=offsets, boxes=boxes, labels=labels, target_image_size=S, mixup_prob=0.5)
+    schedule = [[int(i) for i in rs.integers(0, n, B)] for _ in range(9)]
+    prod = DescriptorProducer(args, B, schedule, rng_seed=51, py_seed=7, np_seed=7, max_boxes=512, slots=3)
+    try:
+        random.seed(7); np.random.seed(7)
+        host = HostProtocol(rng_seed=51, **args)
+        for idx in schedule:
+            d0, m0, per = host.batch(idx)
+            p0 = pack_targets(per)
+            d1, m1, p1 = prod.next(timeout=60)
+            assert d0.tobytes() == d1.tobytes() and m0.tobytes() == m1.tobytes()
+            for a, b in zip(p0, p1):
+                assert a.dtype == b.dtype and np.array_equal(a, b)
+            tg = p1.as_targets()
+            assert len(tg) == B and sum(len(t.labels) for t in tg) == len(p1.labels)
+        with pytest.raises(StopIteration):
+            prod.next()
+    finally:
+        prod.close()
+    assert "torch" in sys.modules          # (this process has it; the worker's module chain does not import it)
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", "import sys, object_detection_cib_amd.data.producer; print('torch' in sys.modules)"],
+                         capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip() == "False", out.stdout + out.stderr
+    small = DescriptorProducer(args, B, schedule[:1], py_seed=7, np_seed=7, max_boxes=1, slots=2)
+    try:
+        with pytest.raises(ValueError, match="capacity"):
+            small.next(timeout=60)
+    finally:
+        small.close()

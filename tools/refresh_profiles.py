@@ -8,7 +8,7 @@ stores.  Per launch = summed counter / number of dispatches of the family in the
 import csv, glob, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 EV = os.path.join(ROOT, "gpurun_out", f"ev_{tag}")
 PR = os.path.join(ROOT, "profiles")
 
@@ -98,7 +98,7 @@ def main():
                      "dispatches": nf, "algorithmic_bytes_per_launch": alg}
         lines.append(f"{fam:22s} {nf:8d} {rd / 1e6:15.2f} {wrb / 1e6:16.2f} {(rd + wrb) / 1e6:16.2f} "
                      + (f"{alg / 1e6:22.2f} {(rd + wrb) / alg:20.2f}" if alg else f"{'-':>22s} {'-':>20s}"))
-    json.dump({"csrc_digest": dig, "workload": "yv5s B=64 640px, one eager bench.py step per PMC pass",
+    json.dump({"csrc_digest": dig, "workload": bench.get("config", {}).get("workload", "yv5s B=64 640px") + "; one eager bench.py step per PMC pass",
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (--kernel-trace only); KiB units; "
                          "read = 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B); mean over the family's dispatches",
                "families": fams}, open(os.path.join(PR, f"{tag}_pmc_traffic.json"), "w"), indent=1)
