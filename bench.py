@@ -152,56 +152,62 @@ def synth_pool(n, S, nc, seed):
     return imgs, boxes, labels
 
 
-def loop_leg(net, loss_fn, B, S, nc, device, steps, mixup_prob=0.0):
-    """The training LOOP BASELINE configs[1] literally names ("mosaic on"): DeviceTrainPipeline (reference sampling /
-    RNG protocol on the host, mosaic + affine + HSV + flip compositing from a u8 pool resident in HBM) feeding the
-    captured step (engine/graphed.py).  Reported beside the step rate, never as `value`."""
+def loop_leg(net, loss_fn, B, S, nc, device, steps, mixup_prob=0.0, producer=True, rank=0):
+    """The training LOOP BASELINE configs[1] literally names ("mosaic on"; configs[2]: mixup_prob > 0): the reference's
+    sampling / RNG protocol on the host, mosaic + affine + HSV + flip (+ mixup) compositing from a u8 pool resident in HBM,
+    feeding the captured step (engine/graphed.py).  producer=True (default): the host side of the protocol runs in a worker
+    process (data/producer.py - the reference's DataLoader workers) that hands descriptors over through shared memory;
+    False: in this process (round 3: the loop was then bound by those 8 - 9 ms of numpy per batch at 0.90 of the step rate).
+    Reported beside the step rate, never as `value`."""
     import random
     import numpy as np
+    from object_detection_cib_amd.data.detection import DetectionTarget
     from object_detection_cib_amd.data.device_pipeline import DeviceTrainPipeline
+    from object_detection_cib_amd.data.producer import DescriptorProducer
     from object_detection_cib_amd.engine.graphed import GraphedTrainStep
     from object_detection_cib_amd import _lib
     _lib.limit_host_threads()      # the host side of the data protocol: torch's pool sized to the cgroup's CPU share
-    imgs, boxes, labels = synth_pool(256, S, nc, 7)
+    imgs, boxes, labels = synth_pool(256, S, nc, 7 + rank)
     pipe = DeviceTrainPipeline(imgs, boxes, labels, S, device, mixup_prob=mixup_prob)
-    random.seed(2023); np.random.seed(2023)
-    main = torch.cuda.current_stream()
-    prep = torch.cuda.Stream()                 # the next batch is composited beside the running step
+    schedule = [[(i * B + k) % 256 for k in range(B)] for i in range(steps + 5)]
+    seed = 2023 + rank
+    prod = None
+    if producer:
+        prod = DescriptorProducer(pipe.host_args(), B, schedule, rng_seed=51, py_seed=seed, np_seed=seed, max_boxes=16384)
+    else:
+        random.seed(seed); np.random.seed(seed)
+    gs = None
 
     def produce(i):
-        """batch i as bf16 pixel pairs - the layout the network's first layer reads - composited on the side stream"""
-        prep.wait_stream(main)                 # (allocator ordering: the buffers it reuses were last read on the main stream)
-        with torch.cuda.stream(prep):
-            _, pairs, tg = pipe.make_batch([(i * B + k) % 256 for k in range(B)], out_f32=False, out_pairs=True)
-            ev = torch.cuda.Event()
-            ev.record(prep)
-        pairs.record_stream(main)
-        return pairs, tg, ev
-    pairs, tg, ev = produce(0)
-    main.wait_event(ev)
-    gs = GraphedTrainStep(net, loss_fn, B, S, S, max_targets=16384, input_pairs=True).capture(pairs, tg)
-    # (the loop is bound by the host side of the data protocol - per-sample numpy in the reference's RNG order, 8 - 9 ms per
-    # batch of 64 plus 2 ms for the step call - not by the GPU; a producer thread made it slower (13.7 ms: the GIL), the
-    # reference's answer, DataLoader worker processes, is outside this path)
-    nxt = produce(0)
-    for i in range(3):
-        pairs, tg, ev = nxt
-        nxt = produce(i + 1)
-        main.wait_event(ev)
-        gs(pairs, tg)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        pairs, tg, ev = nxt
-        nxt = produce(i + 4)                   # issued before this step's replay: composited while the step runs
-        main.wait_event(ev)
-        total, _ = gs(pairs, tg)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+        """batch i as bf16 pixel pairs - the layout the network's first layer reads - composited on the step's own stream
+        straight into the network's input buffer (measured, tools/loop_parts.py: on a side stream beside the running step the
+        VALU-heavy compositing kernel costs the step more than its own 0.3 ms, and needs a 210 MB copy into the input buffer)"""
+        if prod is not None:
+            descs, mix, tg = prod.next()
+        else:
+            descs, mix, per = pipe.host.batch(schedule[i])
+            tg = tuple(DetectionTarget(torch.from_numpy(bb), torch.from_numpy(lb)) for bb, lb in per)
+        _, pairs = pipe.compose_host_batch(descs, mix, out_f32=False, out_pairs=True, pairs_out=gs.input_buffer() if gs is not None else None)
+        return pairs, tg
+    try:
+        first = produce(0)
+        gs = GraphedTrainStep(net, loss_fn, B, S, S, max_targets=16384, input_pairs=True).capture(first[0], first[1])
+        for i in range(3):
+            gs(*produce(i + 1))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            total, _ = gs(*produce(i + 4))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        if prod is not None:
+            prod.close()
     return {"value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
             "workload": f"DeviceTrainPipeline (mosaic + affine + HSV + flip, mixup p={mixup_prob}, u8 pool of 256 images in HBM, "
-                        "host RNG protocol; the next batch composited as bf16 pixel pairs on a side stream) -> hipGraph replay of "
-                        "the training step", "final_loss": float(total)}
+                        + ("host RNG protocol in a producer process (descriptors through shared memory)" if producer else "host RNG protocol in-process")
+                        + "; each batch composited as bf16 pixel pairs straight into the network's input buffer) -> hipGraph replay of the training step",
+            "final_loss": float(total)}
 
 
 def validation_leg(net, loss_fn, B, S, nc, device, batches=12):
@@ -438,6 +444,8 @@ def main():
     ap.add_argument("--no-loop", action="store_true", help="skip the training-loop leg (device data pipeline -> captured step)")
     ap.add_argument("--no-extra", action="store_true", help="skip the validation-loop and yv5m legs")
     ap.add_argument("--loop-steps", type=int, default=20)
+    ap.add_argument("--loop-mixup", type=float, default=None, help="mixup probability of the loop leg (default 0 at N=1, 0.1 at N>1)")
+    ap.add_argument("--loop-in-process", action="store_true", help="loop leg: host side of the data protocol in this process (round 3)")
     args = ap.parse_args()
 
     # decided before anything touches a GPU; the parent only starts and supervises the ranks (never re-executes itself)
@@ -589,8 +597,17 @@ def main():
         dt = max(dts)                              # the job is as fast as its slowest rank
     final_loss = float(last.item())
     loop = None
-    if world == 1 and not use_dist and not args.no_loop and not args.autograd and use_graph:
-        loop = loop_leg(net, loss_fn, B, S, nc, device, args.loop_steps)
+    # (with collectives in the step every rank runs the leg - its replays contain the same RCCL calls - fed by its own producer)
+    if not args.no_loop and not args.autograd and graph is not None:
+        mix_p = args.loop_mixup if args.loop_mixup is not None else (0.1 if world > 1 else 0.0)      # configs[2]: "mosaic+mixup"
+        barrier()
+        loop = loop_leg(net, loss_fn, B, S, nc, device, args.loop_steps, mixup_prob=mix_p, producer=not args.loop_in_process, rank=rank)
+        if dist is not None:
+            lts = [None] * world
+            dist.all_gather_object(lts, loop["ms_per_step"])
+            loop["per_rank_ms_per_step"] = lts
+            loop["ms_per_step"] = max(lts)
+            loop["value"] = round(world * B / (max(lts) * 1e-3), 1)
     # further legs of the default single-GPU run (each reported beside `value`, none inside the timed region; a leg that
     # fails is reported as its error, the line itself stands): the validation loop and the yv5m scale
     extra = {}

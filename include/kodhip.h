@@ -244,6 +244,10 @@ int kodhip_sgd_nesterov(float* params, const float* grads, float* momentum_buf, 
                         long n, const float* hyper /* device, 10 floats: lr[3] momentum[3] wd[3] grad_scale */,
                         kodStream_t stream);
 int kodhip_fill_u32(void* p, uint32_t value, long n, kodStream_t stream);
+/* dst (device) <- src (PINNED host memory), bytes % 16 == 0, both 16-byte aligned: a kernel pulling the bytes through the
+ * host memory's device mapping - the small per-step tables of the data path (kod/data/detection.py's per-sample results)
+ * without an async-copy hand-over on the step's stream; hipMemcpyAsync when the memory has no device mapping */
+int kodhip_pull_from_host(void* dst, const void* src_pinned, long bytes, kodStream_t stream);
 /* debug: *dst = the device's constant-rate wall clock (100 MHz), stream-ordered - time stamps inside a replayed hipGraph */
 int kodhip_debug_stamp(unsigned long long* dst, kodStream_t stream);
 
@@ -338,10 +342,16 @@ typedef struct KodPeerView {                       /* passed BY VALUE to the *_p
 int kodhip_peer_create(void** peer, int rank, int world, long granules /* 8-byte granules: 4 per channel per exchange site */);
 int kodhip_peer_export(void* peer, void* handle64 /* host, 64 bytes out: hipIpcMemHandle_t */);
 int kodhip_peer_connect(void* peer, const void* handles /* host, world x 64 bytes in rank order */);
+/* the same for ranks living in ONE process (no IPC): peers = the world's kodhip_peer_create handles in rank order */
+int kodhip_peer_connect_local(void* peer, void* const* peers);
 int kodhip_peer_view_bytes(void);
 int kodhip_peer_view(void* peer, void* view_out /* host KodPeerView */);
 int kodhip_peer_step_begin(void* peer, kodStream_t stream);      /* once per step, before its first exchange */
 int kodhip_peer_allreduce_f64(void* peer, const double* in, double* out, int n, unsigned int slot, kodStream_t stream);
+/* all ranks of a one-process group (kodhip_peer_connect_local) in ONE dispatch (the ranks' blocks wait for each other, so they
+ * must be co-resident: separate launches on separate streams may share a hardware queue); ins / outs in rank order */
+int kodhip_peer_allreduce_f64_multi(void* const* peers, int world, const double* const* ins, double* const* outs, int n,
+                                    unsigned int slot, kodStream_t stream);
 int kodhip_peer_timed_out(void* peer, int* flag /* host out; synchronises, resets the flag */);
 /* the verdict without a device synchronisation (pinned host mirror): 0 ok, 1 a poll gave up, 2 step counters diverged.
  * A failed exchange never folds a stale payload into the statistics: its sums become NaN. */

@@ -85,6 +85,7 @@ SIGNATURES = {
     "kodhip_head_bwd_prep": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "kodhip_sgd_nesterov": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "kodhip_fill_u32": (i32, [vp, u32, i64, vp]),
+    "kodhip_pull_from_host": (i32, [vp, vp, i64, vp]),
     "kodhip_debug_stamp": (i32, [vp, vp]),
     "kodhip_comm_load": (i32, [C.c_char_p]),
     "kodhip_comm_unique_id": (i32, [vp]),
@@ -96,10 +97,12 @@ SIGNATURES = {
     "kodhip_peer_create": (i32, [C.POINTER(vp), i32, i32, i64]),
     "kodhip_peer_export": (i32, [vp, vp]),
     "kodhip_peer_connect": (i32, [vp, vp]),
+    "kodhip_peer_connect_local": (i32, [vp, vp]),
     "kodhip_peer_view_bytes": (i32, []),
     "kodhip_peer_view": (i32, [vp, vp]),
     "kodhip_peer_step_begin": (i32, [vp, vp]),
     "kodhip_peer_allreduce_f64": (i32, [vp, vp, vp, i32, u32, vp]),
+    "kodhip_peer_allreduce_f64_multi": (i32, [vp, i32, vp, vp, i32, u32, vp]),
     "kodhip_peer_timed_out": (i32, [vp, C.POINTER(i32)]),
     "kodhip_peer_status": (i32, [vp, C.POINTER(i32)]),
     "kodhip_peer_destroy": (i32, [vp]),

@@ -182,8 +182,9 @@ __global__ void peer_step_begin_kernel(unsigned int* seq, KodPeerView pv) {
 }
 
 // transport self-test / generic form: out[i] = sum over ranks of in[i] (pairs of values per wave, like the BN kernels)
-__global__ void peer_allreduce_f64_kernel(const double* in, double* out, int n, KodPeerView pv, unsigned int slot) {
-  const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__device__ __forceinline__ void peer_allreduce_f64_body(const double* in, double* out, int n, const KodPeerView& pv, unsigned int slot,
+                                                        int block) {
+  const int pair = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int i0 = 2 * pair, i1 = 2 * pair + 1;
   if (i0 >= n) return;
@@ -214,6 +215,23 @@ __global__ void peer_allreduce_f64_kernel(const double* in, double* out, int n, 
     out[i0] = t0;
     if (second_ok) out[i1] = t1;
   }
+}
+
+__global__ void peer_allreduce_f64_kernel(const double* in, double* out, int n, KodPeerView pv, unsigned int slot) {
+  peer_allreduce_f64_body(in, out, n, pv, slot, blockIdx.x);
+}
+
+// every rank of a one-process exchange in ONE dispatch (blockIdx.y = rank): the ranks' blocks are co-resident by
+// construction, whatever hardware queue a stream would have been given (eight polling launches on eight streams share
+// four queues by default: a launch queued behind the one that waits for it never starts)
+struct PeerMultiArgs {
+  KodPeerView pv[KOD_PEER_MAX];
+  const double* in[KOD_PEER_MAX];
+  double* out[KOD_PEER_MAX];
+};
+__global__ void peer_allreduce_f64_multi_kernel(PeerMultiArgs a, int n, unsigned int slot) {
+  const int r = blockIdx.y;
+  peer_allreduce_f64_body(a.in[r], a.out[r], n, a.pv[r], slot, blockIdx.x);
 }
 
 #define KOD_HIP(call, what)                                                   \
@@ -295,6 +313,33 @@ int kodhip_peer_connect(void* peer, const void* handles) {
   return KOD_OK;
 }
 
+// The same connection for ranks that live in ONE process (one host thread driving several GPUs with peer access, or
+// several exchange buffers on one GPU): `peers` = the world's kodhip_peer_create handles in rank order, this rank's own
+// entry included; the other ranks' buffers are used through their device pointers, no IPC handle involved.
+int kodhip_peer_connect_local(void* peer, void* const* peers) {
+  KOD_CHECK_ARG(peer && peers, "peer_connect_local: null");
+  PeerComm* c = (PeerComm*)peer;
+  for (int r = 0; r < c->world; ++r) {
+    PeerComm* o = (PeerComm*)peers[r];
+    KOD_CHECK_ARG(o && o->world == c->world && o->rank == r && o->granules == c->granules && o->local,
+                  "peer_connect_local: entry %d is not rank %d of the same %d-rank exchange", r, r, c->world);
+  }
+  KOD_CHECK_ARG(peers[c->rank] == peer, "peer_connect_local: this rank's own entry must be its handle");
+  c->view = KodPeerView{};
+  for (int r = 0; r < c->world; ++r) {
+    c->mapped[r] = nullptr;            // (nothing to close: the buffers belong to the other handles)
+    c->view.peers[r] = (unsigned long long*)(((PeerComm*)peers[r])->local + PEER_HEADER);
+  }
+  c->view.world = c->world; c->view.rank = c->rank;
+  c->view.seq = (const unsigned int*)c->local;
+  c->view.timeout_flag = (int*)(c->local + 64);
+  void* hfd = nullptr;
+  KOD_HIP(hipHostGetDevicePointer(&hfd, c->host_flag, 0), "peer_connect_local");
+  c->view.host_flag = (int*)hfd;
+  c->view.max_spins = 1l << 26;
+  return KOD_OK;
+}
+
 int kodhip_peer_view_bytes(void) { return (int)sizeof(KodPeerView); }
 
 // copies the KodPeerView the BatchNorm kernels take by value (device pointers of every rank's granule area)
@@ -327,6 +372,29 @@ int kodhip_peer_allreduce_f64(void* peer, const double* in, double* out, int n, 
   v.max_spins = 1l << 22;                    // the transport alone (self-test): a few seconds
   hipLaunchKernelGGL(peer_allreduce_f64_kernel, dim3(cdiv(pairs, 4)), dim3(256), 0, stream, in, out, n, v, slot);
   KOD_LAUNCH_CHECK("peer_allreduce_f64");
+  return KOD_OK;
+}
+
+// The same exchange for ALL ranks of a one-process group (kodhip_peer_connect_local) as one dispatch: ins / outs = the
+// ranks' n-value vectors in rank order.  The whole grid must be resident at once (the ranks' blocks wait for each other):
+// ceil(n / 8) * world blocks of 256 threads, at most 2048.
+int kodhip_peer_allreduce_f64_multi(void* const* peers, int world, const double* const* ins, double* const* outs, int n,
+                                    unsigned int slot, hipStream_t stream) {
+  KOD_CHECK_ARG(peers && ins && outs && world >= 1 && world <= KOD_PEER_MAX && n > 0, "peer_allreduce_f64_multi: bad args");
+  PeerMultiArgs a = {};
+  for (int r = 0; r < world; ++r) {
+    PeerComm* c = (PeerComm*)peers[r];
+    KOD_CHECK_ARG(c && c->world == world && c->rank == r && c->view.world == world && ins[r] && outs[r],
+                  "peer_allreduce_f64_multi: entry %d is not a connected rank %d of %d", r, r, world);
+    KOD_CHECK_ARG((long)slot + 2l * n <= c->granules, "peer_allreduce_f64_multi: slot range beyond the exchange buffer");
+    a.pv[r] = c->view;
+    a.pv[r].max_spins = 1l << 22;
+    a.in[r] = ins[r]; a.out[r] = outs[r];
+  }
+  const int pairs = (n + 1) / 2;
+  KOD_CHECK_ARG((long)cdiv(pairs, 4) * world <= 2048, "peer_allreduce_f64_multi: the grid must be resident at once (n too large)");
+  hipLaunchKernelGGL(peer_allreduce_f64_multi_kernel, dim3(cdiv(pairs, 4), world), dim3(256), 0, stream, a, n, slot);
+  KOD_LAUNCH_CHECK("peer_allreduce_f64_multi");
   return KOD_OK;
 }
 

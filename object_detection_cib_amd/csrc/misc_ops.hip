@@ -398,6 +398,13 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n) {
 
 __global__ void stamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
 
+// small host -> device upload as a KERNEL reading pinned host memory through its device mapping (16 bytes per lane):
+// on this stack an async copy queued on a compute stream costs that stream ~0.15 ms whatever its size (engine hand-over),
+// a kernel that pulls the same bytes over PCIe a few microseconds
+__global__ __launch_bounds__(256) void pull_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -506,6 +513,26 @@ int kodhip_debug_stamp(unsigned long long* dst, hipStream_t stream) {
   KOD_CHECK_ARG(dst, "debug_stamp: null");
   hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, stream, dst);
   KOD_LAUNCH_CHECK("debug_stamp");
+  return KOD_OK;
+}
+
+// dst (device) <- src (PINNED host memory, e.g. a torch pin_memory() tensor), bytes a multiple of 16, both 16-byte aligned:
+// the per-step tables of the data path (compositing descriptors, the batch's target block) without a copy-engine hand-over
+// on the step's stream.  Falls back to hipMemcpyAsync when the host memory has no device mapping.
+int kodhip_pull_from_host(void* dst, const void* src_pinned, long bytes, hipStream_t stream) {
+  KOD_CHECK_ARG(dst && src_pinned && bytes > 0 && bytes % 16 == 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)src_pinned % 16) == 0,
+                "pull_from_host: bad args (16-byte granularity)");
+  void* mapped = nullptr;
+  if (hipHostGetDevicePointer(&mapped, const_cast<void*>(src_pinned), 0) != hipSuccess || !mapped) {
+    (void)hipGetLastError();
+    hipError_t e = hipMemcpyAsync(dst, src_pinned, (size_t)bytes, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) { kodhip_set_error("pull_from_host: %s", hipGetErrorString(e)); return (int)e; }
+    return KOD_OK;
+  }
+  const long n16 = bytes / 16;
+  const int grid = (int)(cdiv(n16, 256) < 256 ? cdiv(n16, 256) : 256);
+  hipLaunchKernelGGL(pull_host_kernel, dim3(grid), dim3(256), 0, stream, (const uint4*)mapped, (uint4*)dst, n16);
+  KOD_LAUNCH_CHECK("pull_from_host");
   return KOD_OK;
 }
 

@@ -30,10 +30,12 @@ from .host_protocol import (AffineParams, HSVParams, AugParams, SAMPLE_DESC, Hos
 
 
 def bilinear_table() -> np.ndarray:
-    """OpenCV's fixed-point INTER_LINEAR table (imgwarp.cpp initInterTab2D, fixpt): [32*32][4] int16 weights
-    (y0x0, y0x1, y1x0, y1x1) = saturate_cast<short>(wy*wx*32768).  All products are exact multiples of 32, so
-    every entry sums to 32768 except (0,0), where 32768 saturates to 32767 (OpenCV's sum fix-up for that entry
-    lands outside the 2x2 block and is overwritten, so it stays 32767)."""
+    """The constant tables of the compositing kernel as one int16 array: OpenCV's fixed-point INTER_LINEAR table
+    (imgwarp.cpp initInterTab2D, fixpt): [32*32][4] int16 weights (y0x0, y0x1, y1x0, y1x1) = saturate_cast<short>(wy*wx*32768) -
+    all products are exact multiples of 32, so every entry sums to 32768 except (0,0), where 32768 saturates to 32767
+    (OpenCV's sum fix-up for that entry lands outside the 2x2 block and is overwritten, so it stays 32767) - followed by the
+    two division tables of cvtColor's RGB2HSV_b (color_hsv.simd.hpp: sdiv_table[i] = cvRound((255 << 12) / (1. * i)),
+    hdiv_table180[i] = cvRound((180 << 12) / (6. * i)), entry 0 = 0; int32 [256] each, stored as int16 pairs)."""
     n = 32
     t1 = np.stack((1.0 - np.arange(n) / n, np.arange(n) / n), 1).astype(np.float32)
     tab = np.zeros((n, n, 4), dtype=np.int16)
@@ -41,7 +43,10 @@ def bilinear_table() -> np.ndarray:
         for j in range(n):
             f = (t1[i][:, None] * t1[j][None, :]).astype(np.float32).reshape(-1)
             tab[i, j] = np.clip(np.rint(f.astype(np.float64) * 32768), -32768, 32767).astype(np.int16)
-    return tab.reshape(n * n, 4)
+    i = np.arange(1, 256, dtype=np.float64)
+    sdiv = np.concatenate(([0], np.rint((255 << 12) / i))).astype(np.int32)
+    hdiv = np.concatenate(([0], np.rint((180 << 12) / (6.0 * i)))).astype(np.int32)
+    return np.concatenate((tab.reshape(-1), sdiv.view(np.int16), hdiv.view(np.int16)))
 
 
 class _Stager:
@@ -55,30 +60,41 @@ class _Stager:
 
     def upload(self, arr: np.ndarray) -> torch.Tensor:
         raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        size = (raw.size + 15) // 16 * 16              # (kodhip_pull_from_host moves 16-byte pieces)
         k = self.i
         self.i = (self.i + 1) % self.depth
         if self.events[k] is not None:
             self.events[k].synchronize()
-        if self.slots[k] is None or self.slots[k].numel() < raw.size:
-            self.slots[k] = torch.empty(max(raw.size, 1024), dtype=torch.uint8).pin_memory()
-        host = self.slots[k][:raw.size]
-        host.numpy()[:] = raw
-        dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
-        dev.copy_(host, non_blocking=True)
+        if self.slots[k] is None or self.slots[k].numel() < size:
+            self.slots[k] = torch.empty(max(size, 1024), dtype=torch.uint8).pin_memory()
+        host = self.slots[k][:size]
+        host.numpy()[:raw.size] = raw
+        dev = torch.empty(size, dtype=torch.uint8, device=self.device)
+        # a kernel pulling the pinned bytes through their device mapping: an async copy queued on the stream costs the stream
+        # ~0.15 ms whatever its size on this stack (tools/loop_parts.py)
+        _lib.check(_lib.lib().kodhip_pull_from_host(dev.data_ptr(), host.data_ptr(), size, torch.cuda.current_stream().cuda_stream),
+                   "pull_from_host")
         ev = torch.cuda.Event()
         ev.record()
         self.events[k] = ev
-        return dev
+        return dev[:raw.size]
 
 
 def compose(pool: torch.Tensor, descs: np.ndarray, mix: np.ndarray, tab: torch.Tensor, S: int, stager: "_Stager",
-            out_f32: bool = True, out_pairs: bool = False):
-    """One launch of compose_kernel for descs [B][2] / mix [B][2]; returns (f32 [B,3,S,S] | None, pairs | None)."""
+            out_f32: bool = True, out_pairs: bool = False, pairs_out: torch.Tensor = None):
+    """One launch of compose_kernel for descs [B][2] / mix [B][2]; returns (f32 [B,3,S,S] | None, pairs | None).
+    pairs_out: write the pixel pairs into this tensor (the network's own input buffer, Engine.image_buffer) instead of a new one."""
     B = descs.shape[0]
     d_dev = stager.upload(descs)
     m_dev = stager.upload(mix).view(torch.float32)
     img = torch.empty((B, 3, S, S), dtype=torch.float32, device=pool.device) if out_f32 else None
-    pairs = torch.empty((B, S, S // 2, 8), dtype=torch.bfloat16, device=pool.device) if out_pairs else None
+    pairs = None
+    if out_pairs:
+        if pairs_out is not None:
+            assert tuple(pairs_out.shape) == (B, S, S // 2, 8) and pairs_out.dtype == torch.bfloat16 and pairs_out.is_contiguous()
+            pairs = pairs_out
+        else:
+            pairs = torch.empty((B, S, S // 2, 8), dtype=torch.bfloat16, device=pool.device)
     _lib.check(_lib.lib().kodhip_compose_batch(pool.data_ptr(), d_dev.data_ptr(), m_dev.data_ptr(), tab.data_ptr(),
                                                img.data_ptr() if out_f32 else None,
                                                pairs.data_ptr() if out_pairs else None, B, S,
@@ -93,7 +109,8 @@ class ImagePool:
         self.shapes = [(im.shape[0], im.shape[1]) for im in images]
         sizes = [im.shape[0] * im.shape[1] * 3 for im in images]
         self.offsets = np.concatenate(([0], np.cumsum(sizes)[:-1])).astype(np.int64)
-        flat = np.concatenate([np.ascontiguousarray(im, dtype=np.uint8).reshape(-1) for im in images])
+        # (+ 8 bytes of slack: the compositing kernel fetches a pixel's three channel bytes with one 4-byte load)
+        flat = np.concatenate([np.ascontiguousarray(im, dtype=np.uint8).reshape(-1) for im in images] + [np.zeros(8, np.uint8)])
         self.data = torch.from_numpy(flat).to(device)
 
 
@@ -128,9 +145,10 @@ class DeviceTrainPipeline:
         return dict(shapes=h.shapes, offsets=h.offsets, boxes=h.boxes, labels=h.labels, target_image_size=h.S,
                     aug_params=h.aug, mixup_prob=h.mixup_prob, image_repeat_factors=h.weights, sampler_indices=h.sampler_indices)
 
-    def compose_host_batch(self, descs: np.ndarray, mix: np.ndarray, out_f32: bool = True, out_pairs: bool = False):
-        """The device half alone: descriptors (from this process or from a producer process) -> (f32 | None, pairs | None)."""
-        img, pairs, self._keep = compose(self.pool.data, descs, mix, self.tab, self.S, self._stager, out_f32, out_pairs)
+    def compose_host_batch(self, descs: np.ndarray, mix: np.ndarray, out_f32: bool = True, out_pairs: bool = False, pairs_out=None):
+        """The device half alone: descriptors (from this process or from a producer process) -> (f32 | None, pairs | None).
+        pairs_out: the tensor to composite into (e.g. the network's input buffer: no copy between pipeline and step)."""
+        img, pairs, self._keep = compose(self.pool.data, descs, mix, self.tab, self.S, self._stager, out_f32, out_pairs, pairs_out)
         return img, pairs
 
     def make_batch(self, batch_indices: Sequence[int], out_f32: bool = True, out_pairs: bool = False):

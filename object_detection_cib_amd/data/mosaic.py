@@ -58,7 +58,8 @@ def upload_images(images: Sequence[np.ndarray], device):
     """u8 HWC images -> one flat device buffer + byte offsets."""
     flats = [np.ascontiguousarray(im, dtype=np.uint8).reshape(-1) for im in images]
     offs = np.concatenate(([0], np.cumsum([f.size for f in flats])[:-1])).astype(np.int64)
-    host = torch.from_numpy(np.concatenate(flats)).pin_memory()
+    # (+ 8 bytes of slack: the compositing kernel fetches a pixel's three channel bytes with one 4-byte load)
+    host = torch.from_numpy(np.concatenate(flats + [np.zeros(8, np.uint8)])).pin_memory()
     return host.to(device, non_blocking=True), offs
 
 

@@ -17,6 +17,7 @@ from typing import Optional, Sequence
 
 import torch
 
+from .. import _lib
 from ..core.label_assignment.yv5 import BatchedTargets
 from ..core.types import FeatureShape
 
@@ -34,18 +35,33 @@ class GraphedTrainStep:
         self.cap = int(max_targets)
         self.scale = float(batch_size if loss_scale is None else loss_scale)     # exp.py:104-138: total = B * sum
         self.x = torch.zeros((batch_size, 3, height, width), dtype=torch.float32, device=dev)
-        self.boxes = torch.zeros((self.cap, 4), dtype=torch.float64, device=dev)
-        self.labels = torch.zeros(self.cap, dtype=torch.int64, device=dev)
-        self.samples = torch.zeros(self.cap, dtype=torch.int32, device=dev)
+        # boxes f64 [cap, 4] | labels i64 [cap] | sample ids i32 [cap] as views of ONE device block: a batch's targets arrive
+        # as one host -> device copy of the pinned mirror block (three copies + three fills cost 0.17 ms per step)
+        cap = self.cap
+        tbytes = (cap * 44 + 15) // 16 * 16            # (kodhip_pull_from_host moves 16-byte pieces)
+        self._tblock = torch.zeros(tbytes, dtype=torch.uint8, device=dev)
+        self.boxes = self._tblock[:cap * 32].view(torch.float64).view(cap, 4)
+        self.labels = self._tblock[cap * 32:cap * 40].view(torch.int64)
+        self.samples = self._tblock[cap * 40:cap * 44].view(torch.int32)
         self.targets = BatchedTargets(self.boxes, self.labels, self.samples, self.cap)
         self.shape = FeatureShape(width=width, height=height)
         self.params = list(net.parameters())
         self.graph = None
         self.total = None
         self.parts = None
-        self._host = [(torch.zeros((self.cap, 4), dtype=torch.float64).pin_memory(), torch.zeros(self.cap, dtype=torch.int64).pin_memory(),
-                       torch.zeros(self.cap, dtype=torch.int32).pin_memory()) for _ in range(4)]
-        self._events, self._slot = [None] * 4, 0
+        self._host = []
+        for _ in range(4):
+            blk = torch.zeros(tbytes, dtype=torch.uint8).pin_memory()
+            self._host.append((blk, blk[:cap * 32].view(torch.float64).view(cap, 4), blk[cap * 32:cap * 40].view(torch.int64),
+                               blk[cap * 40:cap * 44].view(torch.int32)))
+        self._events, self._slot, self._used = [None] * 4, 0, [0] * 4
+
+    def input_buffer(self) -> torch.Tensor:
+        """input_pairs=True: the network's own input buffer (bf16 pixel pairs [B, H, W/2, 8]).  A data pipeline that runs on
+        the step's stream may write the next batch straight into it (DeviceTrainPipeline.compose_host_batch(pairs_out=...))
+        and pass the same tensor to __call__: no copy between pipeline and step."""
+        assert self.input_pairs
+        return self.eng.image_buffer(self.B, self.H, self.W)
 
     # -- the step itself (what gets captured)
     def _step(self):
@@ -60,7 +76,8 @@ class GraphedTrainStep:
         if self.input_pairs:
             buf = self.eng.image_buffer(self.B, self.H, self.W)
             assert tuple(images.shape) == tuple(buf.shape) and images.dtype == buf.dtype, (images.shape, images.dtype, buf.shape)
-            buf.copy_(images, non_blocking=True)
+            if images.data_ptr() != buf.data_ptr():        # (a pipeline may composite straight into the input buffer: input_buffer())
+                buf.copy_(images, non_blocking=True)
         else:
             assert tuple(images.shape) == tuple(self.x.shape), (images.shape, self.x.shape)
             self.x.copy_(images, non_blocking=True)
@@ -86,8 +103,11 @@ class GraphedTrainStep:
         self._slot = (self._slot + 1) % len(self._host)
         if self._events[k] is not None:
             self._events[k].synchronize()
-        hb, hl, hs = self._host[k]
-        hb.zero_(); hl.zero_(); hs.zero_()
+        blk, hb, hl, hs = self._host[k]
+        m_old = self._used[k]                  # padding = zero-size boxes: only what the slot's previous batch filled needs clearing
+        if m_old > n:
+            hb[n:m_old].zero_(); hl[n:m_old].zero_(); hs[n:m_old].zero_()
+        self._used[k] = n
         if packed:
             if n:
                 hb.numpy()[:n] = targets.boxes
@@ -102,9 +122,8 @@ class GraphedTrainStep:
                 hl[o:o + m] = t.labels.reshape(-1).to(torch.int64)
                 hs[o:o + m] = i
                 o += m
-        self.boxes.copy_(hb, non_blocking=True)
-        self.labels.copy_(hl, non_blocking=True)
-        self.samples.copy_(hs, non_blocking=True)
+        _lib.check(self.eng.lib.kodhip_pull_from_host(self._tblock.data_ptr(), blk.data_ptr(), blk.numel(),
+                                                      torch.cuda.current_stream().cuda_stream), "pull_from_host")
         ev = torch.cuda.Event()
         ev.record()
         self._events[k] = ev

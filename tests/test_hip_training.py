@@ -179,6 +179,59 @@ def test_graphed_step_from_pixel_pairs_equals_fp32_input():
     assert torch.equal(runs[True][1], runs[False][1])
 
 
+def test_producer_process_loop_equals_in_process_loop():
+    """data/producer.py feeding the captured step (bench.py's loop leg; the reference feeds its trainer from DataLoader worker
+    processes, kod/lightning/data_module.py:135-144): the host side of the data protocol in a worker process - descriptors,
+    mixup ratios and packed targets through shared memory, compositing here - must give the very batches of the in-process
+    protocol: images bit for bit, the same losses and parameters after five replayed steps (mixup on: the worker owns
+    numpy.random too)."""
+    from object_detection_cib_amd.data.producer import DescriptorProducer
+    from object_detection_cib_amd.engine.graphed import GraphedTrainStep
+    from bench import build
+    S, nc, B, steps, seed = 160, 10, 8, 5, 9
+    cache = synth.coco_zipf_like(64, S, seed, nc)
+    schedule = [[(i * B + k) % len(cache) for k in range(B)] for i in range(steps + 1)]
+    runs = {}
+    for use_producer in (False, True):
+        pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda", mixup_prob=0.4)
+        prod = None
+        if use_producer:
+            prod = DescriptorProducer(pipe.host_args(), B, schedule, rng_seed=51, py_seed=seed, np_seed=seed, max_boxes=512)
+        else:
+            random.seed(seed); np.random.seed(seed)
+        try:
+            torch.manual_seed(seed)
+            net, loss_fn = build(nc, torch.device("cuda", 0), seed=seed, widen=0.25)
+            net.engine().sgd_step((0.01, 0.01, 0.01), (0.9,) * 3, (0.0, 5e-4, 0.0), 1.0)
+
+            def produce(i):
+                if prod is not None:
+                    descs, mix, tg = prod.next(timeout=120)
+                    _, pr = pipe.compose_host_batch(descs, mix, out_f32=False, out_pairs=True)
+                    return pr, tg
+                _, pr, tg = pipe.make_batch(schedule[i], out_f32=False, out_pairs=True)
+                return pr, tg
+            first = produce(0)
+            gs = GraphedTrainStep(net, loss_fn, B, S, S, max_targets=512, input_pairs=True).capture(first[0], first[1])
+            losses, imgs, nxt = [], [first[0].clone()], first
+            for i in range(steps):
+                x, tg = nxt
+                nxt = produce(i + 1)
+                imgs.append(nxt[0].clone())
+                total, _ = gs(x, tg)
+                losses.append(float(total))
+            torch.cuda.synchronize()
+        finally:
+            if prod is not None:
+                prod.close()
+        runs[use_producer] = (losses, torch.cat([p.detach().flatten() for p in net.parameters()]).cpu(), [t.cpu() for t in imgs])
+    assert np.isfinite(runs[False][0]).all()
+    for a, b in zip(runs[True][2], runs[False][2]):
+        assert torch.equal(a, b)
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
+    assert torch.equal(runs[True][1], runs[False][1])
+
+
 def test_graphed_loop_survives_validation_at_other_shapes():
     """A captured hipGraph bakes the engine's buffer addresses in.  A validation forward at another batch size /
     resolution between replays must not free or reuse them (Engine.allocate keeps one buffer set per shape):
@@ -321,8 +374,10 @@ def test_first_epoch_map_vs_cpu_trainer(golden):
         assert (runs[:, i] >= 0.4 * mean[i]).all() and (runs[:, i] <= mean[i] + 6 * sd[i]).all(), (k, runs[:, i], mean[i], sd[i])
 
 
-def test_class_aware_mixup_reweighted_config_tracks_cpu_oracle():
-    """BASELINE configs[2] + configs[3] on one GPU, all pieces together: ClassAwareSampler(dataset_info) drives the epoch
+@pytest.mark.parametrize("scale", ["yv5n_160", "yv5s_640"])
+def test_class_aware_mixup_reweighted_config_tracks_cpu_oracle(scale):
+    """BASELINE configs[2] + configs[3] on one GPU, all pieces together (yv5s_640: at configs[3]'s own network and
+    resolution, B = 8, eight steps; yv5n_160: 24 steps of the small form): ClassAwareSampler(dataset_info) drives the epoch
     order and (through its `sampler_indices` side channel, kod/data/detection.py:114-122) the mosaic partner choice,
     mosaic + mixup (p = 0.3) compositing on the device, BCE classification loss re-weighted with
     pos_weight = sum(count) / count_c (kod/lightning/tasks/trainer.py:54-58).  The HIP trainer's loss trajectory must
@@ -330,7 +385,7 @@ def test_class_aware_mixup_reweighted_config_tracks_cpu_oracle():
     import datetime
     from object_detection_cib_amd.data.cache import DatasetInfo, ImageMetadata, SampleInfo, TargetInfo
     from object_detection_cib_amd.data.samplers import ClassAwareSampler
-    S, nc, B, steps, seed = 160, 10, 8, 24, 9
+    (S, steps, widen), nc, B, seed = {"yv5n_160": (160, 24, 0.25), "yv5s_640": (640, 8, 0.5)}[scale], 10, 8, 9
     cache = synth.coco_zipf_like(96, S, seed, nc)
     names = [f"c{i}" for i in range(nc)]
     meta = ImageMetadata(S, S, 3, "image/jpeg", 1)
@@ -350,14 +405,14 @@ def test_class_aware_mixup_reweighted_config_tracks_cpu_oracle():
                                mixup_prob=0.3, sampler_indices=sampler.sampler_indices)
     random.seed(seed); np.random.seed(seed)
     torch.manual_seed(seed)
-    net = Yolov5Network(3, nc, widen_factor=0.25, deepen_factor=0.33).cuda().train()
+    net = Yolov5Network(3, nc, widen_factor=widen, deepen_factor=0.33).cuda().train()
     infos = (voc_anchor_info(8), voc_anchor_info(16), voc_anchor_info(32))
     loss = Yolov5Loss(Yolov5LabelAssigner(AssignmentAnchorInfo(*infos), 4.0), Yolov5LossParams.get_default(),
                       IoUCalculator("ciou", 1e-7), full.tolist())
     exp = DefaultYolov5Experiment(net, loss, LayerwiseAnchorInfo(*infos),
                                   optimizer_warmup_updater=OptimizerWarmupUpdater(3, 0.1, 0.8, 0.937))
     torch.manual_seed(seed)
-    ref = OracleYolov5(3, nc, 0.25, 0.33).train()
+    ref = OracleYolov5(3, nc, widen, 0.33).train()
     bias, decay, norm = O.param_groups(ref)
     opt = torch.optim.SGD([dict(params=bias, weight_decay=0.0), dict(params=decay, weight_decay=5e-4),
                            dict(params=norm, weight_decay=0.0)], lr=0.01, momentum=0.937, nesterov=True)

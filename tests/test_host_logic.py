@@ -114,9 +114,14 @@ def test_device_pipeline_host_math_matches_golden(golden):
         np.testing.assert_array_equal(keep, ga["keep"][i])
         inv = P.invert_affine(M)
         np.testing.assert_allclose(np.vstack([inv, [0, 0, 1]]) @ M, np.eye(3), atol=1e-9)
-    tab = P.bilinear_table()
+    full = P.bilinear_table()          # bilinear weights [1024][4] int16 | sdiv_table[256] | hdiv_table180[256] (int32)
+    assert full.dtype == np.int16 and full.shape == (4096 + 1024,)
+    tab = full[:4096].reshape(1024, 4)
     sums = tab.astype(np.int64).sum(1)
-    assert tab.shape == (1024, 4) and tab[0].tolist() == [32767, 0, 0, 0] and (sums[1:] == 32768).all()
+    assert tab[0].tolist() == [32767, 0, 0, 0] and (sums[1:] == 32768).all()
+    sdiv, hdiv = full[4096:4608].view(np.int32), full[4608:].view(np.int32)
+    # OpenCV color_hsv.simd.hpp: sdiv_table[i] = cvRound((255 << 12) / (1. * i)), hdiv_table180[i] = cvRound((180 << 12) / (6. * i))
+    assert sdiv[0] == 0 and hdiv[0] == 0 and sdiv[1] == 255 << 12 and sdiv[255] == 4096 and hdiv[1] == 122880 and hdiv[255] == 482
 
 
 def test_samplers_and_schedule_host_mirrors(golden):
