@@ -37,8 +37,11 @@ class _Composite(torch.Tensor):
 class TrainSampleAugmentor(object):
     def __init__(self, aug_params: AugParams, rng_seed: int = 51, device="cuda"):
         if aug_params.image_color_transforms:
-            raise NotImplementedError("image_color_transforms (Blur / MedianBlur / ToGray / CLAHE at p = 0.01, "
-                                      "default.py:420-431) are not on the HIP path; use image_color_transforms=False")
+            raise NotImplementedError(
+                "image_color_transforms=True (kod/configs/data/augmentations/aug_params.yaml:15: albumentations Blur / MedianBlur / "
+                "ToGray / CLAHE at p = 0.01 each, kod/data/augmentations/default.py:420-431) is not on the HIP path (SURVEY 2.1: out "
+                "of scope). Run the reference config with the Hydra override "
+                "`data.augmentations.aug_params.image_color_transforms=false` (or AugParams(image_color_transforms=False)).")
         self.aug_params = aug_params
         self.rng: np.random.Generator = np.random.default_rng(rng_seed)
         self.device = torch.device(device)
