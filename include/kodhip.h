@@ -239,9 +239,10 @@ int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx,
 int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_box, float* db_obj, float* db_cls,
                          int B, int HW, int A, int nc, int Npad, kodStream_t stream);
 
-/* ---- optimizer (torch.optim.SGD nesterov as grouped by kod/nn/optim/smart.py:36-58) --------------- */
+/* ---- optimizer (torch.optim.SGD, dampening 0, as grouped by kod/nn/optim/smart.py:36-58) ---------- */
 int kodhip_sgd_nesterov(float* params, const float* grads, float* momentum_buf, const void* group_ids,
-                        long n, const float* hyper /* device, 10 floats: lr[3] momentum[3] wd[3] grad_scale */,
+                        long n, const float* hyper /* device, 12 floats: lr[3] momentum[3] wd[3] grad_scale,
+                                                      nesterov (smart_sgd.yaml: 1; 0 = plain momentum), reserved */,
                         kodStream_t stream);
 int kodhip_fill_u32(void* p, uint32_t value, long n, kodStream_t stream);
 /* dst (device) <- src (PINNED host memory), bytes % 16 == 0, both 16-byte aligned: a kernel pulling the bytes through the
@@ -274,6 +275,13 @@ int kodhip_yolo_loss(const KodLossLevel* levels /* host[3] */, int B, int A, int
                      float lam_box, float lam_obj, float lam_cls, const float* pos_weight,
                      const float* upstream, float* partials, int nslots, float* out, int compute_grad,
                      kodStream_t stream);
+
+/* the same with the loss's IoUCalculator (loss.py:46-63,96): iou_kind 0 iou | 1 giou | 2 diou | 3 ciou (iou.py:9-14) and its eps;
+ * (3, 1e-7f) is what kodhip_yolo_loss runs */
+int kodhip_yolo_loss_iou(const KodLossLevel* levels /* host[3] */, int B, int A, int nc, int cap,
+                         float lam_box, float lam_obj, float lam_cls, const float* pos_weight,
+                         const float* upstream, float* partials, int nslots, float* out, int compute_grad,
+                         int iou_kind, float iou_eps, kodStream_t stream);
 
 /* Aligned IoU family behind kod.core.bbox.iou.IoUCalculator.__call__ (kod/core/bbox/iou.py:77-95,142-268):
  * boxes [m][4] xyxy fp32 -> out [m]; kind 0 iou | 1 giou | 2 diou | 3 ciou (IoUType order, iou.py:9-14).

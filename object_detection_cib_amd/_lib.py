@@ -120,6 +120,8 @@ SIGNATURES = {
     "kodhip_iou_bwd": (i32, [vp, vp, vp, vp, vp, i64, i32, f32, vp]),
     "kodhip_yolo_loss": (i32, [C.POINTER(KodLossLevel), i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp,
                                i32, vp]),
+    "kodhip_yolo_loss_iou": (i32, [C.POINTER(KodLossLevel), i32, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp,
+                                   i32, i32, f32, vp]),
 }
 
 _lib = None

@@ -10,6 +10,7 @@
 // Duplicate-cell gradient accumulation is done in row order by the cell's last writer (no float atomics),
 // loss sums go through fixed-order partial slabs => bitwise run-to-run reproducible.
 #include "kodhip_common.h"
+#include "kodhip_iou.h"
 #include <limits.h>
 
 namespace {
@@ -173,6 +174,9 @@ struct LossArgs {
   float* out;                          // [3] losses + [9] per-level raw means
   int compute_grad;
   uint32_t magic_p;                    // magic of P (loss_cells: element index -> cell within a 64-cell chunk)
+  int iou_kind;                        // 0 iou | 1 giou | 2 diou | 3 ciou (IoUCalculator.iou_type, kod/core/bbox/iou.py:9-14)
+  float iou_eps;
+  int iou_generic;                     // anything but the fused ciou / 1e-7 form: the dual-number row of kodhip_iou.h
 };
 
 __device__ __forceinline__ int cell_of(const LossLevel& L, int A, int cap, int r) {
@@ -241,6 +245,20 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
     float v = c4 * dat * dat;
     float alpha = v / ((1.f - iou) + v + eps);
     float ciou = iou - D - alpha * v;
+    // any other IoUCalculator (iou / giou / diou, or another eps; loss.py:46-63 takes whichever it is given): the value and
+    // its four derivatives w.r.t. the predicted box from the dual-number row that also backs the IoUCalculator op
+    float dgen[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.iou_generic) {
+      const float b1[4] = {x1, y1, x2, y2}, b2[4] = {x1g, y1g, x2g, y2g};
+      if (a.compute_grad) {
+        const Dual<8> rr = iou_row<8>(b1, b2, a.iou_kind, a.iou_eps);
+        ciou = rr.v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dgen[k] = rr.d[k];
+      } else {
+        ciou = iou_row<0>(b1, b2, a.iou_kind, a.iou_eps).v;
+      }
+    }
     lbox = 1.f - ciou;
     L.tobj[r] = fmaxf(ciou, 0.f);
 
@@ -286,7 +304,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossArgs a) {
         float dU = dA1[k] - dI[k];
         float diou = (dI[k] * ue - inter * dU) / (ue * ue);
         float dD = (dCd[k] * de - cdist * dDiag[k]) / (de * de);
-        dC[k] = diou - dD - alpha * dV[k];
+        dC[k] = a.iou_generic ? dgen[k] : diou - dD - alpha * dV[k];
       }
       float d_px = dC[0] + dC[2], d_py = dC[1] + dC[3];
       float d_pw = 0.5f * (dC[2] - dC[0]), d_ph = 0.5f * (dC[3] - dC[1]);
@@ -481,12 +499,29 @@ struct KodLossLevel {
 
 // partials: 9 * nslots floats with nslots >= max(ceil(cap/256), 1024) (need not be initialised); out: 16 floats
 // ([0..2] losses, [3..11] per-level raw means, [12] upstream[0] * ((loc + cls) + obj) when upstream is given).
+int kodhip_yolo_loss_iou(const KodLossLevel* levels, int B, int A, int nc, int cap, float lam_box, float lam_obj, float lam_cls,
+                         const float* pos_weight, const float* upstream, float* partials, int nslots, float* out,
+                         int compute_grad, int iou_kind, float iou_eps, hipStream_t stream);
+
 int kodhip_yolo_loss(const KodLossLevel* levels /*[3], host*/, int B, int A, int nc, int cap,
                      float lam_box, float lam_obj, float lam_cls, const float* pos_weight,
                      const float* upstream, float* partials, int nslots, float* out, int compute_grad,
                      hipStream_t stream) {
+  return kodhip_yolo_loss_iou(levels, B, A, nc, cap, lam_box, lam_obj, lam_cls, pos_weight, upstream, partials, nslots, out,
+                              compute_grad, 3, 1e-7f, stream);
+}
+
+// The same with the IoUCalculator the loss was constructed with (kod/lightning/experiments/yv5_baseline/loss.py:46-63, 96:
+// `iou = self.iou_calculator(pred_xyxy, gt_xyxy)`): iou_kind 0 iou | 1 giou | 2 diou | 3 ciou, its eps.  (3, 1e-7) - the
+// reference's configuration, kod/configs/nn/losses/yv5.yaml:13-16 - runs the closed-form CIoU and its analytic gradient.
+int kodhip_yolo_loss_iou(const KodLossLevel* levels /*[3], host*/, int B, int A, int nc, int cap,
+                         float lam_box, float lam_obj, float lam_cls, const float* pos_weight,
+                         const float* upstream, float* partials, int nslots, float* out, int compute_grad,
+                         int iou_kind, float iou_eps, hipStream_t stream) {
   KOD_CHECK_ARG(levels && partials && out && B > 0 && A > 0 && nc > 0 && cap > 0, "yolo_loss: bad args");
+  KOD_CHECK_ARG(iou_kind >= 0 && iou_kind <= 3 && iou_eps >= 0.f, "yolo_loss: bad IoU kind %d / eps", iou_kind);
   LossArgs a = {};
+  a.iou_kind = iou_kind; a.iou_eps = iou_eps; a.iou_generic = !(iou_kind == 3 && iou_eps == 1e-7f);
   long max_cells = 0;
   for (int l = 0; l < 3; ++l) {
     const KodLossLevel& s = levels[l];

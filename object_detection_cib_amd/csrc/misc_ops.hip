@@ -368,7 +368,8 @@ __global__ void head_bias_reduce_kernel(const float* bpart, int nblk, int Npad, 
 
 // ------------------------------------------------------------------ SGD
 // group id per 64-element granule: 0 bias, 1 decay, 2 norm, 255 padding
-// hyper (device memory, so a captured hipGraph sees per-step schedules): lr[3] | momentum[3] | wd[3] | grad_scale
+// hyper (device memory, so a captured hipGraph sees per-step schedules): lr[3] | momentum[3] | wd[3] | grad_scale | nesterov
+// (12 floats; torch.optim.SGD with dampening = 0: buf = mu * buf + g; p -= lr * (nesterov ? g + mu * buf : buf))
 __global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, const unsigned char* gid, long n,
                                     const float* hyper) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -376,6 +377,7 @@ __global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, const 
   unsigned char grp = gid[i >> 6];
   if (grp > 2) return;
   const float lr = hyper[grp], mu = hyper[3 + grp], wd = hyper[6 + grp], gscale = hyper[9];
+  const bool nesterov = hyper[10] != 0.f;
   f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
   f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
   f32x4 bv = *reinterpret_cast<const f32x4*>(buf + i);
@@ -385,7 +387,7 @@ __global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, const 
     if (wd != 0.f) gg = gg + wd * pv[e];
     float b = mu * bv[e] + gg;
     bv[e] = b;
-    pv[e] = pv[e] - lr * (gg + mu * b);
+    pv[e] = pv[e] - lr * (nesterov ? gg + mu * b : b);
   }
   *reinterpret_cast<f32x4*>(p + i) = pv;
   *reinterpret_cast<f32x4*>(buf + i) = bv;

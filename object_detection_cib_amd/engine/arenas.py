@@ -156,9 +156,10 @@ class ArenaMixin:
         self.pack_blocks = blk
         self.exec_units = exec_units
         self.device = device
-        self.hyper = torch.zeros(10, dtype=torch.float32, device=device)
+        self.hyper = torch.zeros(12, dtype=torch.float32, device=device)      # lr[3] | momentum[3] | wd[3] | grad scale | nesterov | -
+        self.sgd_nesterov = True          # FusedSGD(nesterov=...): smart_sgd.yaml's default, kod/configs/nn/optimizers/smart_sgd.yaml
         # pinned staging ring: the H2D copy is asynchronous, so a slot is not rewritten for the next 15 uploads
-        self._hyper_host = [torch.zeros(10, dtype=torch.float32).pin_memory() for _ in range(16)]
+        self._hyper_host = [torch.zeros(12, dtype=torch.float32).pin_memory() for _ in range(16)]
         self._hyper_events = [None] * len(self._hyper_host)
         self._hyper_slot = 0
         self._hyper_vals = None
@@ -200,7 +201,7 @@ class ArenaMixin:
     def set_hyper(self, lr, momentum, weight_decay, grad_scale: float = 1.0):
         """Upload the optimizer hyper-parameters (3-tuples for bias_params, decay_params, norm_params) to the device
         buffer the fused SGD kernel reads - outside any captured graph, so schedules keep working under replay."""
-        vals = (*lr, *momentum, *weight_decay, grad_scale)
+        vals = (*lr, *momentum, *weight_decay, grad_scale, 1.0 if self.sgd_nesterov else 0.0, 0.0)
         if vals != self._hyper_vals:                       # only touch the device copy when the schedule moved
             k = self._hyper_slot
             self._hyper_slot = (k + 1) % len(self._hyper_host)
@@ -221,7 +222,7 @@ class ArenaMixin:
         self.sgd_step_device()
 
     def sgd_step_device(self):
-        """SGD with whatever is in self.hyper (device, 10 floats) - the graph-capturable form."""
+        """SGD with whatever is in self.hyper (device, 12 floats) - the graph-capturable form."""
         _lib.check(self.lib.kodhip_sgd_nesterov(self.p_arena.data_ptr(), self.current_grad_arena().data_ptr(),
                                                 self.m_arena.data_ptr(), self.gid.data_ptr(), self.n_arena,
                                                 self.hyper.data_ptr(), self._stream()), "sgd")

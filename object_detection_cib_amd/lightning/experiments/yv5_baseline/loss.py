@@ -51,12 +51,12 @@ def _run(mod, shape, raws, asg, cap, grads, upstream, work):
     lam_obj = hp.lambda_objectness * ((shape.width / 640) ** 2)          # loss.py:231-233
     lam_cls = hp.lambda_classification * (nc / 80)                        # loss.py:235-237
     pw = mod.weights
-    _lib.check(lib.kodhip_yolo_loss(levels, B, A, nc, cap, hp.lambda_localization, lam_obj, lam_cls,
-                                    pw.data_ptr() if pw is not None else None,
-                                    upstream.data_ptr() if upstream is not None else None,
-                                    work["partials"].data_ptr(), work["nslots"], work["out"].data_ptr(),
-                                    1 if grads is not None else 0,
-                                    torch.cuda.current_stream().cuda_stream), "yolo_loss")
+    _lib.check(lib.kodhip_yolo_loss_iou(levels, B, A, nc, cap, hp.lambda_localization, lam_obj, lam_cls,
+                                        pw.data_ptr() if pw is not None else None,
+                                        upstream.data_ptr() if upstream is not None else None,
+                                        work["partials"].data_ptr(), work["nslots"], work["out"].data_ptr(),
+                                        1 if grads is not None else 0, mod.iou_kind, mod.iou_eps,
+                                        torch.cuda.current_stream().cuda_stream), "yolo_loss")
 
 
 class _LossFn(torch.autograd.Function):
@@ -97,10 +97,14 @@ class Yolov5Loss(nn.Module):
         self.assigner = assigner
         self.hparams = hparams
         self.iou_calculator = iou_calculator
+        # loss.py:46-63 takes any IoUCalculator; the kernel evaluates its kind / eps: ciou with eps 1e-7
+        # (kod/configs/nn/losses/yv5.yaml:13-16) in closed form, the other members of the family on dual numbers (csrc/kodhip_iou.h)
         kind = getattr(getattr(iou_calculator, "iou_type", None), "value", getattr(iou_calculator, "iou_type", None))
-        if kind != "ciou" or abs(float(getattr(iou_calculator, "eps", 1e-7)) - 1e-7) > 1e-12:
-            raise NotImplementedError("the fused HIP loss kernel implements iou_type=ciou, eps=1e-7 "
-                                      "(kod/configs/nn/losses/yv5.yaml:13-16)")
+        kinds = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3}
+        if kind not in kinds:
+            raise ValueError(f"unknown IoU type {kind!r}: expected one of {sorted(kinds)} (kod/core/bbox/iou.py:9-14)")
+        self.iou_kind = kinds[kind]
+        self.iou_eps = float(getattr(iou_calculator, "eps", 1e-7))
         # reference: plain attribute moved to CUDA when available (loss.py:58-61)
         self.weights = torch.tensor(weights, dtype=torch.float32) if weights is not None else None
 

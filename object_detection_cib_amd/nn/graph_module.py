@@ -60,14 +60,17 @@ def add_unit_parameters(root: nn.Module, graph: Graph, norm_layer):
         slot.add_module("1", norm_layer(u.cout))
 
 
-def add_head_parameters(root: nn.Module, graph: Graph, use_yv5_init: bool = True):
-    """The three biased 1x1 convs of every head, with the reference's bias initialisation (heads/yolov5.py:65-73,113-121)."""
+def add_head_parameters(root: nn.Module, graph: Graph, use_yv5_init: bool = True, prior_probability: float = 0.01):
+    """The three biased 1x1 convs of every head, with the reference's bias initialisation (heads/yolov5.py:65-73,113-121):
+    use_yv5_init: objectness + log(8 / (640 / stride)^2), classes + log(0.6 / (nc - 0.99999)); otherwise both get the
+    focal-loss prior - log((1 - p) / p) of `prior_probability`.  The box head keeps torch's default initialisation."""
     A, nc = graph.num_anchors, graph.num_classes
+    prior = -math.log((1 - prior_probability) / prior_probability)
     for h in graph.heads:
-        for key, p, shift in (("box", 4, 0.0), ("obj", 1, math.log(8 / (640 / h.stride) ** 2)),
-                              ("cls", nc, math.log(0.6 / (nc - 0.99999)))):
+        for key, p, shift in (("box", 4, 0.0), ("obj", 1, math.log(8 / (640 / h.stride) ** 2) if use_yv5_init else prior),
+                              ("cls", nc, math.log(0.6 / (nc - 0.99999)) if use_yv5_init else prior)):
             conv = nn.Conv2d(h.cin, A * p, 1)
-            if shift and use_yv5_init:
+            if shift:
                 with torch.no_grad():
                     conv.bias.add_(shift)
             ensure_path(root, head_param(h, key, "weight")[:-len(".conv.weight")]).add_module("conv", conv)
@@ -96,12 +99,12 @@ class _GraphFn(torch.autograd.Function):
 class GraphModule(nn.Module):
     """Base of the sub-network modules: parameters as torch holders, execution through an Engine over `self.graph`."""
 
-    def _init_graph(self, graph: Graph, norm_layer):
+    def _init_graph(self, graph: Graph, norm_layer, use_yv5_init: bool = True, prior_probability: float = 0.01):
         from .networks.yolov5 import Yolov5BatchNorm2d
         self.graph = graph
         add_unit_parameters(self, graph, norm_layer or Yolov5BatchNorm2d)
         if graph.heads:
-            add_head_parameters(self, graph)
+            add_head_parameters(self, graph, use_yv5_init, prior_probability)
         self._engine = None
         self._engine_device = None
         self._last_heads = ()

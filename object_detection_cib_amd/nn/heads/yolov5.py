@@ -14,9 +14,8 @@ class Yolov5Head(GraphModule):
     def __init__(self, in_channels: int, num_anchors_per_cell: int, num_classes: int, stride: int,
                  prior_probability: float = 0.01, use_yv5_init: bool = True):
         super().__init__()
-        if not use_yv5_init:
-            raise NotImplementedError("the HIP head mirrors the reference's default (use_yv5_init=True) bias initialisation")
-        self._init_graph(build_head_graph(in_channels, num_anchors_per_cell, num_classes, stride), None)
+        # (heads/yolov5.py:65-73,113-121: the YOLOv5 bias shifts by default, the focal-loss prior of `prior_probability` otherwise)
+        self._init_graph(build_head_graph(in_channels, num_anchors_per_cell, num_classes, stride), None, use_yv5_init, prior_probability)
 
     def forward(self, x: torch.Tensor) -> DetectionHeadResult:
         t = self._run([x])[0][0]                  # [B, A, h, w, 5 + nc]: the reference's 'b (a p) h w -> b a h w p' views

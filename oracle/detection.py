@@ -139,13 +139,13 @@ class LossOut(NamedTuple):                # type_defs.py:28-31
     classification: torch.Tensor
 
 
-def level_losses(box, obj, cls, a: Assigned, balance: float, pos_weight=None, iou_kind="ciou"):
+def level_losses(box, obj, cls, a: Assigned, balance: float, pos_weight=None, iou_kind="ciou", iou_eps: float = 1e-7):
     """loss.py:65-164 for one level; returns (box_mean, obj_scaled, cls_mean, iou)."""
     idx = (a.samples, a.anchors_idx, a.grid_y, a.grid_x)
     p = box[idx]
     pxy = p[:, :2].sigmoid() * 2 - 0.5
     pwh = (p[:, 2:4].sigmoid() * 2) ** 2 * a.anchors
-    iou = iou_family(_to_xyxy(torch.cat((pxy, pwh), 1)), _to_xyxy(a.gt_boxes), iou_kind).squeeze()
+    iou = iou_family(_to_xyxy(torch.cat((pxy, pwh), 1)), _to_xyxy(a.gt_boxes), iou_kind, iou_eps).squeeze()
     l_box = (1 - iou).mean()
     tobj = torch.zeros_like(obj).squeeze(-1)
     tobj[idx] = iou.clamp(0).type(tobj.dtype)            # NOT detached (loss.py:113-118)
@@ -158,12 +158,12 @@ def level_losses(box, obj, cls, a: Assigned, balance: float, pos_weight=None, io
 
 
 def yolo_loss(img_w: int, img_h: int, net_out, targets: Sequence[Target],
-              pos_weight=None, iou_kind="ciou") -> LossOut:
+              pos_weight=None, iou_kind="ciou", iou_eps: float = 1e-7) -> LossOut:
     """Yolov5Loss.forward (loss.py:166-248)."""
     asg = assign(img_w, img_h, targets)
     lb = lo = lc = 0.0
     for head, a, bal in zip(net_out, asg, OBJ_BALANCE):
-        b, o, c, _ = level_losses(head.box, head.obj, head.cls, a, bal, pos_weight, iou_kind)
+        b, o, c, _ = level_losses(head.box, head.obj, head.cls, a, bal, pos_weight, iou_kind, iou_eps)
         lb, lo, lc = lb + b, lo + o, lc + c
     nc = net_out[0].cls.shape[-1]
     return LossOut(LAMBDA_BOX * lb, LAMBDA_OBJ * (img_w / 640) ** 2 * lo, LAMBDA_CLS * (nc / 80) * lc)

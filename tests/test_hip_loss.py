@@ -79,6 +79,37 @@ def test_loss_fwd_bwd(golden, case):
             assert err <= 2e-5 * scale + 1e-9, (case, lvl, nm, err, scale)
 
 
+@pytest.mark.parametrize("kind,eps", [("iou", 1e-7), ("giou", 1e-7), ("diou", 1e-7), ("ciou", 1e-5)])
+def test_loss_with_other_iou_calculators_vs_oracle(kind, eps):
+    """Yolov5Loss takes whichever IoUCalculator it is constructed with (kod/lightning/experiments/yv5_baseline/loss.py:46-63,
+    96; the shipped config is ciou / 1e-7): IoU, GIoU, DIoU - and CIoU with another eps - through the same fused kernels
+    (csrc/loss.hip: the row's value and derivatives on dual numbers, csrc/kodhip_iou.h) against the fp32 oracle
+    (oracle/detection.py iou_family, pinned by iou.npz): losses and the gradients of all three heads, duplicate cells and
+    an empty image included."""
+    size, nc, B = 160, 10, 4
+    heads = synth.head_logits(B, size, nc, seed=21)
+    tg = synth.targets(B, size, nc, seed=21, nmin=3, nmax=12)
+    tg[2] = (tg[2][0][:0], tg[2][1][:0])                                  # an image without boxes
+    tg[3] = (torch.cat((tg[3][0], tg[3][0][:2])), torch.cat((tg[3][1], tg[3][1][:2])))   # duplicates -> same cells
+    raws = [torch.cat(h, -1).cuda().requires_grad_(True) for h in heads]
+    loss = Yolov5Loss(_assigner(), Yolov5LossParams.get_default(), IoUCalculator(kind, eps), None)
+    res = loss(FeatureShape(width=size, height=size), tuple((r[..., :4], r[..., 4:5], r[..., 5:]) for r in raws), _targets(tg))
+    total = B * (res.localization + res.objectness + res.classification)
+    total.backward()
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)            # (sequential index_put_: "last row wins" on duplicate cells, as on the device)
+    ref_heads = [[t.clone().requires_grad_(True) for t in h] for h in heads]
+    want = D.yolo_loss(size, size, NetOut(*[HeadOut(*h) for h in ref_heads]), [D.Target(b, l) for b, l in tg], iou_kind=kind, iou_eps=eps)
+    rt = D.train_step_total(want, B)
+    rt.backward()
+    torch.set_num_threads(nthreads)
+    got = np.array([res.localization.item(), res.objectness.item(), res.classification.item(), total.item()])
+    np.testing.assert_allclose(got, np.array([want.localization.item(), want.objectness.item(), want.classification.item(), rt.item()]), rtol=1e-5)
+    for h, r in zip(ref_heads, raws):
+        ref = torch.cat([t.grad for t in h], -1)
+        assert (r.grad.cpu() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item() + 1e-9, kind
+
+
 def test_loss_full_size_properties():
     """BASELINE shapes (B=64, 640 px): finite, reproducible bit for bit, gradient of obj only where expected."""
     B, size, nc = 64, 640, 10

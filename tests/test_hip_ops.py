@@ -398,8 +398,10 @@ def test_maxpool_chain_and_upsample():
     _close(nchw(dx), xr.grad + 1, 1e-2, 2e-2, "upsample grad (accumulate)")
 
 
-def test_sgd_nesterov():
-    from oracle import optim as O
+@pytest.mark.parametrize("nesterov", [True, False])
+def test_sgd_nesterov(nesterov):
+    """kodhip_sgd_nesterov against torch.optim.SGD itself (dampening = 0), Nesterov momentum (smart_sgd.yaml) and plain
+    momentum (hyper[10] = 0), three groups with their own lr / momentum / weight decay, three steps."""
     g = torch.Generator().manual_seed(2)
     n = 64 * 7
     p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g)
@@ -407,21 +409,21 @@ def test_sgd_nesterov():
     lr, mom, wd = (0.1, 0.01, 0.02), (0.8, 0.9, 0.937), (0.0, 5e-4, 0.0)
     pc, buf = p.clone().cuda(), torch.zeros(n, device="cuda")
     lib = _lib.lib()
-    import ctypes as C
-    refp, refb = p.clone(), [None] * 7
     grc, gidc = gr.cuda(), gid.cuda()
+    refs = [torch.nn.Parameter(p[64 * k:64 * k + 64].clone()) for k in range(7)]
+    opt = torch.optim.SGD([dict(params=[refs[k] for k in range(7) if int(gid[k]) == gi], lr=lr[gi], momentum=mom[gi],
+                                weight_decay=wd[gi]) for gi in range(3)], lr=0.1, nesterov=nesterov, momentum=0.5)
     for step in range(3):
-        hyper = torch.tensor([*lr, *mom, *wd, 0.5], dtype=torch.float32, device="cuda")
+        hyper = torch.tensor([*lr, *mom, *wd, 0.5, 1.0 if nesterov else 0.0, 0.0], dtype=torch.float32, device="cuda")
         _lib.check(lib.kodhip_sgd_nesterov(pc.data_ptr(), grc.data_ptr(), buf.data_ptr(), gidc.data_ptr(), n,
                                            hyper.data_ptr(), stream()), "sgd")
         for k in range(7):
-            gi = int(gid[k])
-            if gi > 2:
-                continue
-            sl = slice(64 * k, 64 * k + 64)
-            pk = refp[sl]
-            refb[k] = O.sgd_nesterov_step(pk, gr[sl] * 0.5, refb[k], lr[gi], mom[gi], wd[gi])
-    _close(pc.cpu(), refp, 1e-6, 1e-6, "sgd")
+            refs[k].grad = gr[64 * k:64 * k + 64].clone() * 0.5
+        opt.step()
+    got = pc.cpu()
+    for k in range(7):
+        want = p[64 * k:64 * k + 64] if int(gid[k]) > 2 else refs[k].detach()          # padding granules stay untouched
+        _close(got[64 * k:64 * k + 64], want, 1e-6, 1e-6, f"sgd granule {k}")
 
 
 @pytest.mark.parametrize("case", [

@@ -322,6 +322,16 @@ def test_submodule_classes_mirror_reference_parameters_and_refuse_cpu():
         sh, sr = hip.state_dict(), ref.state_dict()
         assert list(sh.keys()) == list(sr.keys()), type(hip).__name__
         assert all(torch.equal(a, b) for a, b in zip(sh.values(), sr.values())), type(hip).__name__
+    # use_yv5_init=False (heads/yolov5.py:65-73,113-121): objectness and class biases get the focal-loss prior
+    # - log((1 - p) / p) on top of torch's default initialisation instead of the YOLOv5 shifts; same random draws
+    import math
+    torch.manual_seed(11); plain = Yolov5Head(128, 3, 10, 16, prior_probability=0.02, use_yv5_init=False)
+    torch.manual_seed(11); yv5 = Yolov5Head(128, 3, 10, 16)
+    prior = -math.log((1 - 0.02) / 0.02)
+    sp, sy = plain.state_dict(), yv5.state_dict()
+    assert torch.equal(sp["box_head.conv.bias"], sy["box_head.conv.bias"]) and torch.equal(sp["cls_head.conv.weight"], sy["cls_head.conv.weight"])
+    assert torch.allclose(sp["obj_head.conv.bias"] - prior, sy["obj_head.conv.bias"] - math.log(8 / (640 / 16) ** 2), atol=1e-6)
+    assert torch.allclose(sp["cls_head.conv.bias"] - prior, sy["cls_head.conv.bias"] - math.log(0.6 / (10 - 0.99999)), atol=1e-6)
     with pytest.raises(RuntimeError, match="MI355X"):
         CSPLayer(64, 64)(torch.zeros(1, 64, 8, 8))
     with pytest.raises(ValueError):

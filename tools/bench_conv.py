@@ -16,6 +16,13 @@ LAYERS = {  # name: (Cin, H, W, Cout, k, s, p)
     "s2.last 128->128 1x1 @80": (128, 80, 80, 128, 1, 1, 0),
     "s4.last 512->512 1x1 @20": (512, 20, 20, 512, 1, 1, 0),
     "sppf.conv2 1024->512 1x1 @20": (1024, 20, 20, 512, 1, 1, 0),
+    # the deep pointwise layers (strides 16 / 32: M = 102 400 / 25 600 rows - one round of blocks, latency-bound K loops)
+    "s3.main 256->128 1x1 @40": (256, 40, 40, 128, 1, 1, 0),
+    "s3.conv1 128->128 1x1 @40": (128, 40, 40, 128, 1, 1, 0),
+    "s3.last 256->256 1x1 @40": (256, 40, 40, 256, 1, 1, 0),
+    "s4.main 512->256 1x1 @20": (512, 20, 20, 256, 1, 1, 0),
+    "s4.conv1 256->256 1x1 @20": (256, 20, 20, 256, 1, 1, 0),
+    "td0.main 512->128 1x1 @40": (512, 40, 40, 128, 1, 1, 0),
 }
 B = 64
 which = sys.argv[1:] or list(LAYERS)
