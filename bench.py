@@ -243,7 +243,14 @@ def profile_step(eng, step):
     """Per-kernel durations of every family: eager steps with HIP events around each launch on its launch stream (events
     cannot be read back from inside a replayed graph); weight gradients on the main stream for these steps so that the
     families do not overlap each other.  Returns the engine's raw profile list for family_table()."""
-    prof = profile_step(eng, step)
+    eng.profile = None
+    ov, eng.wgrad_overlap = eng.wgrad_overlap, False
+    step(); step()
+    eng.profile = []
+    step()
+    torch.cuda.synchronize()
+    prof = eng.profile
+    eng.profile, eng.wgrad_overlap = None, ov
     return prof
 
 
@@ -579,14 +586,7 @@ def main():
     # per-kernel durations of every family: one extra eager step with HIP events around each launch on its launch
     # stream, outside the timed region (events cannot be read back from inside a replayed graph); weight gradients
     # on the main stream for this step so that the families do not overlap each other
-    eng.profile = None
-    ov, eng.wgrad_overlap = eng.wgrad_overlap, False
-    step(); step()
-    eng.profile = []
-    step()
-    torch.cuda.synchronize()
-    prof = eng.profile
-    eng.profile, eng.wgrad_overlap = None, ov
+    prof = profile_step(eng, step)
     if eng.peer is not None and eng.peer.timed_out():
         raise SystemExit(f"[bench rank {rank}] a SyncBN peer exchange gave up waiting for another rank: the run is invalid")
     per_rank = [round(B * args.steps / dt, 1)]
