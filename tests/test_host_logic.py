@@ -84,8 +84,10 @@ def test_iou_calculator_contract():
         assert IoUCalculator(IoUType(kind), 1e-6).fn is fn                          # iou.py:254-261
     with pytest.raises(RuntimeError):          # no CPU fallback: the op is HIP only
         IoUCalculator(IoUType.giou)(torch.zeros(2, 4), torch.zeros(2, 4))
-    with pytest.raises(NotImplementedError):   # the fused loss kernel is CIoU / 1e-7 only
-        Yolov5Loss(None, Yolov5LossParams.get_default(), IoUCalculator("giou"), None)
+    # the loss takes any member of the family (kod/lightning/experiments/yv5_baseline/loss.py:46-63) and hands kind / eps to the kernel
+    assert Yolov5Loss(None, Yolov5LossParams.get_default(), IoUCalculator("giou", 1e-5), None).iou_kind == 1
+    full = Yolov5Loss(None, Yolov5LossParams.get_default(), IoUCalculator(IoUType.ciou, 1e-7), None)
+    assert (full.iou_kind, full.iou_eps) == (3, 1e-7)
 
 
 def test_device_pipeline_host_math_matches_golden(golden):
