@@ -601,13 +601,20 @@ def main():
     if not args.no_loop and not args.autograd and graph is not None:
         mix_p = args.loop_mixup if args.loop_mixup is not None else (0.1 if world > 1 else 0.0)      # configs[2]: "mosaic+mixup"
         barrier()
-        loop = loop_leg(net, loss_fn, B, S, nc, device, args.loop_steps, mixup_prob=mix_p, producer=not args.loop_in_process, rank=rank)
+        try:            # (a leg that fails is reported as its error, the measured line stands - like the extra legs below)
+            loop = loop_leg(net, loss_fn, B, S, nc, device, args.loop_steps, mixup_prob=mix_p, producer=not args.loop_in_process, rank=rank)
+        except Exception as e:          # noqa: BLE001
+            loop = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize()
         if dist is not None:
             lts = [None] * world
-            dist.all_gather_object(lts, loop["ms_per_step"])
-            loop["per_rank_ms_per_step"] = lts
-            loop["ms_per_step"] = max(lts)
-            loop["value"] = round(world * B / (max(lts) * 1e-3), 1)
+            dist.all_gather_object(lts, loop.get("ms_per_step"))
+            if all(t is not None for t in lts):
+                loop["per_rank_ms_per_step"] = lts
+                loop["ms_per_step"] = max(lts)
+                loop["value"] = round(world * B / (max(lts) * 1e-3), 1)
+            elif "error" not in loop:
+                loop = {"error": "the loop leg failed on another rank", "per_rank_ms_per_step": lts}
     # further legs of the default single-GPU run (each reported beside `value`, none inside the timed region; a leg that
     # fails is reported as its error, the line itself stands): the validation loop and the yv5m scale
     extra = {}

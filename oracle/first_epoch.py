@@ -65,12 +65,19 @@ def evaluate(cfg, net, val):
     return map_eval.report(map_eval.accumulate(per_image, cfg["nc"]))
 
 
-def run_cpu(cfg=CONFIG, emulate_bf16: bool = False, log=None):
+def run_cpu(cfg=CONFIG, emulate_bf16: bool = False, log=None, ulp: int = -1):
+    """ulp >= 0: element `ulp` of the stem's weight starts one fp32 ulp away from the seeded value - a perturbation far
+    below any rounding of the step, enough to give another draw of the chaotic first-epoch trajectory (the thread-count
+    trick of main() / extra() has only eight settings on this machine)."""
     S, B, nc, seed = cfg["S"], cfg["B"], cfg["nc"], cfg["seed"]
     train = synth.coco_zipf_like(cfg["n_train"], S, cfg["data_seed"], nc)
     val = synth.coco_zipf_like(cfg["n_val"], S, cfg["data_seed"] + 1, nc)
     torch.manual_seed(seed)
     net = OracleYolov5(3, nc, cfg["widen"], cfg["deepen"]).train()
+    if ulp >= 0:
+        with torch.no_grad():
+            w = next(net.parameters()).view(-1)
+            w[ulp] = torch.nextafter(w[ulp], w[ulp] + 1)
     if emulate_bf16:
         from . import bf16_emul
         net = bf16_emul.emulate(net)
@@ -153,5 +160,29 @@ def extra():
     print(f"wrote {out}: {len(samples)} samples")
 
 
+def extra2():
+    """`python -m oracle.first_epoch --extra2`: round 4 - more draws of BOTH CPU trainers (bf16-storage emulation first: the
+    HIP-vs-CPU comparison that matters rested on five of them), each from initial weights one fp32 ulp away in one element."""
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "first_epoch.npz")
+    log = lambda s: print(s, file=sys.stderr, flush=True)
+    keys = ("map", "map30", "map50", "map75", "map90")
+    res = dict(np.load(out))
+    tags = [str(t) for t in res["map_sample_tags"]]
+    samples = [row for row in res["map_cpu_samples"]]
+    torch.set_num_threads(os.cpu_count() or 1)
+    plan = [(f"bf16emu_u{k}", True, k) for k in range(1, 8)] + [(f"fp32_u{k}", False, k) for k in range(1, 6)]
+    for tag, emu, k in plan:
+        if tag in tags:
+            continue
+        r = run_cpu(CONFIG, emu, log, ulp=k)
+        log(f"{tag}: { {kk: round(r['report'][kk], 4) for kk in keys} }")
+        tags.append(tag)
+        samples.append(np.array([r["report"][kk] for kk in keys]))
+        res["map_cpu_samples"] = np.stack(samples)
+        res["map_sample_tags"] = np.array(tags)
+        np.savez_compressed(out, **res)               # after every run: a stopped job keeps what it has
+    print(f"wrote {out}: {len(samples)} samples")
+
+
 if __name__ == "__main__":
-    extra() if "--extra" in sys.argv else main()
+    extra2() if "--extra2" in sys.argv else (extra() if "--extra" in sys.argv else main())

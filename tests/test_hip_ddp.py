@@ -246,6 +246,9 @@ def test_bench_self_launch_runs_the_collective_path():
     assert "RCCL" in cfg["collectives"] and "overlapped with backward" in cfg["collectives"], cfg
     assert d["engine_options"]["comm_overlap"] is True and d["engine_options"]["force_collectives"] is True
     assert abs(sum(f["share_of_step"] for f in d["families"]) - 1.0) < 0.02
+    # the training-loop leg runs on the collective path too (every rank with its own producer process, mixup on: configs[2])
+    assert d["loop"]["value"] > 0 and "producer process" in d["loop"]["workload"] and "mixup p=0.1" not in d["loop"]["workload"]
+    assert d["loop"]["per_rank_ms_per_step"] == [d["loop"]["ms_per_step"]]
 
 
 @pytest.mark.parametrize("ranks,batch,size", [(2, 4, 256), (4, 2, 128)])
