@@ -418,7 +418,7 @@ def family_table(prof):
     share_of_step = family time / sum of all families' times of that SAME eager one-stream step (shares sum to 1; the
     replayed step is shorter than that sum because its families overlap)."""
     fam = {}
-    for name, e0, e1, nb in prof:
+    for name, e0, e1, nb, *_ in prof:
         f = fam.setdefault(name, [0, 0.0, 0.0])
         f[0] += 1
         f[1] += e0.elapsed_time(e1)

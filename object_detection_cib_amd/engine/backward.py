@@ -103,7 +103,7 @@ class BackwardMixin:
                 chk(lib.kodhip_conv_wgrad_partial(*args[:3], *args[4:-3], sid), name + ".wgrad")
             else:
                 chk(lib.kodhip_conv_wgrad(*args, sid), name + ".wgrad")
-            self._t1(e0, "wgrad", nbytes, stream_obj)
+            self._t1(e0, "wgrad", nbytes, stream_obj, name=name)
 
         def flush_wgrads():
             """call after the main stream's next kernel has been launched"""
@@ -244,7 +244,7 @@ class BackwardMixin:
                     chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
                                                       aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
                                                       st.bpart.data_ptr(), st.M, C_, s), u.name)
-                    self._t1(e0, "bn_bwd_reduce", 4.0 * st.M * C_)
+                    self._t1(e0, "bn_bwd_reduce", 4.0 * st.M * C_, name=u.name)
             e0 = self._t0()
             if sync and self.peer is not None:
                 for u in group:
@@ -255,7 +255,7 @@ class BackwardMixin:
                                                                gp + 4 * st.g_off, gp + 4 * st.b_off, st.coef.data_ptr(), C_,
                                                                1 if st.fused_red else 0, self.peer.view_ptr(),
                                                                self.peer_slots[(u.name, "b")], s), u.name)
-                self._t1(e0, "bn_bwd_coeffs", sum(8.0 * u.cout * self.ustate[u.name].T2 for u in group))
+                self._t1(e0, "bn_bwd_coeffs", sum(8.0 * u.cout * self.ustate[u.name].T2 for u in group), name="+".join(u.name for u in group))
                 return
             if sync:
                 for u in group:
@@ -287,7 +287,7 @@ class BackwardMixin:
                     chk(lib.kodhip_bn_bwd_coeffs_partials(st.bpart.data_ptr(), st.T2, float(st.M), pa + 4 * st.g_off,
                                                           aff + 8 * C_, aff + 12 * C_, gp + 4 * st.g_off,
                                                           gp + 4 * st.b_off, st.coef.data_ptr(), C_, rawm, s), u.name)
-            self._t1(e0, "bn_bwd_coeffs", sum(8.0 * u.cout * self.ustate[u.name].T2 for u in group))
+            self._t1(e0, "bn_bwd_coeffs", sum(8.0 * u.cout * self.ustate[u.name].T2 for u in group), name="+".join(u.name for u in group))
 
         # (with every collective on the main stream - KODHIP_COMM_OVERLAP=0, RCCL SyncBN - the head chains stay there too)
         heads_side = (wg is not None and defer and self.branch_overlap and self.profile is None and
@@ -332,7 +332,7 @@ class BackwardMixin:
                                           B, hs["H"], hs["W"], src.buf.C, src.coff, hu.cin,
                                           self.head_npad, 1, 1, 1, 1, 0, 0, hs["Kdp"], self.head_npad, 0,
                                           acc | fm, fptr, hs_), hu.name + ".dgrad")
-                self._t1(e0, "dgrad", 2.0 * hs["M"] * (self.head_npad + hu.cin))
+                self._t1(e0, "dgrad", 2.0 * hs["M"] * (self.head_npad + hu.cin), name=hu.name)
                 if side:
                     ev = torch.cuda.Event()
                     ev.record(hstream)
@@ -413,7 +413,7 @@ class BackwardMixin:
                 e0 = self._t0()
                 chk(lib.kodhip_stem_bwd_fused(*fargs, self.stem_part.data_ptr(), gp + 4 * st.w_off,
                                               B, st.H, st.W, C_, 1.0, s), u.name + ".bwd_fused")
-                self._t1(e0, "wgrad", nb)
+                self._t1(e0, "wgrad", nb, name=u.name)
                 self._flush_wgrads()
                 self._join_main()          # a gradient bucket on the weight-gradient stream must see this gradient
                 return
@@ -428,7 +428,7 @@ class BackwardMixin:
                                          self._ptr(res, True) if res else None,
                                          res.buf.C if res else 0, res.coff if res else 0,
                                          racc, st.M, C_, s), u.name)
-        self._t1(e0, "bn_silu_bwd_apply", (6.0 + ((4.0 if racc else 2.0) if res else 0.0)) * st.M * C_)
+        self._t1(e0, "bn_silu_bwd_apply", (6.0 + ((4.0 if racc else 2.0) if res else 0.0)) * st.M * C_, name=u.name)
         self._fork_point()
         # st.raw now holds dY
         if u.stem:
@@ -471,7 +471,7 @@ class BackwardMixin:
                 fn = lib.kodhip_conv_dgrad if st.segs is None else lib.kodhip_conv_dgrad_bnred
                 chk(fn(st.raw.data_ptr(), dp + 2 * st.d_off, self._ptr(u.src, True),
                        *geo, st.Kdp, st.raw_ld, 0, acc_src, fptr, *fz, s), u.name + ".dgrad")
-            self._t1(e0, "dgrad" if st.segs is None else "dgrad+bn_reduce", nb)
+            self._t1(e0, "dgrad" if st.segs is None else "dgrad+bn_reduce", nb, name=u.name + ("+" + partner.name if dgrad == "dual" else ""))
         if dgrad == "dual" and dual_w:
             ps = self.ustate[partner.name]
             self._wg_hold[0] = False

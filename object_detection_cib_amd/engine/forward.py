@@ -37,12 +37,12 @@ class ForwardMixin:
         e.record(stream) if stream is not None else e.record()
         return e
 
-    def _t1(self, e0, family: str, nbytes: float, stream=None):
+    def _t1(self, e0, family: str, nbytes: float, stream=None, name: str = ""):
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record(stream) if stream is not None else e1.record()
-        self.profile.append((family, e0, e1, nbytes))
+        self.profile.append((family, e0, e1, nbytes, name))          # name: the unit(s) the launch belongs to (tools/layer_table.py)
 
     def _stamp(self, name: str, stream=None):
         """(debug) device time stamp `name` on `stream` (a torch stream; default: the current one)"""
@@ -142,7 +142,7 @@ class ForwardMixin:
                                         st.stats.data_ptr(), *geo, st.raw_ld, 0, s), u.name)
             cin_true = 3 if u.stem else u.cin
             in_px = B * H * W if u.stem else B * st.H * st.W
-            self._t1(e0, "conv_fwd", 2 * (in_px * cin_true + st.M * C_))
+            self._t1(e0, "conv_fwd", 2 * (in_px * cin_true + st.M * C_), name=u.name)
 
         def pair_stage(mu: ConvUnit, su: ConvUnit, s=s):
             """A CSP layer's main_conv + short_conv (same input): one convolution with N = 2 * mid columns, one launch for
@@ -221,7 +221,7 @@ class ForwardMixin:
                     chk(lib.kodhip_bn_finalize(st.sums.data_ptr(), float(st.M) * self.world_size, pa + 4 * st.g_off,
                                                pa + 4 * st.b_off, rm + 4 * st.rs_off, rv + 4 * st.rs_off, BN_MOMENTUM,
                                                BN_EPS, aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
-            self._t1(e0, "bn_finalize", sum(8.0 * u.cout * self.ustate[u.name].T for u in group))
+            self._t1(e0, "bn_finalize", sum(8.0 * u.cout * self.ustate[u.name].T for u in group), name="+".join(u.name for u in group))
 
         def apply_stage(u: ConvUnit, s=s):
             st, C_ = self.ustate[u.name], u.cout
@@ -233,7 +233,7 @@ class ForwardMixin:
                                          self._ptr(res) if res else None, res.buf.C if res else 0,
                                          res.coff if res else 0,
                                          self._ptr(u.dst), u.dst.buf.C, u.dst.coff, st.M, C_, s), u.name)
-            self._t1(e0, "bn_silu_apply", (6.0 if res else 4.0) * st.M * C_)
+            self._t1(e0, "bn_silu_apply", (6.0 if res else 4.0) * st.M * C_, name=u.name)
 
         # A CSP layer's short_conv (conv -> statistics -> apply) depends only on the layer input and is needed only by
         # last_conv: it runs on a side stream next to main_conv and the blocks, where it fills the chip while the main

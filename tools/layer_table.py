@@ -1,56 +1,70 @@
-"""Per-layer conv timing table from a rocprofv3 kernel trace of bench.py --no-graph (last full step)."""
-import csv, glob, sys
-sys.path.insert(0, '.')
-from object_detection_cib_amd.engine.graph import build_graph
-d = sys.argv[1]
-tr = list(csv.DictReader(open((glob.glob(d + '/*/*kernel_trace.csv') + glob.glob(d + '/*kernel_trace.csv'))[0])))
-tr.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(tr) if 'nchw_to_nhwc4' in r['Kernel_Name']]
-step = tr[idx[-2]:idx[-1]]
-dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-g = build_graph(3, 10, 0.5, 0.33)
-units = [op.unit for op in g.ops if op.kind == 'conv']
-B = 64
-isk = lambda r, s: s in r['Kernel_Name']
-import re
-def mode(r):
-    m = re.search(r'conv_igemm(?:_x4)?_kernel<\d+, \d+, \d+, \d+, (\d), ', r['Kernel_Name'])
-    if m:
-        return int(m.group(1))
-    m = re.search(r'conv_igemm_row3_kernel<\d+, \d+, \d+, (\d)>', r['Kernel_Name'])
-    return int(m.group(1)) if m else -1
-fw = [r for r in step if mode(r) == 0]
-dg = [r for r in step if mode(r) in (1, 3)]
-wg = [r for r in step if isk(r, 'conv_wgrad')]
-# backward per unit in reverse order; the three heads come first (one dgrad + one wgrad each)
-ru = list(reversed(units))
-dmap, wmap = {}, {}
-dpos, wpos = 3, 3
-dual_shorts = {u.sibling.name for u in units if u.sibling is not None}     # their dX comes from the main_conv's launch
-for u in ru:
-    if not u.stem and u.name not in dual_shorts:
-        dmap[u.name] = dur(dg[dpos]); dpos += 1
-    wmap[u.name] = dur(wg[wpos]); wpos += 1
-tot = [0, 0, 0]
-for i, u in enumerate(units):
-    st = u.dst.stride; Ho = 640 // st; M = B * Ho * Ho
-    cin = 3 if u.stem else u.cin; k = 6 if u.stem else u.k
-    Min = B * (640 // (1 if u.stem else u.src.stride)) ** 2
-    byts = 2 * (Min * cin + M * u.cout); fl = 2 * M * u.cout * cin * k * k
-    f = dur(fw[i]); tot[0] += f
-    line = "%-44s %4d %4d %d%d %7d | %6.1f %5.0f %4.0f" % (u.name[-44:], cin, u.cout, k, u.s, M, f, byts / f / 1e3, fl / f / 1e6)
-    if u.name in dmap:
-        dd = dmap[u.name]; tot[1] += dd; line += " | %6.1f %5.0f %4.0f" % (dd, byts / dd / 1e3, fl / dd / 1e6)
-    else:
-        line += " |    -     -    -  "
-    w = wmap[u.name]; tot[2] += w; line += " | %6.1f %5.0f %4.0f" % (w, byts / w / 1e3, fl / w / 1e6)
-    print(line)
-print("totals fwd/dgrad/wgrad us", [round(t) for t in tot])
-fam = {}
-for r in step:
-    n = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').replace('_ZN12_GLOBAL__N_1', '')
-    key = n.split('(')[0][:48]
-    fam.setdefault(key, [0, 0.0]); fam[key][0] += 1; fam[key][1] += dur(r)
-print("step kernel time %.2f ms" % (sum(v[1] for v in fam.values()) / 1e3))
-for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:60]:
-    print("   %8.1f us  x%-4d %s" % (t, c, k))
+"""Per-unit timing table of one eager training step (bench.py's event-timed profile, one stream, families not overlapping):
+for every conv unit its forward conv / statistics finalize / apply, BatchNorm-backward coefficients / apply, data gradient,
+weight gradient (+ slab reduction), with the algorithmic GB/s and TF/s of the three convolution passes and the share of the
+step spent per stride level.  usage (GPU box): python tools/layer_table.py [yv5s|yv5m] > profiles/<tag>_layer_table.txt"""
+import sys
+import torch
+sys.path.insert(0, ".")
+from bench import build, synth_batch, VARIANTS, profile_step
+from object_detection_cib_amd.core.types import FeatureShape
+
+variant = sys.argv[1] if len(sys.argv) > 1 else "yv5s"
+B, S, nc = 64, 640, 10
+dev = torch.device("cuda", 0)
+widen, deepen = VARIANTS[variant]
+net, loss_fn = build(nc, dev, widen=widen, deepen=deepen)
+eng = net.engine()
+x, targets = synth_batch(B, S, nc, 2023, dev)
+shape = FeatureShape(width=S, height=S)
+eng.sgd_step((0.1, 1e-4, 1e-4), (0.8,) * 3, (0.0, 5e-4, 0.0), 1.0)
+params = list(net.parameters())
+
+
+def step():
+    for p in params:
+        p.grad = None
+    net.train_step(x, loss_fn, shape, targets, float(B))
+    eng.wait_grads()
+    eng.sgd_step_device()
+
+
+prof = profile_step(eng, step)
+per = {}                       # unit name -> {family: us}
+for fam, e0, e1, nb, name in prof:
+    us = 1e3 * e0.elapsed_time(e1)
+    for n in (name.split("+") if name else ["?"]):
+        # a launch shared by two units (dual data / weight gradient, pair coefficients) is booked to the first, flagged on the second
+        per.setdefault(n, {})
+    first = name.split("+")[0] if name else "?"
+    per[first][fam] = per[first].get(fam, 0.0) + us
+    for other in name.split("+")[1:]:
+        per[other].setdefault("shared_with", first)
+units = [op.unit for op in eng.g.ops if op.kind == "conv"]
+print(f"# {variant}, B={B}, {S} px, one eager step on one stream (event-timed; the weight gradients' time includes their slab reductions)")
+print("# us per launch; GB/s = algorithmic bytes 2*(M_in*Cin + M*Cout) / time, TF = 2*M*Cout*Cin*k*k / time; '=' the launch is shared with the unit named at the end")
+print("%-46s %4s %4s %2s %8s | %6s %5s %4s | %5s %6s | %6s %6s | %6s %5s %4s | %6s %5s %4s" % (
+    "unit", "cin", "cout", "ks", "M", "fwd", "GB/s", "TF", "fin", "apply", "coeff", "bapply", "dgrad", "GB/s", "TF", "wgrad", "GB/s", "TF"))
+by_stride, tot = {}, 0.0
+for u in units:
+    st = eng.ustate[u.name]
+    cin = 3 if u.stem else u.cin
+    k = 6 if u.stem else u.k
+    Min = B * (S // (1 if u.stem else u.src.stride)) ** 2
+    byts, fl = 2.0 * (Min * cin + st.M * u.cout), 2.0 * st.M * u.cout * cin * k * k
+    d = per.get(u.name, {})
+    g = lambda f: d.get(f, 0.0)
+    dg = g("dgrad") + g("dgrad+bn_reduce")
+    cell = lambda us: ("%6.1f %5.0f %4.0f" % (us, byts / us / 1e3, fl / us / 1e6)) if us > 0 else ("%6s %5s %4s" % ("=", "", ""))
+    row_us = sum(v for kk, v in d.items() if kk != "shared_with")
+    stride = u.dst.stride
+    by_stride[stride] = by_stride.get(stride, 0.0) + row_us
+    tot += row_us
+    print("%-46s %4d %4d %d%d %8d | %s | %5.1f %6.1f | %6.1f %6.1f | %s | %s%s" % (
+        u.name[-46:], cin, u.cout, k, u.s, st.M, cell(g("conv_fwd")), g("bn_finalize"), g("bn_silu_apply"),
+        g("bn_bwd_coeffs") + g("bn_bwd_reduce"), g("bn_silu_bwd_apply"), cell(dg), cell(g("wgrad")),
+        ("   = " + d["shared_with"][-30:]) if "shared_with" in d else ""))
+other = sum(1e3 * e0.elapsed_time(e1) for fam, e0, e1, nb, name in prof if not name or name.split("+")[0] not in {u.name for u in units})
+print("# time per output stride of the units (us; conv units only, heads / pools / loss / optimizer = %.0f us beside them):" % other)
+for stv in sorted(by_stride):
+    print("#   stride %2d: %7.0f us  %4.1f %%" % (stv, by_stride[stv], 100.0 * by_stride[stv] / tot))
+print("#   total    : %7.0f us" % tot)
