@@ -66,9 +66,11 @@ def evaluate(cfg, net, val):
 
 
 def run_cpu(cfg=CONFIG, emulate_bf16: bool = False, log=None, ulp: int = -1):
-    """ulp >= 0: element `ulp` of the stem's weight starts one fp32 ulp away from the seeded value - a perturbation far
-    below any rounding of the step, enough to give another draw of the chaotic first-epoch trajectory (the thread-count
-    trick of main() / extra() has only eight settings on this machine)."""
+    """ulp >= 0: element `ulp` of the stem's weight starts one ulp away from the seeded value - one fp32 ulp for the fp32
+    trainer, one BF16 ulp (2^-8 relative) for the bf16-storage emulation, which rounds the weight to bf16 before it is used
+    (an fp32 ulp vanishes there: seven such runs reproduced the unperturbed one digit for digit) - a perturbation of one of
+    the network's 7 M weights at the level of the storage rounding itself, enough to give another draw of the chaotic
+    first-epoch trajectory (the thread-count trick of main() / extra() has only eight settings on this machine)."""
     S, B, nc, seed = cfg["S"], cfg["B"], cfg["nc"], cfg["seed"]
     train = synth.coco_zipf_like(cfg["n_train"], S, cfg["data_seed"], nc)
     val = synth.coco_zipf_like(cfg["n_val"], S, cfg["data_seed"] + 1, nc)
@@ -77,7 +79,7 @@ def run_cpu(cfg=CONFIG, emulate_bf16: bool = False, log=None, ulp: int = -1):
     if ulp >= 0:
         with torch.no_grad():
             w = next(net.parameters()).view(-1)
-            w[ulp] = torch.nextafter(w[ulp], w[ulp] + 1)
+            w[ulp] = w[ulp] * (1.0 + 2.0 ** -8) if emulate_bf16 else torch.nextafter(w[ulp], w[ulp] + 1)
     if emulate_bf16:
         from . import bf16_emul
         net = bf16_emul.emulate(net)

@@ -1,6 +1,8 @@
 """HIP side of tests/test_hip_training.py::test_first_epoch_map_vs_cpu_trainer as a script: prints the epoch's loss
-fifths and mAP (used to sample the run-to-run spread under summation-order switches such as KODHIP_FORCE_BM=128)."""
-import random, sys
+fifths and mAP (used to sample the run-to-run spread under summation-order switches such as KODHIP_FORCE_BM=128).
+KODHIP_FE_ULP=k: element k of the stem's weight starts one bf16 ulp (2^-8 relative) away from the seeded value - the
+perturbation oracle/first_epoch.py --extra2 gives the CPU trainer's bf16-storage emulation: another draw of the trajectory."""
+import os, random, sys
 import numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from oracle import first_epoch as FE, synth
@@ -15,6 +17,12 @@ val = synth.coco_zipf_like(cfg["n_val"], S, cfg["data_seed"] + 1, nc)
 pipe = DeviceTrainPipeline([c[0] for c in train], [c[1] for c in train], [c[2] for c in train], S, "cuda", rng_seed=51)
 exp = _experiment(cfg["widen"], cfg["deepen"], nc, seed)
 exp.val_nms_conf_threshold, exp.val_nms_iou_threshold = cfg["conf_thres"], cfg["nms_thres"]
+ulp = int(os.environ.get("KODHIP_FE_ULP", "-1"))
+if ulp >= 0:
+    with torch.no_grad():
+        w = next(exp.net.parameters()).view(-1)
+        w[ulp] = w[ulp] * (1.0 + 2.0 ** -8)
+    exp.net.engine().mark_params_changed()
 order = FE.epoch_order(cfg)
 n_batches = len(order) // B
 random.seed(seed); np.random.seed(seed)
