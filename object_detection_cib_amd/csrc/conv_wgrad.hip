@@ -1084,7 +1084,11 @@ Row3Cfg row3_cfg(int N, int Cin, int KH, int KW, int SH, int SW, int PH, int PW)
   if (mode < 0) { const char* e = getenv("KODHIP_WGRAD_ROW3"); mode = e ? atoi(e) : 1; }
   Row3Cfg c = {false, 0, 0, 0, 0};
   if (!mode || KH != 3 || KW != 3 || SH != 1 || SW != 1 || PH != 1 || PW != 1 || Cin % 32 != 0 || N % 8 != 0) return c;
-  if (mode == 1 && !(N <= 32 || Cin >= 256)) return c;
+  // mode 1 (default): where the form measured faster than the generic split-K kernel IN THE STEP: narrow outputs (N <= 32) and
+  // Cin >= 256 as long as the nine-tap output tile stays small (N <= 256: 256 -> 256 @20 79 vs 94 us; yv5m's 384 -> 384 @20
+  // 256 vs 198 us - round 3's rule took the form there).  (96 -> 96 @80 gains alone, 174 vs 197 us, and loses in the yv5m step:
+  // 2 220 vs 2 232 img/s - its larger slabs cost the co-running main chain more than the kernel saves.)
+  if (mode == 1 && !(N <= 32 || (Cin >= 256 && N <= 256))) return c;
   c.on = true;
   if (N <= 32) { c.wn = 1; c.rn = 1; }
   else if (N <= 64) { c.wn = 1; c.rn = 2; }
@@ -1141,7 +1145,9 @@ static int wgrad_rows_per_split_geo(long M, int N, int Cin, int KH, int KW, int 
   const Row3Cfg c = row3_cfg(N, Cin, KH, KW, SH, SW, PH, PW);
   if (!c.on || x_bytes >= (1l << 32) - 64 || dy_bytes >= (1l << 32) - 64) return wgrad_rows_per_split(M, N, Kp);
   const int tiles = cdiv(N, c.tnb) * cdiv(Cin, c.wc * 32);
-  const int slots = 3072 / (c.wn * 3 * c.wc);          // resident blocks: 1024 (3 waves), 512 (6), 256 (12)
+  static int wave_slots = 0;                            // KODHIP_WGRAD_ROW3_SLOTS: resident-wave target (A/B knob; default 3072)
+  if (!wave_slots) { const char* e = getenv("KODHIP_WGRAD_ROW3_SLOTS"); wave_slots = e ? atoi(e) : 3072; if (wave_slots < 96) wave_slots = 3072; }
+  const int slots = wave_slots / (c.wn * 3 * c.wc);    // resident blocks: 1024 (3 waves), 512 (6), 256 (12)
   int sp = slots / tiles;
   if (sp < 1) sp = 1;
   const long maxs = (M + 255) / 256;

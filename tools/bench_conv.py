@@ -23,6 +23,12 @@ LAYERS = {  # name: (Cin, H, W, Cout, k, s, p)
     "s4.main 512->256 1x1 @20": (512, 20, 20, 256, 1, 1, 0),
     "s4.conv1 256->256 1x1 @20": (256, 20, 20, 256, 1, 1, 0),
     "td0.main 512->128 1x1 @40": (512, 40, 40, 128, 1, 1, 0),
+    # yv5m widths (BASELINE configs[4]): the 3x3 layers whose weight gradients are 2.2 - 2.9 x their forward
+    "m.s3.b.conv2 192->192 3x3 @40": (192, 40, 40, 192, 3, 1, 1),
+    "m.s4.b.conv2 384->384 3x3 @20": (384, 20, 20, 384, 3, 1, 1),
+    "m.s2.b.conv2 96->96 3x3 @80": (96, 80, 80, 96, 3, 1, 1),
+    "m.s1.b.conv2 48->48 3x3 @160": (48, 160, 160, 48, 3, 1, 1),
+    "m.s4.conv 384->768 3x3s2 @40": (384, 40, 40, 768, 3, 2, 1),
 }
 B = 64
 which = sys.argv[1:] or list(LAYERS)
@@ -51,7 +57,8 @@ for name in which:
     flops = 2.0 * M * Cout * Cin * k * k
     byts = 2.0 * (B * H * W * Cin + M * Cout)
     line = f"{name:32s}"
-    for fn in (fwd, dgrad, wgrad):
+    import os
+    for fn in ((wgrad,) if os.environ.get("BENCH_CONV_ONLY") == "wgrad" else (fwd, dgrad, wgrad)):
         for _ in range(3): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
