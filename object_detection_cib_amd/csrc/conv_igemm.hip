@@ -1179,11 +1179,15 @@ Plan make_plan(long M, int N, int K, bool fast, bool row3 = false) {
   static int force_bn = -1, force_bm = -1;
   if (force_bn < 0) { const char* e = getenv("KODHIP_FORCE_BN"); force_bn = e ? atoi(e) : 0; }
   if (force_bm < 0) { const char* e = getenv("KODHIP_FORCE_BM"); force_bm = e ? atoi(e) : 0; }
-  const int widest = (N >= 128) ? 128 : (N > 32 ? 64 : 32);
+  // 64 < N < 128 (yv5m's 96): one 128-column tile (three quarters used) stages every pixel tile once, two 64-column tiles twice
+  static int wide96 = -1;                  // KODHIP_PLAN_WIDE96=0: A/B knob
+  if (wide96 < 0) { const char* e = getenv("KODHIP_PLAN_WIDE96"); wide96 = e ? atoi(e) : 1; }
+  const int widest = (N >= 128 || (wide96 && N > 64)) ? 128 : (N > 32 ? 64 : 32);
   const bool can256 = fast && widest >= 64 && M >= 256 * 64;       // 256 x 128 and 256 x 64 tiles
   const int bm = !row3 && can256 && (force_bm ? force_bm == 256 : K >= 512) ? 256 : 128;
   Plan best = {};
   double best_cost = 1e30;
+  // (128 < N <= 192 as three 64-column tiles instead of two 128-column ones: 3x3 + 5 %, stride-2 forward - 39 %, 1x1 - 10 %: not taken)
   for (int bn = widest; bn >= 32 && bn >= widest / 2; bn >>= 1) {
     if (bm == 256 && bn != widest) continue;
     if (force_bn && force_bn <= widest && bn != force_bn) continue;

@@ -1112,6 +1112,12 @@ int launch_row3(WgradArgs a, hipStream_t stream) {
 
 void tile_shape(int N, int Kp, int* tn, int* tk) {
   *tn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  // yv5m widths: N = 192 as three 64-row tiles (all used) instead of two 128-row tiles (a quarter idle); KODHIP_WGRAD_TN192: A/B knob
+  // (measured, profiles/r04_convbench_yv5m_tiles.txt: 192 -> 192 3x3 @40 234 -> 191 us, 96 -> 192 s2 431 -> 337, 384 -> 192 1x1 49 -> 34)
+  // (N = 96 as three 32-row tiles instead of one 128-row tile: 198 -> 296 us, not taken)
+  static int tn192 = -1;
+  if (tn192 < 0) { const char* e = getenv("KODHIP_WGRAD_TN192"); tn192 = e ? atoi(e) : 64; }
+  if (N > 128 && N <= 192 && tn192 == 64) *tn = 64;
   *tk = Kp > 64 ? 128 : (Kp > 32 ? 64 : 32);
   // narrow outputs: let one block cover all of K so dY is streamed once
   if (*tn == 32 && (Kp == 160 || Kp == 288)) *tk = Kp;

@@ -29,6 +29,12 @@ LAYERS = {  # name: (Cin, H, W, Cout, k, s, p)
     "m.s2.b.conv2 96->96 3x3 @80": (96, 80, 80, 96, 3, 1, 1),
     "m.s1.b.conv2 48->48 3x3 @160": (48, 160, 160, 48, 3, 1, 1),
     "m.s4.conv 384->768 3x3s2 @40": (384, 40, 40, 768, 3, 2, 1),
+    "m.s1.conv 48->96 3x3s2 @320": (48, 320, 320, 96, 3, 2, 1),
+    "m.s1.last 96->96 1x1 @160": (96, 160, 160, 96, 1, 1, 0),
+    "m.s2.main 192->96 1x1 @80": (192, 80, 80, 96, 1, 1, 0),
+    "m.s2.conv 96->192 3x3s2 @160": (96, 160, 160, 192, 3, 2, 1),
+    "m.s3.main 384->192 1x1 @40": (384, 40, 40, 192, 1, 1, 0),
+    "m.s3.conv1 192->192 1x1 @40": (192, 40, 40, 192, 1, 1, 0),
 }
 B = 64
 which = sys.argv[1:] or list(LAYERS)
@@ -58,7 +64,8 @@ for name in which:
     byts = 2.0 * (B * H * W * Cin + M * Cout)
     line = f"{name:32s}"
     import os
-    for fn in ((wgrad,) if os.environ.get("BENCH_CONV_ONLY") == "wgrad" else (fwd, dgrad, wgrad)):
+    only = os.environ.get("BENCH_CONV_ONLY")
+    for fn in ((wgrad,) if only == "wgrad" else ((fwd, dgrad) if only == "fd" else (fwd, dgrad, wgrad))):
         for _ in range(3): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
