@@ -31,7 +31,33 @@ struct WgradArgs {
   // half take their dY from dy2.  n_half = 0: one layer
   const bf16_t* dy2;
   int n_half;
+  int linear_map;                    // block -> (tile, split) without the split-per-XCD banding (wg_map)
 };
+
+// block -> (tile, split).  Default: the blocks of one split sit on ONE XCD (bid & 7), so the input rows a split streams are
+// fetched from HBM once for all of its n / k tiles.  That banding idles XCDs when the split count is small and not a multiple
+// of 8 - yv5m's 384 -> 768 stride-2 layer has 162 tiles and 3 splits: five of eight XCDs had nothing to do (555 us; 333 with six
+// splits) - so layers with few splits (deep layers: their operands live in the caches anyway) take a linear map, which deals
+// every split's tiles round-robin over the XCDs.  The slabs are indexed by split either way: results do not depend on the map.
+__device__ __forceinline__ bool wg_map(const WgradArgs& a, int bid, int tiles, int& tile, int& split) {
+  if (a.linear_map) {
+    if (bid >= tiles * a.splits) return false;
+    split = bid % a.splits;
+    tile = bid / a.splits;
+    return true;
+  }
+  const int j = bid >> 3;
+  tile = j % tiles;
+  split = (j / tiles) * 8 + (bid & 7);
+  return split < a.splits;
+}
+__host__ inline int wg_grid(WgradArgs& a) {
+  const int tiles = a.tiles_n * a.tiles_k;
+  static int mode = -1;               // KODHIP_WGRAD_LINEAR=0: A/B knob
+  if (mode < 0) { const char* e = getenv("KODHIP_WGRAD_LINEAR"); mode = e ? atoi(e) : 1; }
+  a.linear_map = (mode && a.splits % 8 != 0 && a.splits < 64) ? 1 : 0;
+  return a.linear_map ? tiles * a.splits : cdiv(a.splits, 8) * 8 * tiles;
+}
 
 __host__ __device__ constexpr int row_bytes(int T) { return (T * 2) % 128 == 0 ? T * 2 + 64 : T * 2; }
 
@@ -55,12 +81,9 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_kernel(WgradArgs a) {
   const int wn = wave / WK, wk = wave % WK;
 
   const int bid = blockIdx.x;
-  const int xcd = bid & 7;
-  const int j = bid >> 3;
   const int tiles = a.tiles_n * a.tiles_k;
-  const int tile = j % tiles;
-  const int split = (j / tiles) * 8 + xcd;
-  if (split >= a.splits) return;
+  int tile, split;
+  if (!wg_map(a, bid, tiles, tile, split)) return;
   const int n0 = (tile % a.tiles_n) * TNB;
   const int k0 = (tile / a.tiles_n) * TKB;
   const int m_begin = split * a.m_per_split;
@@ -249,12 +272,9 @@ __global__ __launch_bounds__(64 * WN * WK) void conv_wgrad_dma_kernel(WgradArgs 
   const int wn = wave / WK, wk = wave % WK;
 
   const int bid = blockIdx.x;
-  const int xcd = bid & 7;
-  const int j = bid >> 3;
   const int tiles = a.tiles_n * a.tiles_k;
-  const int tile = j % tiles;
-  const int split = (j / tiles) * 8 + xcd;
-  if (split >= a.splits) return;
+  int tile, split;
+  if (!wg_map(a, bid, tiles, tile, split)) return;
   // slab rows n0 .. of this block; dY columns ny0 .. of its layer (dual form: the second half of the n tiles reads dy2)
   const int nt = tile % a.tiles_n;
   const bool half2 = a.n_half && nt >= (a.tiles_n >> 1);
@@ -512,12 +532,9 @@ __global__ __launch_bounds__(64 * WN * 3 * WC) void conv_wgrad_row3_kernel(Wgrad
   const int wc = wave % WC, kh = (wave / WC) % 3, wn = wave / (3 * WC);
 
   const int bid = blockIdx.x;
-  const int xcd = bid & 7;
-  const int j = bid >> 3;
   const int tiles = a.tiles_n * a.tiles_k;
-  const int tile = j % tiles;
-  const int split = (j / tiles) * 8 + xcd;
-  if (split >= a.splits) return;
+  int tile, split;
+  if (!wg_map(a, bid, tiles, tile, split)) return;
   const int n0 = (tile % a.tiles_n) * TNB;
   const int c0 = (tile / a.tiles_n) * (WC * 32);
   const int m_begin = split * a.m_per_split;
@@ -854,7 +871,7 @@ int launch_cfg(WgradArgs a, hipStream_t stream) {
   constexpr int TNB = WN * RN * 32, TKB = WK * RK * 32;
   a.tiles_n = a.n_half ? 2 * cdiv(a.n_half, TNB) : cdiv(a.N, TNB);
   a.tiles_k = cdiv(a.Kp, TKB);
-  int grid = cdiv(a.splits, 8) * 8 * a.tiles_n * a.tiles_k;
+  int grid = wg_grid(a);
   // LDS-DMA ring by default: +4-5 % on the whole training step over the register-staged kernel (in the network the
   // operands come from HBM and the deeper prefetch pays; back-to-back microbenchmarks with L2-hot operands show
   // mixed results for the 3x3 layers because an LDS-DMA piece costs 60+ issue cycles).  KODHIP_WGRAD_DMA=none
@@ -1104,7 +1121,7 @@ int launch_row3(WgradArgs a, hipStream_t stream) {
   // (4 resident) and the widest 6-wave stage
   constexpr int NST = (WN * 3 * WC == 3 || (WN == 1 && RN == 2 && WC == 2)) ? 3 : 4;
   const long xb = (long)a.B * a.Hs * a.Ws * a.ldx * 2, yb = (long)a.M * a.ldy * 2;
-  const int grid = cdiv(a.splits, 8) * 8 * a.tiles_n * a.tiles_k;
+  const int grid = wg_grid(a);
   hipLaunchKernelGGL((conv_wgrad_row3_kernel<WN, RN, WC, NST>), dim3(grid), dim3(64 * WN * 3 * WC), 0, stream, a, (uint32_t)xb, (uint32_t)yb);
   KOD_LAUNCH_CHECK("conv_wgrad_row3");
   return KOD_OK;
