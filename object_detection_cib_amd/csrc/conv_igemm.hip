@@ -62,6 +62,8 @@ struct ConvArgs {
   int out_mul, out_off_y, out_off_x, out_H, out_W;   // PLAIN: output pixel (oy,ox) -> (oy*mul+off_y, ox*mul+off_x) of an out_H x out_W image
   int d2s_C;                   // PLAIN, folded stride-2 data gradient: output column n = class * d2s_C + channel, class (py,px)
                                // = (n / d2s_C) >> 1, & 1 is the pixel's parity offset (depth-to-space epilogue); 0 = off
+  int d2s_skip;                // folded form: column tiles that lie inside the py = 0 classes (n < 2 * d2s_C) stop after the
+                               // dy = 0 taps - the first half of the K steps; their other weights are zero by construction
   int head_A, head_P, head_nc;
   uint32_t magic_hp;           // HEAD: magic of head_P
   uint32_t magic_cin, magic_kw;
@@ -167,7 +169,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   for (int i = 0; i < 8; ++i) ssum[i] = ssq[i] = 0.f;
   float bn_run = 0.f;                        // MODE_PLAIN_BN: running sum of (channel tid>>1, statistic tid&1)
 
-  const int nk = STEM ? a.KH : (ROW3 ? 3 * (a.cin_step / BK) : (a.nk1 ? 2 * a.nk1 : a.Kp / BK));
+  int nk_steps = STEM ? a.KH : (ROW3 ? 3 * (a.cin_step / BK) : (a.nk1 ? 2 * a.nk1 : a.Kp / BK));
+  if constexpr ((MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) && FAST && !ROW3 && !STEM) {
+    // folded stride-2 data gradient (prep_dgrad_s2f): classes (0, px) meet only the taps dy = 0, K steps [0, nk / 2)
+    if (a.d2s_skip && n0 + BN <= 2 * a.d2s_C) nk_steps >>= 1;
+  }
+  const int nk = nk_steps;
   // FAST path (Cin % 32 == 0, unit tap stride, no K tail): operands come through raw buffer loads - the tap of a
   // K step is wave-uniform (scalar registers), invalid (padding) elements are fetched from an out-of-range offset
   // that the buffer unit returns as zeros, so a step costs ~10 VALU instead of ~110 and has no branches.
@@ -1175,14 +1182,15 @@ constexpr int MAX_STATS_SLOTS = 1024;
 // Tile shape: the widest channel tile that fits N (or the next narrower one when that removes a badly quantised
 // last round).  256-pixel tiles (8 waves, 3-stage ring) when the reduction is long enough to amortise their deeper
 // pipeline fill (measured on gfx950: 3x3 layers with N >= 128 gain 15-25 %, short-K 1x1 layers lose ~5 %).
-Plan make_plan(long M, int N, int K, bool fast, bool row3 = false) {
+Plan make_plan(long M, int N, int K, bool fast, bool row3 = false, int bn_cap = 0) {
   static int force_bn = -1, force_bm = -1;
   if (force_bn < 0) { const char* e = getenv("KODHIP_FORCE_BN"); force_bn = e ? atoi(e) : 0; }
   if (force_bm < 0) { const char* e = getenv("KODHIP_FORCE_BM"); force_bm = e ? atoi(e) : 0; }
   // 64 < N < 128 (yv5m's 96): one 128-column tile (three quarters used) stages every pixel tile once, two 64-column tiles twice
   static int wide96 = -1;                  // KODHIP_PLAN_WIDE96=0: A/B knob
   if (wide96 < 0) { const char* e = getenv("KODHIP_PLAN_WIDE96"); wide96 = e ? atoi(e) : 1; }
-  const int widest = (N >= 128 || (wide96 && N > 64)) ? 128 : (N > 32 ? 64 : 32);
+  int widest = (N >= 128 || (wide96 && N > 64)) ? 128 : (N > 32 ? 64 : 32);
+  if (bn_cap && widest > bn_cap) widest = bn_cap;
   const bool can256 = fast && widest >= 64 && M >= 256 * 64;       // 256 x 128 and 256 x 64 tiles
   const int bm = !row3 && can256 && (force_bm ? force_bm == 256 : K >= 512) ? 256 : 128;
   Plan best = {};
@@ -1224,11 +1232,20 @@ bool row3_eligible(const ConvArgs& a, bool fast) {
   return true;
 }
 
+// folded stride-2 data gradient: d2s_skip pays where the class boundary 2 * Cin falls on a tile boundary of the plan the
+// layer has anyway (Cin = 64: 170.7 -> 153.0 us); forcing 64-column tiles on Cin = 32 to get one costs more in
+// re-staging than the skipped taps save (236 -> 263 us), so no cap is applied (KODHIP_S2F_BN_CAP=64: the experiment)
+int fold_bn_cap(const ConvArgs& a) {
+  static int cap = -1;
+  if (cap < 0) { const char* e = getenv("KODHIP_S2F_BN_CAP"); cap = e ? atoi(e) : 0; }
+  return (cap && a.d2s_C != 0 && a.d2s_skip && 2 * a.d2s_C == cap) ? cap : 0;
+}
+
 Plan plan_conv(const ConvArgs& a, bool fast, bool& row3, int mode) {
   static int modes = -1;                 // KODHIP_ROW3_MODES: bit per MODE (debug: 1 = forward, 2 = dgrad, 8 = dgrad + BN reduction)
   if (modes < 0) { const char* e = getenv("KODHIP_ROW3_MODES"); modes = e ? atoi(e) : 0xF; }
   row3 = row3_eligible(a, fast) && ((modes >> mode) & 1);
-  return make_plan(a.M, a.N, a.nk1 ? 2 * a.K : a.K, fast, row3);
+  return make_plan(a.M, a.N, a.nk1 ? 2 * a.K : a.K, fast, row3, fold_bn_cap(a));
 }
 
 template <int MODE, bool F32ACC = false>
@@ -1504,6 +1521,8 @@ int prep_dgrad_s2f(ConvArgs& a, const void* dy, const void* w_fold, void* dx, in
   if (int rc2 = set_f32(a, accumulate, dx_f32)) return rc2;
   a.mul_h = 1; a.mul_w = 1; a.add_h = 0; a.add_w = 0; a.tap_sign = 1; a.sh_shift = 0; a.sw_shift = 0;
   a.out_mul = 2; a.out_off_y = 0; a.out_off_x = 0; a.out_H = H; a.out_W = W; a.d2s_C = Cin;
+  static const bool skip = !(getenv("KODHIP_S2F_SKIP") && getenv("KODHIP_S2F_SKIP")[0] == '0');      // A/B knob
+  a.d2s_skip = skip ? 1 : 0;
   KOD_CHECK_ARG(fast_eligible(a), "conv_dgrad_s2f: needs the LDS-DMA path (operands within a 32-bit buffer range)");
   return KOD_OK;
 }
@@ -1564,7 +1583,7 @@ int kodhip_conv_dgrad_s2f_bnred_slots(int B, int H, int W, int Cin, int N, int l
   if (getenv("KODHIP_NO_BNRED")) return 0;
   ConvArgs a;
   if (prep_dgrad_s2f(a, fake, fake, (void*)fake, B, H, W, Cin, 0, Cin, N, ldy, 0, 0)) return 0;
-  return 4 * make_plan(a.M, a.N, a.K, true).groups_m;
+  return 4 * make_plan(a.M, a.N, a.K, true, false, fold_bn_cap(a)).groups_m;
 }
 
 int kodhip_conv_dgrad_s2f_bnred(const void* dy, const void* w_fold, void* dx,
