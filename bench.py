@@ -298,14 +298,34 @@ def variant_leg(variant, B, S, nc, device, steps=12):
             "families": fams}
 
 
-def self_launch(args) -> int:
-    """`python bench.py --gpus N` without a launcher: start N FRESH child processes (one per GPU, the env contract of
-    torch.distributed.run) from this parent, which never touches a GPU, wait for them with a deadline, and hand rank
-    0's JSON line through.  A rank that fails - or the job hanging past --timeout - ends every child and the exit code
-    is non-zero: a scaling run never waits forever and never reports a partial job."""
+# What a multi-rank job falls back to when it dies or hangs (a crash inside hipGraph capture or a collective is not an
+# exception a rank could catch): the same job again with eager launches, then with every collective in stream order
+# through RCCL.  The JSON line records the attempt that produced it (config.attempt / config.fallback).
+ATTEMPTS = (
+    {},
+    {"KODHIP_BENCH_NO_GRAPH": "1"},
+    {"KODHIP_BENCH_NO_GRAPH": "1", "KODHIP_SYNCBN": "rccl", "KODHIP_COMM_OVERLAP": "0"},
+)
+
+
+def _stop_group(proc):
     import signal
+    if proc.poll() is None:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)       # exactly the process group this process started
+        except ProcessLookupError:
+            pass
+    try:
+        proc.wait(10)
+    except Exception:
+        pass
+
+
+def _launch_once(args, attempt: int, timeout: float):
+    """One attempt of `python bench.py --gpus N` without a launcher: N fresh ranks, a deadline, rank 0's JSON line."""
     import socket
     import subprocess
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -314,27 +334,12 @@ def self_launch(args) -> int:
     argv = [a for a in sys.argv[1:]]
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KODHIP_BENCH_LAUNCHER="self")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KODHIP_BENCH_LAUNCHER="self",
+                   KODHIP_BENCH_ATTEMPT=str(attempt), **ATTEMPTS[attempt])
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
-
-    def stop_all():
-        for q in procs:
-            if q.poll() is None:
-                try:
-                    os.killpg(q.pid, signal.SIGKILL)       # exactly the process group this parent started
-                except ProcessLookupError:
-                    pass
-        for q in procs:
-            try:
-                q.wait(10)
-            except subprocess.TimeoutExpired:
-                pass
-
-    deadline = time.monotonic() + args.timeout
-    out0 = b""
-    import threading
+    deadline = time.monotonic() + timeout
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
@@ -348,25 +353,110 @@ def self_launch(args) -> int:
         if all(c == 0 for c in codes):
             break
         if time.monotonic() > deadline:
-            failed = f"no result after {args.timeout:.0f} s (hang?): " + ", ".join(
+            failed = f"no result after {timeout:.0f} s (hang?): " + ", ".join(
                 f"rank {r} {'running' if c is None else 'done'}" for r, c in enumerate(codes))
             break
         time.sleep(0.2)
     if failed:
-        stop_all()
-        print(f"bench.py --gpus {n}: {failed}; all ranks stopped", file=sys.stderr, flush=True)
-        return 124 if "hang" in failed else 1
+        for q in procs:
+            _stop_group(q)
+        return None, failed
     reader.join(10)
-    out0 = chunks[0] if chunks else b""
     line = None
-    for ln in out0.decode(errors="replace").splitlines():
+    for ln in (chunks[0] if chunks else b"").decode(errors="replace").splitlines():
         if ln.startswith("{"):
             line = ln
-    if line is None:
-        print(f"bench.py --gpus {n}: rank 0 printed no JSON line", file=sys.stderr, flush=True)
-        return 1
-    print(line, flush=True)
-    return 0
+    return line, (None if line else "rank 0 printed no JSON line")
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N FRESH child processes (one per GPU, the env contract of
+    torch.distributed.run) from this parent, which never touches a GPU, wait for them with a deadline, and hand rank
+    0's JSON line through.  A rank that fails - or the job hanging past --timeout - ends every child; the job is then
+    tried again down the ATTEMPTS ladder, and only when the last attempt fails is the exit code non-zero: a scaling
+    run never waits forever and never reports a partial job."""
+    n = args.gpus
+    why = None
+    for k in range(len(ATTEMPTS) if n > 1 else 1):
+        line, why = _launch_once(args, k, args.timeout if k == 0 else min(args.timeout, 600.0))
+        if line is not None:
+            print(line, flush=True)
+            return 0
+        print(f"bench.py --gpus {n}: attempt {k} ({ATTEMPTS[k] or 'as asked'}): {why}; all ranks stopped", file=sys.stderr, flush=True)
+    return 124 if why and "hang" in why else 1
+
+
+def supervise_rank(args) -> int:
+    """Under an external launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`) every rank this
+    launcher starts becomes a supervisor that never touches a GPU: it runs the real rank as a child process, tells the
+    other supervisors how that went through a TCP store of its own (MASTER_PORT + 23 on MASTER_ADDR, rank 0 hosting), and
+    when any rank of the job died or the job hangs, all supervisors stop their children and start the next attempt of
+    the ATTEMPTS ladder together.  Rank 0's child inherits stdout, so the job's one JSON line passes straight through.
+    Any failure to set the supervision up (port taken, store unreachable) returns None: the rank then runs in-process,
+    exactly as without supervision."""
+    import datetime
+    import subprocess
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    try:
+        from torch.distributed import TCPStore
+        host, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533")) + 23
+        store = TCPStore(host, port, world, rank == 0, timeout=datetime.timedelta(seconds=60), wait_for_workers=False)
+        store.set(f"sup/hello/{rank}", "1")
+        store.wait([f"sup/hello/{r}" for r in range(world)], datetime.timedelta(seconds=60))
+    except Exception as e:      # no supervision: run as a plain rank
+        print(f"[bench rank {rank}] no supervision ({type(e).__name__}: {e}); running in-process", file=sys.stderr, flush=True)
+        return None
+    argv = [a for a in sys.argv[1:]]
+    last = 1
+    for k in range(len(ATTEMPTS)):
+        env = dict(os.environ, KODHIP_BENCH_LAUNCHER="external", KODHIP_BENCH_ATTEMPT=str(k), **ATTEMPTS[k])
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True)
+        deadline = time.monotonic() + (args.timeout if k == 0 else min(args.timeout, 600.0)) + 30.0
+        mine, verdict = None, None
+        while verdict is None:
+            if mine is None and child.poll() is not None:
+                mine = child.returncode
+                try:
+                    store.set(f"sup/{k}/code/{rank}", str(mine))
+                except Exception:
+                    return mine
+            try:
+                codes = [store.get(f"sup/{k}/code/{r}").decode() if store.check([f"sup/{k}/code/{r}"]) else None for r in range(world)]
+            except Exception:       # the store's host (rank 0's supervisor) is gone: it only leaves after a verdict
+                return 0 if mine == 0 else (mine or 1)
+            if any(c not in (None, "0") for c in codes):
+                verdict = "failed"
+            elif all(c == "0" for c in codes):
+                verdict = "ok"
+            elif time.monotonic() > deadline:
+                try:
+                    store.set(f"sup/{k}/code/{rank}", "hang")    # every supervisor sees it on its next poll
+                except Exception:
+                    pass
+                verdict = "failed"
+            else:
+                time.sleep(0.2)
+        if verdict == "ok":
+            # the store lives in rank 0's supervisor: it leaves last
+            try:
+                store.set(f"sup/{k}/bye/{rank}", "1")
+                if rank == 0:
+                    store.wait([f"sup/{k}/bye/{r}" for r in range(world)], datetime.timedelta(seconds=60))
+            except Exception:
+                pass
+            return 0
+        _stop_group(child)
+        last = mine if mine not in (None, 0) else 1
+        if rank == 0:
+            print(f"bench.py --gpus {world}: attempt {k} ({ATTEMPTS[k] or 'as asked'}) failed "
+                  f"(rank codes {codes}); " + ("next attempt" if k + 1 < len(ATTEMPTS) else "giving up"), file=sys.stderr, flush=True)
+        # nobody starts attempt k + 1 before every rank's child of attempt k is gone (their GPU memory, their ports)
+        try:
+            store.set(f"sup/{k}/stopped/{rank}", "1")
+            store.wait([f"sup/{k}/stopped/{r}" for r in range(world)], datetime.timedelta(seconds=120))
+        except Exception:
+            return last
+    return last
 
 
 PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
@@ -462,6 +552,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    attempt = int(os.environ.get("KODHIP_BENCH_ATTEMPT", "0"))
+    # a rank started by an external launcher supervises the real rank (a child process) instead of being it - decided
+    # before anything touches a GPU (KODHIP_BENCH_SUPERVISE=0: plain rank, as in rounds 1-3)
+    if (world > 1 and "KODHIP_BENCH_LAUNCHER" not in os.environ and os.environ.get("KODHIP_BENCH_SUPERVISE", "1") != "0"):
+        rc = supervise_rank(args)
+        if rc is not None:
+            raise SystemExit(rc)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP hot path has no CPU fallback)")
     # KODHIP_BENCH_ONE_GPU=1: every rank on GPU 0 (rehearsal of the multi-rank control flow on a one-GPU box: RCCL wants one
@@ -481,7 +578,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         # control plane (rendezvous id, barriers, max-over-ranks of the clock) on gloo; every GPU collective of the
         # step goes through the engine's own RCCL communicator, enqueued on the step's streams and captured with it
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if attempt > 0 and os.environ.get("KODHIP_BENCH_LAUNCHER") == "external":
+            # a later attempt under the launcher's own store: a key space of its own (attempt 0's rendezvous keys are still there)
+            import datetime
+            agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+            base = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, (rank == 0) and not agent,
+                                 timeout=datetime.timedelta(seconds=300), multi_tenant=True)
+            dist.init_process_group("gloo", store=dist.PrefixStore(f"kodbench_attempt{attempt}", base), rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -532,6 +637,10 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = not args.no_graph and not (one_gpu and use_dist)      # (gloo collectives cannot be captured)
+    use_graph = use_graph and os.environ.get("KODHIP_BENCH_NO_GRAPH") != "1"      # the ATTEMPTS ladder's eager rungs
+    # test hook: the rank named here dies in attempt 0 (rehearsal of the ladder, tests/test_hip_ddp.py)
+    if attempt == 0 and os.environ.get("KODHIP_BENCH_TEST_DIE_RANK") == str(rank) and world > 1:
+        os._exit(3)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -648,7 +757,8 @@ def main():
                                        + (", RCCL gradient buckets " if eng.comm is not None else ", gradient buckets through torch.distributed ")
                                        + ("overlapped with backward on the weight-gradient stream (own communicator)"
                                           if eng.comm_buckets is not None else "in stream order")),
-                       "launcher": os.environ.get("KODHIP_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none")},
+                       "launcher": os.environ.get("KODHIP_BENCH_LAUNCHER", "external" if "WORLD_SIZE" in os.environ else "none"),
+                       "attempt": attempt, "fallback": ATTEMPTS[attempt] if attempt < len(ATTEMPTS) else None},
             "per_rank_images_per_sec": per_rank,
             "engine_options": eng.opt.as_dict(),
             "final_loss": final_loss,

@@ -459,3 +459,39 @@ def test_two_rank_ddp_syncbn_vs_fp32_oracle(tmp_path):
         a = torch.cat([got["state"][k].flatten() for k in sd_r if k.endswith(suffix)])
         b = torch.cat([sd_r[k].flatten() for k in sd_r if k.endswith(suffix)])
         assert rel(a, b) <= tol, (suffix, rel(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("die_rank", [None, 1])
+def test_bench_under_torch_distributed_run_and_attempt_ladder(die_rank):
+    """The driver's own N > 1 command - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` - on the one GPU of the test box (KODHIP_BENCH_ONE_GPU=1, two ranks):
+    the launcher's processes supervise, their children are the ranks (launcher's env contract, agent store rendezvous),
+    rank 0 prints the job's one line.  With a rank that dies in attempt 0 (test hook) every supervisor stops its child and
+    the job runs again on the next rung of bench.ATTEMPTS; the line then says which attempt produced it."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "KODHIP_BENCH_LAUNCHER", "KODHIP_BENCH_ATTEMPT")}
+    env["KODHIP_BENCH_ONE_GPU"] = "1"
+    if die_rank is not None:
+        env["KODHIP_BENCH_TEST_DIE_RANK"] = str(die_rank)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4", "--size", "256", "--no-cpu-baseline",
+                        "--timeout", "300"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["launcher"] == "external" and len(d["per_rank_images_per_sec"]) == 2
+    assert d["config"]["attempt"] == (0 if die_rank is None else 1)
+    if die_rank is not None:
+        assert "attempt 0" in r.stderr and d["config"]["fallback"] == {"KODHIP_BENCH_NO_GRAPH": "1"}
+    assert np.isfinite(d["final_loss"])

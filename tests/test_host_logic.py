@@ -391,3 +391,33 @@ def test_descriptor_producer_process_equals_in_process_protocol():
             small.next(timeout=60)
     finally:
         small.close()
+
+
+def test_bench_ranks_under_an_external_launcher_supervise_and_walk_the_ladder():
+    """What the driver's `python -m torch.distributed.run ... bench.py --gpus N` gives bench.py: N processes with RANK /
+    WORLD_SIZE / MASTER_* set.  Each becomes a supervisor (no GPU call) that runs the real rank as a child and agrees with
+    the others over its own TCP store; when a rank dies, all stop and the job is tried again down bench.ATTEMPTS (eager
+    launches, then every collective in stream order through RCCL).  Here (CPU container) every child fails at once - no
+    MI355X - so both supervisors must walk the whole ladder TOGETHER, stop, and exit non-zero without a JSON line."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = {k: v for k, v in os.environ.items() if k not in ("KODHIP_BENCH_LAUNCHER", "KODHIP_BENCH_ATTEMPT")}
+    procs = []
+    for r in range(2):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                                       "--batch", "2", "--size", "64", "--no-cpu-baseline", "--timeout", "120"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=root))
+    outs = [p.communicate(timeout=400) for p in procs]
+    assert all(p.returncode not in (0, None) for p in procs), [p.returncode for p in procs]
+    err0 = outs[0][1]
+    import bench
+    for k in range(len(bench.ATTEMPTS)):
+        assert f"attempt {k} " in err0, err0[-1500:]
+    assert "giving up" in err0
+    assert not [ln for o in outs for ln in o[0].splitlines() if ln.startswith("{")]
