@@ -298,6 +298,32 @@ def variant_leg(variant, B, S, nc, device, steps=12):
             "families": fams}
 
 
+def _beat(phase: str):
+    """Progress mark of a supervised rank (KODHIP_BENCH_HEARTBEAT = a file the supervisor watches): a job none of whose
+    ranks has reached a new phase for STALL_S seconds is hung - the supervisor need not wait for the whole --timeout."""
+    path = os.environ.get("KODHIP_BENCH_HEARTBEAT")
+    if path:
+        try:
+            with open(path, "a") as f:
+                f.write(f"{time.time():.1f} {phase}\n")
+        except OSError:
+            pass
+
+
+# longest silent phase of a healthy rank: a cold `import torch` + engine build, 1 - 2 minutes (KODHIP_BENCH_STALL_S: tests)
+STALL_S = float(os.environ.get("KODHIP_BENCH_STALL_S", "300"))
+
+
+def _last_beat(paths):
+    t = 0.0
+    for q in paths:
+        try:
+            t = max(t, os.path.getmtime(q))
+        except OSError:
+            pass
+    return t
+
+
 # What a multi-rank job falls back to when it dies or hangs (a crash inside hipGraph capture or a collective is not an
 # exception a rank could catch): the same job again with eager launches, then with every collective in stream order
 # through RCCL.  The JSON line records the attempt that produced it (config.attempt / config.fallback).
@@ -329,13 +355,17 @@ def _launch_once(args, attempt: int, timeout: float):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    import tempfile
     n = args.gpus
     procs = []
     argv = [a for a in sys.argv[1:]]
+    hb_dir = tempfile.mkdtemp(prefix="kodbench_hb_")
+    beats = [os.path.join(hb_dir, f"rank{r}") for r in range(n)]
+    t_start = time.time()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KODHIP_BENCH_LAUNCHER="self",
-                   KODHIP_BENCH_ATTEMPT=str(attempt), **ATTEMPTS[attempt])
+                   KODHIP_BENCH_ATTEMPT=str(attempt), KODHIP_BENCH_HEARTBEAT=beats[r], **ATTEMPTS[attempt])
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
@@ -352,11 +382,14 @@ def _launch_once(args, attempt: int, timeout: float):
             break
         if all(c == 0 for c in codes):
             break
-        if time.monotonic() > deadline:
-            failed = f"no result after {timeout:.0f} s (hang?): " + ", ".join(
+        stalled = time.time() - max(_last_beat(beats), t_start) > STALL_S
+        if time.monotonic() > deadline or stalled:
+            failed = (f"no rank made progress for {STALL_S:.0f} s (hang?): " if stalled else f"no result after {timeout:.0f} s (hang?): ") + ", ".join(
                 f"rank {r} {'running' if c is None else 'done'}" for r, c in enumerate(codes))
             break
         time.sleep(0.2)
+    import shutil
+    shutil.rmtree(hb_dir, ignore_errors=True)
     if failed:
         for q in procs:
             _stop_group(q)
@@ -396,6 +429,7 @@ def supervise_rank(args) -> int:
     exactly as without supervision."""
     import datetime
     import subprocess
+    import tempfile
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     try:
         from torch.distributed import TCPStore
@@ -409,8 +443,10 @@ def supervise_rank(args) -> int:
     argv = [a for a in sys.argv[1:]]
     last = 1
     for k in range(len(ATTEMPTS)):
-        env = dict(os.environ, KODHIP_BENCH_LAUNCHER="external", KODHIP_BENCH_ATTEMPT=str(k), **ATTEMPTS[k])
+        hb = os.path.join(tempfile.gettempdir(), f"kodbench_hb_{os.getpid()}_{k}")
+        env = dict(os.environ, KODHIP_BENCH_LAUNCHER="external", KODHIP_BENCH_ATTEMPT=str(k), KODHIP_BENCH_HEARTBEAT=hb, **ATTEMPTS[k])
         child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True)
+        t_start, t_pub = time.time(), 0.0
         deadline = time.monotonic() + (args.timeout if k == 0 else min(args.timeout, 600.0)) + 30.0
         mine, verdict = None, None
         while verdict is None:
@@ -421,9 +457,15 @@ def supervise_rank(args) -> int:
                 except Exception:
                     return mine
             try:
+                if time.time() - t_pub > 5.0:         # this rank's latest progress mark, for everybody's stall test
+                    t_pub = time.time()
+                    store.set(f"sup/{k}/beat/{rank}", repr(max(_last_beat([hb]), t_start)))
                 codes = [store.get(f"sup/{k}/code/{r}").decode() if store.check([f"sup/{k}/code/{r}"]) else None for r in range(world)]
+                seen = [float(store.get(f"sup/{k}/beat/{r}").decode()) if store.check([f"sup/{k}/beat/{r}"]) else time.time() for r in range(world)]
             except Exception:       # the store's host (rank 0's supervisor) is gone: it only leaves after a verdict
                 return 0 if mine == 0 else (mine or 1)
+            if time.time() - max(seen) > STALL_S + 10.0:      # (same clock: one node)
+                deadline = 0.0
             if any(c not in (None, "0") for c in codes):
                 verdict = "failed"
             elif all(c == "0" for c in codes):
@@ -561,6 +603,7 @@ def main():
             raise SystemExit(rc)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP hot path has no CPU fallback)")
+    _beat("start")
     # KODHIP_BENCH_ONE_GPU=1: every rank on GPU 0 (rehearsal of the multi-rank control flow on a one-GPU box: RCCL wants one
     # GPU per rank, so gradient buckets then go through the gloo group and the step runs eagerly; SyncBN still takes the
     # peer-buffer exchange, the ranks being processes of one node)
@@ -601,11 +644,13 @@ def main():
     widen, deepen = VARIANTS[args.variant]
     net, loss_fn = build(nc, device, widen=widen, deepen=deepen)
     algo_bytes, algo_flop = algorithmic_work(widen, deepen, nc, S)
+    _beat("network built")
     if args.variant == "yv5s" and S == 640:
         assert abs(algo_bytes - ALGO_BYTES_PER_IMG_BF16) < 1e-3 * ALGO_BYTES_PER_IMG_BF16 and abs(algo_flop - ALGO_FLOP_PER_IMG) < 1e-3 * ALGO_FLOP_PER_IMG
     eng = net.engine()
     if use_dist:
         net.configure_distributed(None, sync_batchnorm=not args.no_sync_bn, native_rccl=not one_gpu)
+        _beat("collectives configured")
     from object_detection_cib_amd.core.types import FeatureShape
     x, targets = synth_batch(B, S, nc, 2023 + rank, device)
     shape = FeatureShape(width=S, height=S)
@@ -641,6 +686,8 @@ def main():
     # test hook: the rank named here dies in attempt 0 (rehearsal of the ladder, tests/test_hip_ddp.py)
     if attempt == 0 and os.environ.get("KODHIP_BENCH_TEST_DIE_RANK") == str(rank) and world > 1:
         os._exit(3)
+    if attempt == 0 and os.environ.get("KODHIP_BENCH_TEST_HANG_RANK") == str(rank) and world > 1:
+        time.sleep(3600)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -648,6 +695,7 @@ def main():
             last = step()
     torch.cuda.current_stream().wait_stream(side)
     graph = None
+    _beat("warm-up steps done")
     launch_note = "eager"
     if use_graph:
         # the whole step (~650 launches, and for N>1 the RCCL all-reduces between them) becomes one hipGraph
@@ -683,6 +731,7 @@ def main():
                 last = step()
     barrier()
     t0 = time.perf_counter()
+    _beat("timed region begins")
     for _ in range(args.steps):
         if graph is not None:
             graph.replay()
@@ -690,6 +739,7 @@ def main():
             last = step()
     barrier()
     dt = time.perf_counter() - t0
+    _beat("timed region done")
     if eng.stamps_on:          # KODHIP_DEBUG_STAMPS=1: where the step's time goes, from device clock stamps
         stamp_report(eng, graph, step)
     # per-kernel durations of every family: one extra eager step with HIP events around each launch on its launch
@@ -706,6 +756,7 @@ def main():
         dt = max(dts)                              # the job is as fast as its slowest rank
     final_loss = float(last.item())
     loop = None
+    _beat("profile step done")
     # (with collectives in the step every rank runs the leg - its replays contain the same RCCL calls - fed by its own producer)
     if not args.no_loop and not args.autograd and graph is not None:
         mix_p = args.loop_mixup if args.loop_mixup is not None else (0.1 if world > 1 else 0.0)      # configs[2]: "mosaic+mixup"
@@ -727,6 +778,7 @@ def main():
     # further legs of the default single-GPU run (each reported beside `value`, none inside the timed region; a leg that
     # fails is reported as its error, the line itself stands): the validation loop and the yv5m scale
     extra = {}
+    _beat("loop leg done")
     if world == 1 and not use_dist and not (args.no_extra or args.no_loop) and not args.autograd and use_graph and args.variant == "yv5s":
         for name, fn in (("validation", lambda: validation_leg(net, loss_fn, B, S, nc, device)),
                          ("yv5m", lambda: variant_leg("yv5m", B, S, nc, device))):

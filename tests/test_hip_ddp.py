@@ -462,13 +462,14 @@ def test_two_rank_ddp_syncbn_vs_fp32_oracle(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("die_rank", [None, 1])
+@pytest.mark.parametrize("die_rank", [None, 1, "hang"])
 def test_bench_under_torch_distributed_run_and_attempt_ladder(die_rank):
     """The driver's own N > 1 command - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N ...` - on the one GPU of the test box (KODHIP_BENCH_ONE_GPU=1, two ranks):
     the launcher's processes supervise, their children are the ranks (launcher's env contract, agent store rendezvous),
     rank 0 prints the job's one line.  With a rank that dies in attempt 0 (test hook) every supervisor stops its child and
-    the job runs again on the next rung of bench.ATTEMPTS; the line then says which attempt produced it."""
+    the job runs again on the next rung of bench.ATTEMPTS; the line then says which attempt produced it.  The same when a
+    rank hangs: no rank reaches a new phase (heartbeat files, bench._beat) for STALL_S seconds."""
     import json
     import socket
     import subprocess
@@ -480,7 +481,9 @@ def test_bench_under_torch_distributed_run_and_attempt_ladder(die_rank):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                              "KODHIP_BENCH_LAUNCHER", "KODHIP_BENCH_ATTEMPT")}
     env["KODHIP_BENCH_ONE_GPU"] = "1"
-    if die_rank is not None:
+    if die_rank == "hang":          # rank 1 stops making progress: no rank reaches a new phase -> stall verdict, next attempt
+        env["KODHIP_BENCH_TEST_HANG_RANK"], env["KODHIP_BENCH_STALL_S"] = "1", "25"
+    elif die_rank is not None:
         env["KODHIP_BENCH_TEST_DIE_RANK"] = str(die_rank)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
