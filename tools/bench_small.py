@@ -1,0 +1,27 @@
+"""Micro-benchmark of the step's small kernels at their yv5s B=64 / 640 px shapes (SPPF pools, upsample): us per launch."""
+import sys, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from object_detection_cib_amd import _lib
+from hip_helpers import stream
+
+lib = _lib.lib()
+st = stream()
+
+
+def timed(fn, n=30):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+for name, (B, H, W, C) in {"sppf pool yv5s [64,20,20,256]": (64, 20, 20, 256), "sppf pool yv5m [64,20,20,384]": (64, 20, 20, 384)}.items():
+    buf = torch.randn(B, H, W, 4 * C, device="cuda").to(torch.bfloat16)
+    idx = torch.zeros((B, H, W, C), dtype=torch.uint8, device="cuda")
+    g = torch.randn(B, H, W, 4 * C, device="cuda").to(torch.bfloat16)
+    f = timed(lambda: _lib.check(lib.kodhip_maxpool5_fwd(buf.data_ptr(), 4 * C, 0, buf.data_ptr(), 4 * C, C, idx.data_ptr(), B, H, W, C, st)))
+    b = timed(lambda: _lib.check(lib.kodhip_maxpool5_bwd(g.data_ptr(), 4 * C, C, idx.data_ptr(), g.data_ptr(), 4 * C, 0, B, H, W, C, None, st)))
+    mb = B * H * W * C * 2 / 1e6
+    print(f"{name:34s} | fwd {f:6.1f} us ({(2 * mb + mb / 2) / f * 1e-3 * 1e3:6.0f} GB/s) | bwd {b:6.1f} us ({(3 * mb + mb / 2) / b:6.0f} GB/s)")
