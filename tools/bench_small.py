@@ -24,4 +24,4 @@ for name, (B, H, W, C) in {"sppf pool yv5s [64,20,20,256]": (64, 20, 20, 256), "
     f = timed(lambda: _lib.check(lib.kodhip_maxpool5_fwd(buf.data_ptr(), 4 * C, 0, buf.data_ptr(), 4 * C, C, idx.data_ptr(), B, H, W, C, st)))
     b = timed(lambda: _lib.check(lib.kodhip_maxpool5_bwd(g.data_ptr(), 4 * C, C, idx.data_ptr(), g.data_ptr(), 4 * C, 0, B, H, W, C, None, st)))
     mb = B * H * W * C * 2 / 1e6
-    print(f"{name:34s} | fwd {f:6.1f} us ({(2 * mb + mb / 2) / f * 1e-3 * 1e3:6.0f} GB/s) | bwd {b:6.1f} us ({(3 * mb + mb / 2) / b:6.0f} GB/s)")
+    print(f"{name:34s} | fwd {f:6.1f} us ({(2 * mb + mb / 2) / f * 1e3:6.0f} GB/s) | bwd {b:6.1f} us ({(3 * mb + mb / 2) / b * 1e3:6.0f} GB/s)")
