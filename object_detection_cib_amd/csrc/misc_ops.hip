@@ -116,75 +116,141 @@ __global__ void pack_weights_kernel(const float* master, bf16_t* fpack, bf16_t* 
 }
 
 // ------------------------------------------------------------------ SPPF max pool 5x5 s1 p2
-// One thread = PX consecutive output columns x 8 channels: the 5 x (PX + 4) input window is loaded once and shared
-// by the PX outputs (40 instead of 100 sixteen-byte loads per 4 outputs; the pool is L2-read-bound).  Argmax follows
-// torch's scan (row-major over the window, first maximum wins; a NaN replaces anything).
-constexpr int POOL_PX = 4;
+// These kernels are bound by vector-instruction issue, not by memory (13 MB per launch at 20 x 20: a wave64 instruction
+// takes its 16-lane SIMD four cycles, and comparing every (element, tap) pair in fp32 with torch's NaN rule cost ~6.4
+// instructions per pair: 41 us).  The forward kernel therefore works on integer KEYS:
+//   K = sortable(value) << 16 | (127 - (16 * row + column) in the thread's 8 x 8 input patch)   (0 for taps outside the image)
+// sortable(): bf16 bits h >= 0 -> h | 0x8000, h < 0 -> ~h, NaN -> 0xffff; an unsigned maximum over the window's keys is
+// then torch's scan (kod/nn/layers/sppf.py:46-50 -> F.max_pool2d: row-major over the window, the FIRST maximum wins - the
+// position field breaks ties towards the earlier tap - and a NaN beats every number).  One thread owns a 4 x 4 block of
+// outputs x 4 channels: an 8 x 8 patch is encoded once (not once per output row), the row maxima of a patch row are
+// shared by the four outputs of that row (10 instead of 16 maxima), the column pass works the same way, and value and
+// argmax fall out of the winning key.  Deviations from torch, all without numerical consequence: a window whose maximum
+// is a tie between +0 and -0 yields +0 (torch: whichever comes first); of several NaNs in a window the first is
+// reported (torch: the last); a NaN leaves as 0x7fff.
+// idx byte = dy * 16 + dx of the winning tap (dy, dx in 0..4), read by maxpool5_bwd_kernel.
+__device__ __forceinline__ uint32_t pool_key(const uint32_t x /* fp32 bits of the bf16 value */, const uint32_t code) {
+  // x >= 0: flip the top bit; x < 0: complement (arithmetic, no condition registers: the kernel is issue-bound)
+  int32_t sg = (int32_t)x >> 31;
+  asm volatile("" : "+v"(sg));                              // (or the compiler turns it back into compare + select)
+  const uint32_t t = (uint32_t)sg | 0x80000000u;
+  const uint32_t k = ((x ^ t) & 0xffff0000u) | code;
+  const float f = __uint_as_float(x);
+  return (f != f) ? (0xffff0000u | code) : k;
+}
 
-__global__ void maxpool5_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_t* y, int ldy, int ycoff,
+// window maxima of 5 over 8 keys -> 4 outputs (o = 0..3 covers k[o .. o + 4]), 10 maxima
+__device__ __forceinline__ void pool_max5of8(const uint32_t (&k)[8], uint32_t (&out)[4]) {
+  const uint32_t m34 = max(k[3], k[4]);
+  const uint32_t m234 = max(m34, k[2]), m345 = max(m34, k[5]);
+  const uint32_t m2345 = max(m234, k[5]);
+  out[0] = max(max(k[0], k[1]), m234);
+  out[1] = max(k[1], m2345);
+  out[2] = max(k[6], m2345);
+  out[3] = max(max(k[6], k[7]), m345);
+}
+
+__global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_t* y, int ldy, int ycoff,
                                     unsigned char* idx, int B, int H, int W, int C) {
-  const int CC = C >> 3;
-  const int WG = (W + POOL_PX - 1) / POOL_PX;
+  const int C4 = C >> 2;
+  const int WG = (W + 3) >> 2, HG = (H + 3) >> 2;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = (long)B * H * WG * CC;
+  const long total = (long)B * HG * WG * C4;
   if (i >= total) return;
-  int cc = (int)(i % CC);
-  long p = i / CC;
-  int gx = (int)(p % WG);
-  long q = p / WG;
-  int oy = (int)(q % H);
-  int b = (int)(q / H);
-  const int ox0 = gx * POOL_PX;
-  float best[POOL_PX][8];
-  unsigned char bi[POOL_PX][8];
+  const int c4 = (int)(i % C4);
+  long p = i / C4;
+  const int gx = (int)(p % WG);
+  p /= WG;
+  const int gy = (int)(p % HG);
+  const int b = (int)(p / HG);
+  const int ox0 = gx * 4, oy0 = gy * 4;
+  // patch column c <-> ix = ox0 - 2 + c, patch row r <-> iy = oy0 - 2 + r: clamped addresses, all-ones / zero masks
+  uint32_t cmask[8], rmask[8];
+  int cx[8], ry[8];
 #pragma unroll
-  for (int o = 0; o < POOL_PX; ++o)
+  for (int c = 0; c < 8; ++c) {
+    const int ix = ox0 - 2 + c, iy = oy0 - 2 + c;
+    cmask[c] = (ix >= 0 && ix < W) ? 0xffffffffu : 0u;
+    rmask[c] = (iy >= 0 && iy < H) ? 0xffffffffu : 0u;
+    cx[c] = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+    ry[c] = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+    asm volatile("" : "+v"(cmask[c]), "+v"(rmask[c]));      // plain AND masks (not selects on a condition register pair)
+  }
+  const bf16_t* xb = x + (long)b * H * W * ldx + xcoff + c4 * 4;
+  uint32_t hm[8][4][4];            // [patch row][output column][channel]: that row's maximum over the output's 5 columns
+  uint2 cur[8], nxt[8];
+  auto load_row = [&](const int r, uint2 (&dst)[8]) {
+    const bf16_t* row = xb + (long)ry[r] * W * ldx;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { best[o][e] = -INFINITY; bi[o][e] = 0; }
-  for (int dy = 0; dy < 5; ++dy) {
-    int iy = oy + dy - 2;
-    if (iy < 0 || iy >= H) continue;
-    bf16x8 col[POOL_PX + 4];
-    bool cok[POOL_PX + 4];
+    for (int c = 0; c < 8; ++c) dst[c] = *reinterpret_cast<const uint2*>(row + (long)cx[c] * ldx);
+  };
+  load_row(0, cur);
 #pragma unroll
-    for (int c = 0; c < POOL_PX + 4; ++c) {
-      int ix = ox0 + c - 2;
-      cok[c] = ix >= 0 && ix < W;
-      if (cok[c]) col[c] = *reinterpret_cast<const bf16x8*>(x + ((long)(b * H + iy) * W + ix) * ldx + xcoff + cc * 8);
+  for (int r = 0; r < 8; ++r) {
+    if (r + 1 < 8) load_row(r + 1, nxt);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t k[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t d = (e < 2) ? cur[c].x : cur[c].y;
+        const uint32_t xf = (e & 1) ? (d & 0xffff0000u) : (d << 16);
+        k[c] = pool_key(xf, (uint32_t)(127 - (r * 16 + c))) & cmask[c];
+      }
+      uint32_t o4[4];
+      pool_max5of8(k, o4);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) hm[r][o][e] = o4[o] & rmask[r];
     }
 #pragma unroll
-    for (int o = 0; o < POOL_PX; ++o)
-#pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
-        if (!cok[o + dx]) continue;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float f = (float)col[o + dx][e];
-          if (f > best[o][e] || f != f) { best[o][e] = f; bi[o][e] = (unsigned char)(dy * 5 + dx); }
-        }
-      }
+    for (int c = 0; c < 8; ++c) cur[c] = nxt[c];
   }
+  // column pass + decode + store
 #pragma unroll
-  for (int o = 0; o < POOL_PX; ++o) {
-    if (ox0 + o >= W) break;
-    const long op = (long)(b * H + oy) * W + ox0 + o;
-    bf16x8 v;
+  for (int o = 0; o < 4; ++o) {
+    uint32_t best[4][4];             // [output row][channel]
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)best[o][e];
-    *reinterpret_cast<bf16x8*>(y + op * ldy + ycoff + cc * 8) = v;
-    // the 8 argmax bytes leave as one 8-byte store (C % 8 == 0 keeps it aligned)
-    uint2 packed;
-    packed.x = (uint32_t)bi[o][0] | ((uint32_t)bi[o][1] << 8) | ((uint32_t)bi[o][2] << 16) | ((uint32_t)bi[o][3] << 24);
-    packed.y = (uint32_t)bi[o][4] | ((uint32_t)bi[o][5] << 8) | ((uint32_t)bi[o][6] << 16) | ((uint32_t)bi[o][7] << 24);
-    *reinterpret_cast<uint2*>(idx + op * C + cc * 8) = packed;
+    for (int e = 0; e < 4; ++e) {
+      uint32_t k[8], o4[4];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) k[r] = hm[r][o][e];
+      pool_max5of8(k, o4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) best[q][e] = o4[q];
+    }
+    if (ox0 + o >= W) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (oy0 + q >= H) continue;
+      uint32_t hv[4], ib = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t K = best[q][e];
+        // upper half back to bf16 bits: K >= 2^31 (h >= 0, or NaN -> 0x7fff): flip the top bit; else complement
+        const uint32_t t = (uint32_t)((int32_t)K >> 31) & 0x7fffffffu;
+        hv[e] = ~(K ^ t);
+        // position -> tap: patch position = 127 - (K & 127); minus the window's origin (q, o) = dy * 16 + dx
+        ib |= ((uint32_t)(127 - (q * 16 + o)) - (K & 127u)) << (8 * e);
+      }
+      const long op = (long)(b * H + oy0 + q) * W + ox0 + o;
+      uint2 v;
+      v.x = (hv[0] >> 16) | (hv[1] & 0xffff0000u);
+      v.y = (hv[2] >> 16) | (hv[3] & 0xffff0000u);
+      *reinterpret_cast<uint2*>(y + op * ldy + ycoff + c4 * 4) = v;
+      *reinterpret_cast<uint32_t*>(idx + op * C + c4 * 4) = ib;
+    }
   }
 }
 
-// dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic; same column sharing)
+// dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic): one thread = 4 consecutive input
+// columns x 8 channels, the 5 x 8 outputs whose windows reach them loaded once.  (A 4 x 4 x 4-channel block per thread with
+// one target code per output - the forward kernel's shape - needs fewer instructions per pair but 256 registers and
+// measured 57 us against this form's 34.)
+constexpr int POOL_BWD_PX = 4;
 __global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const unsigned char* idx,
                                     bf16_t* dx, int ldx, int xcoff, int B, int H, int W, int C, const float* dx32) {
   const int CC = C >> 3;
-  const int WG = (W + POOL_PX - 1) / POOL_PX;
+  const int WG = (W + POOL_BWD_PX - 1) / POOL_BWD_PX;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)B * H * WG * CC;
   if (i >= total) return;
@@ -194,10 +260,10 @@ __global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const 
   long q = p / WG;
   int iy = (int)(q % H);
   int b = (int)(q / H);
-  const int ix0 = gx * POOL_PX;
-  float acc[POOL_PX][8];
+  const int ix0 = gx * POOL_BWD_PX;
+  float acc[POOL_BWD_PX][8];
 #pragma unroll
-  for (int o = 0; o < POOL_PX; ++o) {
+  for (int o = 0; o < POOL_BWD_PX; ++o) {
     const bool in = ix0 + o < W;
     bf16x8 old = {};
     const long po = ((long)(b * H + iy) * W + ix0 + o) * ldx + xcoff + cc * 8;
@@ -210,17 +276,17 @@ __global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const 
     if (oy < 0 || oy >= H) continue;
     // output columns ox = ix - dxx + 2 for ix in [ix0, ix0 + PX), dxx in [0, 5): ox0 - 2 .. ox0 + PX + 1
 #pragma unroll
-    for (int c = 0; c < POOL_PX + 4; ++c) {
+    for (int c = 0; c < POOL_BWD_PX + 4; ++c) {
       const int ox = ix0 + c - 2;
       if (ox < 0 || ox >= W) continue;
       const long op = (long)(b * H + oy) * W + ox;
       const uint2 ib = *reinterpret_cast<const uint2*>(idx + op * C + cc * 8);     // 8 argmax bytes in one load
       const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + op * ldy + ycoff + cc * 8);
 #pragma unroll
-      for (int o = 0; o < POOL_PX; ++o) {
+      for (int o = 0; o < POOL_BWD_PX; ++o) {
         const int dxx = o - c + 4;         // ix = ix0 + o, ox = ix - dxx + 2  =>  dxx = ix - ox + 2
         if (dxx < 0 || dxx > 4) continue;
-        const uint32_t want = (uint32_t)(dyy * 5 + dxx);
+        const uint32_t want = (uint32_t)(dyy * 16 + dxx);      // the forward kernel's encoding
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const uint32_t byte = ((e < 4 ? ib.x : ib.y) >> (8 * (e & 3))) & 0xffu;
@@ -230,7 +296,7 @@ __global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const 
     }
   }
 #pragma unroll
-  for (int o = 0; o < POOL_PX; ++o) {
+  for (int o = 0; o < POOL_BWD_PX; ++o) {
     if (ix0 + o >= W) break;
     bf16x8 v;
 #pragma unroll
@@ -438,7 +504,7 @@ int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int
                         int B, int H, int W, int C, hipStream_t stream) {
   KOD_CHECK_ARG(x && y && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
                 "maxpool5_fwd: bad args");
-  long n = (long)B * H * ((W + POOL_PX - 1) / POOL_PX) * (C / 8);
+  long n = (long)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 4);      // a 4 x 4 block of outputs x 4 channels per thread
   hipLaunchKernelGGL(maxpool5_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, xcoff,
                      (bf16_t*)y, ldy, ycoff, (unsigned char*)idx, B, H, W, C);
   KOD_LAUNCH_CHECK("maxpool5_fwd");
@@ -451,7 +517,7 @@ int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, voi
                         int B, int H, int W, int C, const float* dx_f32, hipStream_t stream) {
   KOD_CHECK_ARG(dy && dx && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
                 "maxpool5_bwd: bad args");
-  long n = (long)B * H * ((W + POOL_PX - 1) / POOL_PX) * (C / 8);
+  long n = (long)B * H * ((W + POOL_BWD_PX - 1) / POOL_BWD_PX) * (C / 8);
   hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)dy, ldy, ycoff,
                      (const unsigned char*)idx, (bf16_t*)dx, ldx, xcoff, B, H, W, C, dx_f32);
   KOD_LAUNCH_CHECK("maxpool5_bwd");

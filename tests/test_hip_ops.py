@@ -119,6 +119,38 @@ def test_conv_dgrad_stride2_parity_classes(case, form):
         assert (got[:, :8] == 0).all() and (got[:, 8 + Cin:] == 0).all()
 
 
+@pytest.mark.parametrize("shape", [(1, 8, 1, 1), (2, 8, 3, 9), (1, 16, 5, 7), (2, 8, 20, 20), (1, 8, 6, 13)])
+def test_maxpool_ties_special_values_and_ragged_edges(shape):
+    """The key-based 5x5 pool (csrc/misc_ops.hip maxpool5_fwd_kernel) against torch's scan on inputs made of ties and
+    special values: small integers (most windows hold their maximum several times: the FIRST one in row-major window
+    order must get the gradient), +-inf, and one NaN per image (a NaN beats every number); maps whose sides are not
+    multiples of the 4 x 4 output block; integer-valued output gradients so that the routed sums are exact."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.randint(-3, 4, (B, C, H, W), generator=g).float()
+    x[torch.rand(x.shape, generator=g) < 0.02] = float("inf")
+    x[torch.rand(x.shape, generator=g) < 0.05] = float("-inf")
+    if H * W >= 9:
+        x[:, 0, H // 2, W // 2] = float("nan")
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 5, 1, 2)
+    dy = torch.randint(-4, 5, y.shape, generator=g).float()
+    y.backward(dy)
+    lib = _lib.lib()
+    xb = nhwc(bf(x))
+    yb = torch.zeros_like(xb)
+    idx = torch.zeros((B, H, W, C), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.kodhip_maxpool5_fwd(xb.data_ptr(), C, 0, yb.data_ptr(), C, 0, idx.data_ptr(), B, H, W, C, stream()), "pool")
+    got = nchw(yb)
+    ref = y.detach()
+    assert torch.equal(torch.isnan(got), torch.isnan(ref))
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(ref, nan=7.0))
+    gb = nhwc(bf(dy))
+    dxb = torch.zeros_like(xb)
+    _lib.check(lib.kodhip_maxpool5_bwd(gb.data_ptr(), C, 0, idx.data_ptr(), dxb.data_ptr(), C, 0, B, H, W, C, None, stream()), "pool bwd")
+    assert torch.equal(nchw(dxb), xr.grad)
+
+
 def test_conv_channel_slices():
     """Input read from / output written into channel slices of wider buffers (concat elimination)."""
     g = torch.Generator().manual_seed(5)
