@@ -25,3 +25,15 @@ for name, (B, H, W, C) in {"sppf pool yv5s [64,20,20,256]": (64, 20, 20, 256), "
     b = timed(lambda: _lib.check(lib.kodhip_maxpool5_bwd(g.data_ptr(), 4 * C, C, idx.data_ptr(), g.data_ptr(), 4 * C, 0, B, H, W, C, None, st)))
     mb = B * H * W * C * 2 / 1e6
     print(f"{name:34s} | fwd {f:6.1f} us ({(2 * mb + mb / 2) / f * 1e3:6.0f} GB/s) | bwd {b:6.1f} us ({(3 * mb + mb / 2) / b * 1e3:6.0f} GB/s)")
+
+# the heads' gradient re-layout (csrc/misc_ops.hip head_bwd_prep_kernel + bias reduction) at the three levels, nc = 10
+for name, HW in {"head grads 80x80": 6400, "head grads 40x40": 1600, "head grads 20x20": 400}.items():
+    B, A, nc, Npad = 64, 3, 10, 48
+    g = torch.randn(B, A, HW, 5 + nc, device="cuda")
+    dy = torch.empty(B * HW, Npad, device="cuda", dtype=torch.bfloat16)
+    ws = torch.empty(2048 * Npad, device="cuda")
+    db = [torch.empty(n, device="cuda") for n in (4 * A, A, nc * A)]
+    t = timed(lambda: _lib.check(lib.kodhip_head_bwd_prep(g.data_ptr(), dy.data_ptr(), ws.data_ptr(), db[0].data_ptr(), db[1].data_ptr(),
+                                                        db[2].data_ptr(), B, HW, A, nc, Npad, st)))
+    mb = (g.numel() * 4 + dy.numel() * 2) / 1e6
+    print(f"{name:34s} | prep + bias reduce {t:6.1f} us ({mb / t * 1e3:6.0f} GB/s)")
