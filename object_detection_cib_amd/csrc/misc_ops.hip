@@ -242,66 +242,114 @@ __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const bf16_t* x, int 
   }
 }
 
-// dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic): one thread = 4 consecutive input
-// columns x 8 channels, the 5 x 8 outputs whose windows reach them loaded once.  (A 4 x 4 x 4-channel block per thread with
-// one target code per output - the forward kernel's shape - needs fewer instructions per pair but 256 registers and
-// measured 57 us against this form's 34.)
-constexpr int POOL_BWD_PX = 4;
-__global__ void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const unsigned char* idx,
+// dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic).  Issue-bound like the forward
+// kernel: comparing every (input, output) pair in registers costs ~6 instructions per pair, 25 pairs per input element
+// (34 us).  Here a thread owns a 4 x 4 block of input pixels x 4 channels and keeps their 64 sums in PRIVATE LDS words
+// (word s of thread t at [s][t]: a thread's words never leave its bank column, so a wave's scattered accesses are
+// conflict-free; one array per channel, so that the compiler knows the channels' chains do not alias); it walks the
+// 8 x 8 outputs whose windows reach the block ONCE, in the fixed order (bottom output row first, left to right), turns
+// each stored tap byte into the block position it points at -
+//   t = byte + 16 r + c - 0x44 = 16 (r + dy - 4) + (c + dx - 4), inside the block iff (t & ~0x33) == 0
+// (0x1000 added for outputs outside the image) - and adds the gradient to that word, or to a dump word: one LDS
+// read-modify-write per OUTPUT element, no per-pair compares (84 instead of 156 instructions per input element: 27 us;
+// the LDS float atomic, ds_add_f32, does the same in 176 us).  A thread's accesses to its words execute in program
+// order, so the sums are those of the register form this replaces, in the same order.
+constexpr int POOL_BWD_THREADS = 128;       // 35 KB of private words per block: four blocks per CU
+__global__ __launch_bounds__(POOL_BWD_THREADS) void maxpool5_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const unsigned char* idx,
                                     bf16_t* dx, int ldx, int xcoff, int B, int H, int W, int C, const float* dx32) {
-  const int CC = C >> 3;
-  const int WG = (W + POOL_BWD_PX - 1) / POOL_BWD_PX;
+  // one array per channel: the compiler then knows that the four channels' read-modify-write chains do not alias
+  __shared__ float words0[17 * POOL_BWD_THREADS], words1[17 * POOL_BWD_THREADS], words2[17 * POOL_BWD_THREADS], words3[17 * POOL_BWD_THREADS];      // [block position 0..15 + dump][thread]
+  const int C4 = C >> 2;
+  const int WG = (W + 3) >> 2, HG = (H + 3) >> 2;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = (long)B * H * WG * CC;
+  const long total = (long)B * HG * WG * C4;
   if (i >= total) return;
-  int cc = (int)(i % CC);
-  long p = i / CC;
-  int gx = (int)(p % WG);
-  long q = p / WG;
-  int iy = (int)(q % H);
-  int b = (int)(q / H);
-  const int ix0 = gx * POOL_BWD_PX;
-  float acc[POOL_BWD_PX][8];
+  const int c4 = (int)(i % C4);
+  long p = i / C4;
+  const int gx = (int)(p % WG);
+  p /= WG;
+  const int gy = (int)(p % HG);
+  const int b = (int)(p / HG);
+  const int ix0 = gx * 4, iy0 = gy * 4;
+  float* const mine4[4] = {words0 + threadIdx.x, words1 + threadIdx.x, words2 + threadIdx.x, words3 + threadIdx.x};
 #pragma unroll
-  for (int o = 0; o < POOL_BWD_PX; ++o) {
-    const bool in = ix0 + o < W;
-    bf16x8 old = {};
-    const long po = ((long)(b * H + iy) * W + ix0 + o) * ldx + xcoff + cc * 8;
-    if (in && !dx32) old = *reinterpret_cast<const bf16x8*>(dx + po);
+  for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[o][e] = in ? (dx32 ? dx32[po + e] : (float)old[e]) : 0.f;      // dx32: fp32 partial
-  }
-  for (int dyy = 0; dyy < 5; ++dyy) {
-    int oy = iy - dyy + 2;                 // output row whose window tap dyy hits iy
-    if (oy < 0 || oy >= H) continue;
-    // output columns ox = ix - dxx + 2 for ix in [ix0, ix0 + PX), dxx in [0, 5): ox0 - 2 .. ox0 + PX + 1
+    for (int ci = 0; ci < 4; ++ci) {
+      const bool in = iy0 + ri < H && ix0 + ci < W;
+      const long po = ((long)(b * H + (in ? iy0 + ri : 0)) * W + (in ? ix0 + ci : 0)) * ldx + xcoff + c4 * 4;
+      uint2 old = {0u, 0u};
+      if (in && !dx32) old = *reinterpret_cast<const uint2*>(dx + po);
 #pragma unroll
-    for (int c = 0; c < POOL_BWD_PX + 4; ++c) {
-      const int ox = ix0 + c - 2;
-      if (ox < 0 || ox >= W) continue;
-      const long op = (long)(b * H + oy) * W + ox;
-      const uint2 ib = *reinterpret_cast<const uint2*>(idx + op * C + cc * 8);     // 8 argmax bytes in one load
-      const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + op * ldy + ycoff + cc * 8);
-#pragma unroll
-      for (int o = 0; o < POOL_BWD_PX; ++o) {
-        const int dxx = o - c + 4;         // ix = ix0 + o, ox = ix - dxx + 2  =>  dxx = ix - ox + 2
-        if (dxx < 0 || dxx > 4) continue;
-        const uint32_t want = (uint32_t)(dyy * 16 + dxx);      // the forward kernel's encoding
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint32_t byte = ((e < 4 ? ib.x : ib.y) >> (8 * (e & 3))) & 0xffu;
-          if (byte == want) acc[o][e] += (float)g[e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t d = e < 2 ? old.x : old.y;
+        mine4[e][(ri * 4 + ci) * POOL_BWD_THREADS] =
+            in ? (dx32 ? dx32[po + e] : __uint_as_float((e & 1) ? (d & 0xffff0000u) : (d << 16))) : 0.f;   // dx32: fp32 partial
       }
     }
+  // patch column c <-> ox = ix0 - 2 + c, patch row r <-> oy = iy0 - 2 + r: clamped addresses, 0x1000 for outside
+  uint32_t ck[8], rk[8];
+  int coff_i[8], coff_g[8];
+  long roff[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int ox = ix0 - 2 + c, oy = iy0 - 2 + c;
+    ck[c] = (uint32_t)c + ((ox >= 0 && ox < W) ? 0u : 0x1000u);
+    rk[c] = (uint32_t)(16 * c - 0x44) + ((oy >= 0 && oy < H) ? 0u : 0x1000u);
+    const int cxc = ox < 0 ? 0 : (ox >= W ? W - 1 : ox), ryc = oy < 0 ? 0 : (oy >= H ? H - 1 : oy);
+    coff_i[c] = cxc * C;
+    coff_g[c] = cxc * ldy;
+    roff[c] = (long)(b * H + ryc) * W;
+  }
+  const unsigned char* ibase = idx + c4 * 4;
+  const bf16_t* gbase = dy + ycoff + c4 * 4;
+  uint32_t ibc[8], ibn[8];
+  uint2 gc[8], gn[8];
+  auto load_row = [&](const int r, uint32_t (&ib)[8], uint2 (&g)[8]) {
+    const unsigned char* ir = ibase + roff[r] * C;
+    const bf16_t* gr = gbase + roff[r] * ldy;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      ib[c] = *reinterpret_cast<const uint32_t*>(ir + coff_i[c]);           // 4 argmax bytes in one load
+      g[c] = *reinterpret_cast<const uint2*>(gr + coff_g[c]);
+    }
+  };
+  load_row(7, ibc, gc);
+#pragma unroll
+  for (int r = 7; r >= 0; --r) {
+    if (r > 0) load_row(r - 1, ibn, gn);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      uint32_t word[4];
+      float g[4], cur[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t t = ((ibc[c] >> (8 * e)) & 0xffu) + rk[r] + ck[c];
+        const uint32_t pos = ((t >> 2) & 12u) | (t & 3u);
+        word[e] = (t & ~0x33u) == 0u ? pos : 16u;
+        const uint32_t d = e < 2 ? gc[c].x : gc[c].y;
+        g[e] = __uint_as_float((e & 1) ? (d & 0xffff0000u) : (d << 16));
+      }
+      // this thread's own words (LDS float atomics measured 5 x slower); the four channels' reads leave together
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cur[e] = mine4[e][word[e] * POOL_BWD_THREADS];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mine4[e][word[e] * POOL_BWD_THREADS] = cur[e] + g[e];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { ibc[c] = ibn[c]; gc[c] = gn[c]; }
   }
 #pragma unroll
-  for (int o = 0; o < POOL_BWD_PX; ++o) {
-    if (ix0 + o >= W) break;
-    bf16x8 v;
+  for (int ri = 0; ri < 4; ++ri) {
+    if (iy0 + ri >= H) continue;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)acc[o][e];
-    *reinterpret_cast<bf16x8*>(dx + ((long)(b * H + iy) * W + ix0 + o) * ldx + xcoff + cc * 8) = v;
+    for (int ci = 0; ci < 4; ++ci) {
+      if (ix0 + ci >= W) continue;
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16_t)mine4[e][(ri * 4 + ci) * POOL_BWD_THREADS];
+      *reinterpret_cast<bf16x4*>(dx + ((long)(b * H + iy0 + ri) * W + ix0 + ci) * ldx + xcoff + c4 * 4) = v;
+    }
   }
 }
 
@@ -531,8 +579,8 @@ int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, voi
                         int B, int H, int W, int C, const float* dx_f32, hipStream_t stream) {
   KOD_CHECK_ARG(dy && dx && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0,
                 "maxpool5_bwd: bad args");
-  long n = (long)B * H * ((W + POOL_BWD_PX - 1) / POOL_BWD_PX) * (C / 8);
-  hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)dy, ldy, ycoff,
+  long n = (long)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 4);      // a 4 x 4 block of inputs x 4 channels per thread
+  hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(cdiv(n, POOL_BWD_THREADS)), dim3(POOL_BWD_THREADS), 0, stream, (const bf16_t*)dy, ldy, ycoff,
                      (const unsigned char*)idx, (bf16_t*)dx, ldx, xcoff, B, H, W, C, dx_f32);
   KOD_LAUNCH_CHECK("maxpool5_bwd");
   return KOD_OK;
