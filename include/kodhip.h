@@ -226,6 +226,8 @@ int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout,
 
 /* ---- SPPF max-pool, nearest upsample (kod/nn/layers/sppf.py:46-50,73-76,
  *      kod/nn/necks/yolov5_pafpn.py:144-146,182-184) ------------------------------------------------- */
+/* idx: [B][H][W][C] bytes, the winning tap of every output (an opaque code: written by _fwd, read by _bwd of the same
+ * library); argmax as torch's scan: first maximum in row-major window order, a NaN beats every number */
 int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff, void* idx,
                         int B, int H, int W, int C, kodStream_t stream);
 /* dx_f32 (NULL = none): fp32 shadow of dx holding the earlier producers' partial sum (see kodhip_conv_dgrad) */
