@@ -119,12 +119,13 @@ def test_conv_dgrad_stride2_parity_classes(case, form):
         assert (got[:, :8] == 0).all() and (got[:, 8 + Cin:] == 0).all()
 
 
-@pytest.mark.parametrize("shape", [(1, 8, 1, 1), (2, 8, 3, 9), (1, 16, 5, 7), (2, 8, 20, 20), (1, 8, 6, 13)])
+@pytest.mark.parametrize("shape", [(1, 8, 1, 1), (2, 8, 3, 9), (1, 16, 5, 7), (2, 8, 20, 20), (1, 8, 6, 13), (64, 256, 20, 20), (8, 384, 20, 20)])
 def test_maxpool_ties_special_values_and_ragged_edges(shape):
     """The key-based 5x5 pool (csrc/misc_ops.hip maxpool5_fwd_kernel) against torch's scan on inputs made of ties and
     special values: small integers (most windows hold their maximum several times: the FIRST one in row-major window
     order must get the gradient), +-inf, and one NaN per image (a NaN beats every number); maps whose sides are not
-    multiples of the 4 x 4 output block; integer-valued output gradients so that the routed sums are exact."""
+    multiples of the 4 x 4 output block - and the SPPF's own shapes at full size (yv5s B = 64: 256 channels, yv5m: 384);
+    integer-valued output gradients so that the routed sums are exact."""
     B, C, H, W = shape
     g = torch.Generator().manual_seed(H * 31 + W)
     x = torch.randint(-3, 4, (B, C, H, W), generator=g).float()
