@@ -169,7 +169,8 @@ def loop_leg(net, loss_fn, B, S, nc, device, steps, mixup_prob=0.0, producer=Tru
     _lib.limit_host_threads()      # the host side of the data protocol: torch's pool sized to the cgroup's CPU share
     imgs, boxes, labels = synth_pool(256, S, nc, 7 + rank)
     pipe = DeviceTrainPipeline(imgs, boxes, labels, S, device, mixup_prob=mixup_prob)
-    schedule = [[(i * B + k) % 256 for k in range(B)] for i in range(steps + 5)]
+    warm = 8                       # replays before the clock starts (3 until round 4: the first default run on a box read 0.5 % low)
+    schedule = [[(i * B + k) % 256 for k in range(B)] for i in range(steps + warm + 2)]
     seed = 2023 + rank
     prod = None
     if producer:
@@ -192,12 +193,12 @@ def loop_leg(net, loss_fn, B, S, nc, device, steps, mixup_prob=0.0, producer=Tru
     try:
         first = produce(0)
         gs = GraphedTrainStep(net, loss_fn, B, S, S, max_targets=16384, input_pairs=True).capture(first[0], first[1])
-        for i in range(3):
+        for i in range(warm):
             gs(*produce(i + 1))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            total, _ = gs(*produce(i + 4))
+            total, _ = gs(*produce(i + 1 + warm))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
     finally:
@@ -590,7 +591,7 @@ def main():
     ap.add_argument("--timeout", type=float, default=900.0, help="self-launch: seconds before a hung job is stopped")
     ap.add_argument("--no-loop", action="store_true", help="skip the training-loop leg (device data pipeline -> captured step)")
     ap.add_argument("--no-extra", action="store_true", help="skip the validation-loop and yv5m legs")
-    ap.add_argument("--loop-steps", type=int, default=20)
+    ap.add_argument("--loop-steps", type=int, default=30)
     ap.add_argument("--loop-mixup", type=float, default=None, help="mixup probability of the loop leg (default 0 at N=1, 0.1 at N>1)")
     ap.add_argument("--loop-in-process", action="store_true", help="loop leg: host side of the data protocol in this process (round 3)")
     args = ap.parse_args()
