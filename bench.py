@@ -343,6 +343,17 @@ ATTEMPTS = (
 )
 
 
+def _die_with_parent():
+    """preexec of a rank this process starts: the rank gets SIGKILL when this process dies, however it dies (a launcher
+    that times out kills its own children, not their children - the ranks would keep the GPUs busy under the next run)."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)       # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
 def _stop_group(proc):
     import signal
     if proc.poll() is None:
@@ -376,7 +387,7 @@ def _launch_once(args, attempt: int, timeout: float):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KODHIP_BENCH_LAUNCHER="self",
                    KODHIP_BENCH_ATTEMPT=str(attempt), KODHIP_BENCH_HEARTBEAT=beats[r], **ATTEMPTS[attempt])
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, preexec_fn=_die_with_parent,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
     deadline = time.monotonic() + timeout
     chunks = []
@@ -437,6 +448,7 @@ def supervise_rank(args) -> int:
     Any failure to set the supervision up (port taken, store unreachable) returns None: the rank then runs in-process,
     exactly as without supervision."""
     import datetime
+    import signal
     import subprocess
     import tempfile
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -454,7 +466,11 @@ def supervise_rank(args) -> int:
     for k in range(len(ATTEMPTS)):
         hb = os.path.join(tempfile.gettempdir(), f"kodbench_hb_{os.getpid()}_{k}")
         env = dict(os.environ, KODHIP_BENCH_LAUNCHER="external", KODHIP_BENCH_ATTEMPT=str(k), KODHIP_BENCH_HEARTBEAT=hb, **ATTEMPTS[k])
-        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True)
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True,
+                                 preexec_fn=_die_with_parent)
+        # a launcher that gives up sends SIGTERM to ITS children - the supervisors: take the rank (and its producer) along
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            signal.signal(sig, lambda *_a, _c=child: (_stop_group(_c), os._exit(143)))
         t_start, t_pub = time.time(), 0.0
         deadline = time.monotonic() + (args.timeout if k == 0 else min(args.timeout, 600.0)) + 30.0
         mine, verdict = None, None

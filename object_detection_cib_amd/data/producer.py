@@ -19,6 +19,8 @@ import multiprocessing as mp
 from multiprocessing import shared_memory
 from typing import List, Sequence
 
+import os
+
 import numpy as np
 
 from .host_protocol import SAMPLE_DESC, PackedTargets
@@ -47,6 +49,7 @@ def _worker(shm_name: str, slots: int, B: int, cap: int, host_args: dict, rng_se
     import random
     from .host_protocol import HostProtocol, pack_targets
     shm = shared_memory.SharedMemory(name=shm_name)
+    parent = os.getppid()
     try:
         if py_seed is not None:
             random.seed(py_seed)
@@ -58,7 +61,7 @@ def _worker(shm_name: str, slots: int, B: int, cap: int, host_args: dict, rng_se
             descs, mix, per_sample = host.batch(idx)
             pt = pack_targets(per_sample)
             while not free.acquire(timeout=0.2):
-                if stop.is_set():
+                if stop.is_set() or os.getppid() != parent:       # (a trainer that was killed cannot set `stop`)
                     return
             v = _views(shm.buf, (seq % slots) * lay["size"], lay, B, cap)
             n = len(pt.labels)

@@ -498,3 +498,56 @@ def test_bench_under_torch_distributed_run_and_attempt_ladder(die_rank):
     if die_rank is not None:
         assert "attempt 0" in r.stderr and d["config"]["fallback"] == {"KODHIP_BENCH_NO_GRAPH": "1"}
     assert np.isfinite(d["final_loss"])
+
+
+@pytest.mark.gpu
+def test_bench_ranks_die_with_their_launcher():
+    """A launcher that gives up (the driver's timeout) signals ITS children - bench.py's supervisors - not theirs: the
+    supervisors take their ranks along on SIGTERM, and a rank whose supervisor was killed outright gets SIGKILL through
+    PR_SET_PDEATHSIG, so nothing keeps the GPU busy under the next run.  Here: a two-rank job whose rank 1 hangs (test
+    hook) is started under torch.distributed.run, the launcher is terminated, and no process of the job (found by a
+    marker in its environment) is left."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    import uuid
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tag = "kodtag_" + uuid.uuid4().hex
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "KODHIP_BENCH_LAUNCHER", "KODHIP_BENCH_ATTEMPT")}
+    env.update(KODHIP_BENCH_ONE_GPU="1", KODHIP_BENCH_TEST_HANG_RANK="1", KODHIP_BENCH_STALL_S="600", KODHIP_TEST_MARK=tag)
+
+    def alive():
+        pids = []
+        for d in os.listdir("/proc"):
+            if d.isdigit() and int(d) != os.getpid():
+                try:
+                    with open(f"/proc/{d}/environ", "rb") as f:
+                        if tag.encode() in f.read():
+                            pids.append(int(d))
+                except OSError:
+                    pass
+        return pids
+    p = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4", "--size", "256", "--no-cpu-baseline",
+                          "--timeout", "600"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd=root)
+    try:
+        deadline = time.time() + 120
+        while len(alive()) < 5 and time.time() < deadline:          # launcher + 2 supervisors + 2 ranks (+ producers later)
+            time.sleep(0.5)
+        assert len(alive()) >= 5, alive()
+        time.sleep(5)
+        p.send_signal(signal.SIGTERM)                                # exactly the launcher this test started
+        p.wait(60)
+        deadline = time.time() + 30
+        while alive() and time.time() < deadline:
+            time.sleep(0.5)
+        assert alive() == [], alive()
+    finally:
+        if p.poll() is None:
+            p.kill()
