@@ -129,6 +129,14 @@ __device__ __forceinline__ void wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0
 // to a multiple of 8): [FZ_CTR + nt] launch counter of channel tile nt; [FZ_FLAG + nt] flag granule; then the partial
 // granules part[nt][st][ch][Gp] and the group granules gpart[nt][st][ch][NG][lo | hi].
 constexpr int FZ_CTR = 0, FZ_FLAG = 32, FZ_PART = 64, FZ_MAX_TILES_N = 32;
+#ifdef KOD_FZ_STAMPS   // diagnostic build (tools/build_ablate.sh stamps -DKOD_FZ_STAMPS): device clock (100 MHz) at the steps of the
+                       // hand-off, written by the finalizer (gm == 0) and by the last block of channel tile 0 into ws[8 ..] / ws[20 ..]
+#define FZ_STAMP(i) do { if (fnt == 0 && ftid == 0 && (fgm == 0 || fgm == G - 1)) z.ws[(fgm == 0 ? 8 : 20) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FZ_STAMP_B(i) do { if constexpr (MODE == MODE_RAW_FUSED) { if (nt == 0 && tid == 0 && (gm == 0 || gm == a.groups_m - 1)) a.fz.ws[(gm == 0 ? 8 : 20) + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define FZ_STAMP(i) do { } while (0)
+#define FZ_STAMP_B(i) do { } while (0)
+#endif
 __device__ __forceinline__ unsigned long long fz_ld(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -241,6 +249,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   const int gm = (j / a.tiles_n) * 8 + xcd;
   if (gm >= a.groups_m) return;
   const int n0 = nt * BN;
+  FZ_STAMP_B(7);
 
   // staging assignment
   const int a_chunk = tid & 3;              // which 8-element k chunk of the 32-wide K tile
@@ -690,6 +699,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       }
     };
 
+    FZ_STAMP_B(8);
     if constexpr (STEM) {
       dma_tileS(0);
       for (int kt = 0; kt < nk; ++kt) {
@@ -764,6 +774,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       }
     }
 
+    FZ_STAMP_B(9);
     // ---- epilogue.  acc[i][jj][e]: pixel = wm*WM + jj*32 + (lane&31),
     //      channel = wn*WN + i*32 + 8*(e>>2) + 4*(lane>>5) + (e&3)
     if constexpr (MODE == MODE_HEAD) {
@@ -943,7 +954,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
               ssq[e] += f * f;
             }
           }
-          *reinterpret_cast<bf16x8*>(dst) = v;
+          // (fused forward: the tile leaves the chip only after the statistics hand-off, together with the activated
+          //  tile - stores queued here would sit in this CU's memory pipeline in front of every granule of the hand-off)
+          if constexpr (MODE != MODE_RAW_FUSED) *reinterpret_cast<bf16x8*>(dst) = v;
         }
       }
       __syncthreads();
@@ -959,6 +972,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         unsigned long long* part = z.ws + FZ_PART;
         unsigned long long* gpart = part + (size_t)a.tiles_n * 2 * BN * Gp;
         const unsigned int tag = (unsigned int)z.ws[FZ_CTR + fnt] + 1u;       // this launch's number (bumped by the tile's finalizer)
+        FZ_STAMP(0);
 #pragma unroll
         for (int o = CPR; o < 64; o <<= 1)
 #pragma unroll
@@ -983,6 +997,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
           for (int w = 0; w < NW; ++w) sblk += sred[(w * BN + fch) * 2 + fst];
           fz_st(part + prow * Gp + fgm, tag, __float_as_uint(sblk));
         }
+        FZ_STAMP(1);
         __syncthreads();                                         // sred is reused below (fp64 totals)
         double* dtot = reinterpret_cast<double*>(sred);
         if (fgm % z.S == 0 && ftid < BN * 2) {
@@ -998,6 +1013,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
           }
           if (fgm == 0) dtot[ftid] = bad ? __longlong_as_double(0x7ff8000000000000ll) : s1;
         }
+        FZ_STAMP(2);
         if (fgm == 0) {
           // the channel tile's finalizer: sums -> BatchNorm constants (arithmetic of bn_finalize_fused_kernel, bn_act.hip)
           __syncthreads();
@@ -1021,6 +1037,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the flag goes up
           __syncthreads();
+          FZ_STAMP(3);
           if (ftid == 0) {
             z.ws[FZ_CTR + fnt] = tag;                             // (plain: read by the NEXT launch, behind a kernel boundary)
             fz_st(z.ws + FZ_FLAG + fnt, tag, 1u);
@@ -1035,6 +1052,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         }
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) *z.err = 1;
         __syncthreads();
+        FZ_STAMP(4);
         const int fc = ftid % CPR, fr0 = ftid / CPR, fn = fnt * BN + fc * 8;
         const bool fcol_ok = fn < a.N;
         float fsc[8], fsh[8];
@@ -1044,6 +1062,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
           fsc[e] = __hip_atomic_load(z.aff + nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           fsh[e] = __hip_atomic_load(z.aff + a.N + nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        asm volatile("" :: "v"(fsc[0]), "v"(fsh[7]));
+        FZ_STAMP(5);
 #pragma unroll
         for (int p = 0; p < BM / RPP; ++p) {
           const int row = fr0 + p * RPP;
@@ -1066,10 +1086,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
                 o[e] = (bf16_t)(zz * kod_sigmoid_l2(KOD_NEG_LOG2E * zz));
               }
             }
+            *reinterpret_cast<bf16x8*>(a.y + (size_t)m * a.ldy + a.ycoff + fn) = v;
             *reinterpret_cast<bf16x8*>(z.out + (size_t)m * z.ldo + z.ocoff + fn) = o;
           }
         }
         __syncthreads();
+        FZ_STAMP(6);
       }
       if constexpr (MODE == MODE_PLAIN_BN) {
         // fold this tile's sums into one running value per (channel, statistic), held by thread tid < 2*BN: the
@@ -1456,6 +1478,35 @@ Plan plan_conv(const ConvArgs& a, bool fast, bool& row3, int mode) {
   return make_plan(a.M, a.N, a.nk1 ? 2 * a.K : a.K, fast, row3, fold_bn_cap(a));
 }
 
+// Launches of fewer blocks than the chip holds (strides 16 / 32: 100 - 800 tiles for 256 CUs x 2 - 4 resident blocks): the
+// dispatcher fills a CU up to its occupancy before it moves on, so half of the CUs would run 2 - 4 blocks each while the
+// others idle.  A dynamic-LDS pad that lowers the occupancy to ceil(blocks / 256) per CU spreads the grid over all CUs.
+// KODHIP_SPREAD=0 switches it off (A/B).
+template <typename K>
+unsigned spread_pad(K kernel, long active_blocks) {
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("KODHIP_SPREAD"); mode = e ? atoi(e) : 1; }
+  if (!mode || active_blocks <= 0) return 0;
+  static const void* known[64];
+  static int known_lds[64], n_known = 0;
+  int st = -1;
+  for (int i = 0; i < n_known; ++i) if (known[i] == (const void*)kernel) st = known_lds[i];
+  if (st < 0) {
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, (const void*)kernel) != hipSuccess) return 0;
+    st = (int)at.sharedSizeBytes;
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
+    if (n_known < 64) { known[n_known] = (const void*)kernel; known_lds[n_known++] = st; }
+  }
+  const int lds_cu = 160 * 1024;
+  long per_cu = (active_blocks + 255) / 256;
+  if (per_cu > 8) return 0;
+  const int want = lds_cu / (int)(per_cu + 1) + 1024;       // just too large for per_cu + 1 blocks
+  if (want <= st || want > lds_cu / (int)per_cu) return 0;
+  return (unsigned)((want - st + 1023) & ~1023);
+}
+#define KOD_LAUNCH_SPREAD(KERNEL, THREADS, ACTIVE, ARGS) hipLaunchKernelGGL(KERNEL, g, dim3(THREADS), spread_pad(KERNEL, ACTIVE), stream, ARGS)
+
 template <int MODE, bool F32ACC = false>
 int launch(const ConvArgs& a, hipStream_t stream) {
   if constexpr ((MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) && !F32ACC) {
@@ -1497,21 +1548,22 @@ int launch(const ConvArgs& a, hipStream_t stream) {
       return KOD_OK;
     }
   }
+  const long active = (long)p.groups_m * p.tiles_n;
   if constexpr (MODE != MODE_HEAD) {
     if (row3) {
-      if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_row3_kernel<128, 2, 2, MODE, F32ACC>), g, dim3(256), 0, stream, args);
-      else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_row3_kernel<64, 2, 2, MODE, F32ACC>), g, dim3(256), 0, stream, args);
-      else hipLaunchKernelGGL((conv_igemm_row3_kernel<32, 4, 1, MODE, F32ACC>), g, dim3(256), 0, stream, args);
+      if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<128, 2, 2, MODE, F32ACC>), 256, active, args);
+      else if (p.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<64, 2, 2, MODE, F32ACC>), 256, active, args);
+      else KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<32, 4, 1, MODE, F32ACC>), 256, active, args);
       KOD_LAUNCH_CHECK("conv_igemm_row3");
       return KOD_OK;
     }
   }
   if (fast) {
-    if (p.bm == 256 && p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, args);
-    else if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, args);
-    else if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, args);
-    else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, MODE, true, F32ACC>), g, dim3(256), 0, stream, args);
+    if (p.bm == 256 && p.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_kernel<256, 64, 4, 2, MODE, true, F32ACC>), 512, active, args);
+    else if (p.bm == 256) KOD_LAUNCH_SPREAD((conv_igemm_kernel<256, 128, 4, 2, MODE, true, F32ACC>), 512, active, args);
+    else if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 128, 2, 2, MODE, true, F32ACC>), 256, active, args);
+    else if (p.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 64, 2, 2, MODE, true, F32ACC>), 256, active, args);
+    else KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 32, 4, 1, MODE, true, F32ACC>), 256, active, args);
   } else if constexpr (F32ACC) {
     KOD_CHECK_ARG(false, "conv: fp32 accumulation across producers needs the FAST path");
   } else if constexpr (MODE == MODE_PLAIN_BN) {
@@ -1548,11 +1600,11 @@ int launch_x4(ConvArgs c[4], hipStream_t stream) {
   static const bool interleave = getenv("KODHIP_S2_INTERLEAVE") != nullptr;
   p.per_class = pl.grid; p.interleave = interleave;
   dim3 g(pl.grid * 4);
-  if (pl.bm == 256 && pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, p);
-  else if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, p);
-  else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, p);
-  else if (pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 32, 4, 1, MODE, true, F32ACC>), g, dim3(256), 0, stream, p);
+  if (pl.bm == 256 && pl.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true, F32ACC>), 512, 4l * pl.groups_m * pl.tiles_n, p);
+  else if (pl.bm == 256) KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true, F32ACC>), 512, 4l * pl.groups_m * pl.tiles_n, p);
+  else if (pl.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true, F32ACC>), 256, 4l * pl.groups_m * pl.tiles_n, p);
+  else if (pl.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<128, 64, 2, 2, MODE, true, F32ACC>), 256, 4l * pl.groups_m * pl.tiles_n, p);
+  else KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<128, 32, 4, 1, MODE, true, F32ACC>), 256, 4l * pl.groups_m * pl.tiles_n, p);
   KOD_LAUNCH_CHECK("conv_igemm_x4");
   return KOD_OK;
 }
@@ -1594,7 +1646,8 @@ bool plan_fused(const ConvArgs& a, FusePlan& f) {
     }
   }
   (void)threads;
-  if ((long)p.tiles_m * p.tiles_n > cap[idx]) return false;
+  static const bool force = getenv("KODHIP_FUSE_FORCE") != nullptr;          // (tools/fused_census.py: what is resident in fact)
+  if ((long)p.tiles_m * p.tiles_n > cap[idx] && !force) return false;
   const int G = p.groups_m;
   int S = 8;
   while (S * S < G) S += 4;                         // ~sqrt(G), at least 8: both levels poll <= 32 granules per thread
@@ -1613,14 +1666,14 @@ int launch_fused(const ConvArgs& a, const FusePlan& f, hipStream_t stream) {
   args.fz.S = f.S; args.fz.NG = f.NG;
   dim3 g(p.grid);
   if (f.row3) {
-    if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_row3_kernel<128, 2, 2, MODE_RAW_FUSED>), g, dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL((conv_igemm_row3_kernel<64, 2, 2, MODE_RAW_FUSED>), g, dim3(256), 0, stream, args);
+    if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<128, 2, 2, MODE_RAW_FUSED>), 256, (long)p.groups_m * p.tiles_n, args);
+    else KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<64, 2, 2, MODE_RAW_FUSED>), 256, (long)p.groups_m * p.tiles_n, args);
   } else if (p.bm == 256) {
-    if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE_RAW_FUSED, true>), g, dim3(512), 0, stream, args);
-    else hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 2, MODE_RAW_FUSED, true>), g, dim3(512), 0, stream, args);
+    if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_kernel<256, 128, 4, 2, MODE_RAW_FUSED, true>), 512, (long)p.groups_m * p.tiles_n, args);
+    else KOD_LAUNCH_SPREAD((conv_igemm_kernel<256, 64, 4, 2, MODE_RAW_FUSED, true>), 512, (long)p.groups_m * p.tiles_n, args);
   } else {
-    if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE_RAW_FUSED, true>), g, dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE_RAW_FUSED, true>), g, dim3(256), 0, stream, args);
+    if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 128, 2, 2, MODE_RAW_FUSED, true>), 256, (long)p.groups_m * p.tiles_n, args);
+    else KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 64, 2, 2, MODE_RAW_FUSED, true>), 256, (long)p.groups_m * p.tiles_n, args);
   }
   KOD_LAUNCH_CHECK("conv_igemm_fused");
   return KOD_OK;

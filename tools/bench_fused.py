@@ -21,7 +21,7 @@ LAYERS = {  # name: (Cin, H, W, Cout, k, s, p)
     "ds0 128->128 3x3s2 @80": (128, 80, 80, 128, 3, 2, 1),
 }
 B = 64
-for name in (sys.argv[1:] or list(LAYERS)):
+for name in ((sys.argv[1:] or list(LAYERS)) if __name__ == "__main__" else []):
     Cin, H, W, Cout, k, s, p = LAYERS[name]
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     M = B * Ho * Wo
@@ -37,17 +37,16 @@ for name in (sys.argv[1:] or list(LAYERS)):
     err = torch.zeros(4, dtype=torch.int32, device="cuda")
     nb = lib.kodhip_conv_fwd_bn_silu_ws_bytes(B, H, W, Cin, Cin, Cout, k, k, s, s, p, p)
     ws = torch.zeros(max(nb // 8, 1), dtype=torch.int64, device="cuda")
-    st = stream()
     a = aff.data_ptr()
 
     def three():
-        _lib.check(lib.kodhip_conv_fwd_raw(x.data_ptr(), pk["f"].data_ptr(), raw.data_ptr(), stats.data_ptr(), B, H, W, Cin, 0, Cin, Cout, k, k, s, s, p, p, pk["Kp"], Cout, 0, st))
-        _lib.check(lib.kodhip_bn_finalize_partials(stats.data_ptr(), T, float(M), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.03, 1e-3, a, a + 4 * Cout, a + 8 * Cout, a + 12 * Cout, Cout, 1, st))
-        _lib.check(lib.kodhip_bn_silu_apply(raw.data_ptr(), Cout, a, a + 4 * Cout, None, 0, 0, out.data_ptr(), Cout, 0, M, Cout, st))
+        _lib.check(lib.kodhip_conv_fwd_raw(x.data_ptr(), pk["f"].data_ptr(), raw.data_ptr(), stats.data_ptr(), B, H, W, Cin, 0, Cin, Cout, k, k, s, s, p, p, pk["Kp"], Cout, 0, stream()))
+        _lib.check(lib.kodhip_bn_finalize_partials(stats.data_ptr(), T, float(M), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.03, 1e-3, a, a + 4 * Cout, a + 8 * Cout, a + 12 * Cout, Cout, 1, stream()))
+        _lib.check(lib.kodhip_bn_silu_apply(raw.data_ptr(), Cout, a, a + 4 * Cout, None, 0, 0, out.data_ptr(), Cout, 0, M, Cout, stream()))
 
     def one():
         _lib.check(lib.kodhip_conv_fwd_bn_silu(x.data_ptr(), pk["f"].data_ptr(), raw.data_ptr(), ws.data_ptr(), B, H, W, Cin, 0, Cin, Cout, k, k, s, s, p, p, pk["Kp"], Cout, 0,
-                                               gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.03, 1e-3, a, 1, None, 0, 0, out.data_ptr(), Cout, 0, err.data_ptr(), 0, st))
+                                               gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.03, 1e-3, a, 1, None, 0, 0, out.data_ptr(), Cout, 0, err.data_ptr(), 0, stream()))
 
     line = f"{name:32s}"
     for fn in (three, one) if nb > 0 else (three,):
