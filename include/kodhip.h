@@ -50,22 +50,6 @@ int kodhip_conv_fwd_raw(const void* x, const void* w_packed, void* y, float* sta
                         int B, int H, int W, int ldx, int xcoff, int Cin,
                         int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp,
                         int ldy, int ycoff, kodStream_t stream);
-/* Conv2dNormActivation forward of one unit as ONE launch (conv -> train-mode BatchNorm2d(eps, momentum) -> SiLU
- * [+ the CSPBlock residual], kod/nn/layers/csp.py:30-58, kod/nn/networks/yolov5.py:24) for the layers whose output
- * tiles are all resident on the chip at once (strides 16 / 32): the tile waits in LDS while the batch statistics
- * meet through tagged 8-byte granules.  *_ws_bytes: workspace the caller allocates, zeroes ONCE and passes to every
- * launch of the unit; 0 = take kodhip_conv_fwd_raw + kodhip_bn_finalize_partials + kodhip_bn_silu_apply instead.
- * y_raw = pre-BN output (kept for backward); aff = scale|shift|mean|rstd (4*N floats); err_flag: device-visible int,
- * set to 1 when a hand-off inside the launch gave up (constants are then NaN); max_spins 0 = default. */
-long kodhip_conv_fwd_bn_silu_ws_bytes(int B, int H, int W, int ldx, int Cin, int N, int KH, int KW, int SH, int SW,
-                                      int PH, int PW);
-int kodhip_conv_fwd_bn_silu(const void* x, const void* w_packed, void* y_raw, void* workspace,
-                            int B, int H, int W, int ldx, int xcoff, int Cin,
-                            int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp, int ldy, int ycoff,
-                            const float* gamma, const float* beta, float* running_mean, float* running_var,
-                            float momentum, float eps, float* aff, int update_running,
-                            const void* residual, int ldr, int rcoff, void* out, int ldo, int ocoff,
-                            int* err_flag, long max_spins, kodStream_t stream);
 /* three biased 1x1 head convs of one level fused (kod/nn/heads/yolov5.py:12-136), out [B][A][H*W][5+nc] fp32 */
 int kodhip_conv_fwd_head(const void* x, const void* w_packed, const float* bias, float* out,
                          int B, int H, int W, int ldx, int xcoff, int Cin, int A, int nc, int Kp,

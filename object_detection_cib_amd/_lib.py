@@ -40,9 +40,6 @@ SIGNATURES = {
     "kodhip_pack_desc_bytes": (i32, []),
     "kodhip_conv_stats_slots": (i32, [i64, i32]),
     "kodhip_conv_fwd_raw": (i32, [vp, vp, vp, vp] + [i32] * 16 + [vp]),
-    "kodhip_conv_fwd_bn_silu_ws_bytes": (i64, [i32] * 12),
-    "kodhip_conv_fwd_bn_silu": (i32, [vp, vp, vp, vp] + [i32] * 16 + [vp, vp, vp, vp, f32, f32, vp, i32, vp, i32, i32, vp, i32, i32,
-                                      vp, i64, vp]),
     "kodhip_conv_fwd_head": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp]),
     "kodhip_conv_dgrad": (i32, [vp, vp, vp] + [i32] * 17 + [vp, vp]),
     "kodhip_conv_dgrad_s2": (i32, [vp, vp, vp] + [i32] * 10 + [vp, vp]),

@@ -27,31 +27,7 @@
 
 namespace {
 
-enum { MODE_RAW = 0, MODE_PLAIN = 1, MODE_HEAD = 2, MODE_PLAIN_BN = 3, MODE_RAW_FUSED = 4 };
-
-// MODE_RAW_FUSED: forward conv + train-mode BatchNorm + SiLU (+ residual) of a unit as ONE launch, for the layers whose
-// tiles are all resident at once (strides 16 / 32: one tile per block).  The three-launch form (conv + statistics ->
-// finalize -> apply) pays two kernel boundaries, a one-wave-per-channel latency kernel and a re-read of the pre-BN tensor
-// on layers that take 15 - 40 us in all.  Here the tile stays in LDS (bf16, as stored) while the batch statistics meet:
-//   every block publishes its per-channel partial sums as 8-byte {tag : 32 | fp32 : 32} granules (ONE sc1 store each,
-//   tag = the unit's launch number: no flag, no ordering, no atomics - MI355X_MICROARCH.md, granule hand-offs);
-//   designated blocks (the first of each group of S) poll their group's granules and publish the group's fp64 sums;
-//   the block gm == 0 of a channel tile polls those, turns them into the BatchNorm constants (+ running statistics),
-//   stores them write-through, drains its stores and raises the tile's flag granule;
-//   every block polls that flag with one lane, fetches the constants with sc1 loads and applies them to its LDS tile.
-// All sums are taken in block-index order (not arrival order): deterministic.  A poll that never sees its tag (the grid
-// was not resident after all) gives up after max_spins, raises *err and poisons the constants with NaN.
-struct FuseArgs {
-  unsigned long long* ws;        // zero-initialised by the caller once; layout: fz_* helpers below
-  int S, NG;                     // level-1 group size, number of groups (blocks per channel tile G = groups_m)
-  const float* gamma; const float* beta; float* rmean; float* rvar;
-  float* aff;                    // scale[N] | shift[N] | mean[N] | rstd[N]
-  float momentum, eps; double count; int update_running;
-  const bf16_t* res; int ldr, rcoff;
-  bf16_t* out; int ldo, ocoff;
-  int* err;
-  long max_spins;
-};
+enum { MODE_RAW = 0, MODE_PLAIN = 1, MODE_HEAD = 2, MODE_PLAIN_BN = 3 };
 
 // MODE_PLAIN_BN: a data-gradient launch that is the LAST writer of some conv units' output gradients also produces
 // their BatchNorm-backward reduction (sum dz, sum dz*y per channel) in its epilogue - the tile it has just written
@@ -108,7 +84,6 @@ struct ConvArgs {
   const bf16_t* seg_raw[MAX_SEG];      // the unit's pre-BN output y [M_out][ldr]
   const float* seg_aff[MAX_SEG];       // scale[C] | shift[C]
   float* seg_part[MAX_SEG];            // [2][C][stats_slots]: sum dz | sum dz*y
-  FuseArgs fz;                         // MODE_RAW_FUSED
 };
 
 // q = n / d, r = n % d via a float reciprocal + fix-up (exact: the loops absorb the fp32 rounding of large n)
@@ -124,68 +99,6 @@ constexpr int BK = 32;
 
 template <int N>
 __device__ __forceinline__ void wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// ---- MODE_RAW_FUSED hand-off helpers.  Workspace layout in 8-byte words (G = blocks per channel tile, Gp = G rounded up
-// to a multiple of 8): [FZ_CTR + nt] launch counter of channel tile nt; [FZ_FLAG + nt] flag granule; then the partial
-// granules part[nt][st][ch][Gp] and the group granules gpart[nt][st][ch][NG][lo | hi].
-constexpr int FZ_CTR = 0, FZ_FLAG = 32, FZ_PART = 64, FZ_MAX_TILES_N = 32;
-#ifdef KOD_FZ_STAMPS   // diagnostic build (tools/build_ablate.sh stamps -DKOD_FZ_STAMPS): device clock (100 MHz) at the steps of the
-                       // hand-off, written by the finalizer (gm == 0) and by the last block of channel tile 0 into ws[8 ..] / ws[20 ..]
-#define FZ_STAMP(i) do { if (fnt == 0 && ftid == 0 && (fgm == 0 || fgm == G - 1)) z.ws[(fgm == 0 ? 8 : 20) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define FZ_STAMP_B(i) do { if constexpr (MODE == MODE_RAW_FUSED) { if (nt == 0 && tid == 0 && (gm == 0 || gm == a.groups_m - 1)) a.fz.ws[(gm == 0 ? 8 : 20) + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define FZ_STAMP(i) do { } while (0)
-#define FZ_STAMP_B(i) do { } while (0)
-#endif
-__device__ __forceinline__ unsigned long long fz_ld(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void fz_st(unsigned long long* p, unsigned int tag, unsigned int payload) {
-  __hip_atomic_store(p, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Sum (fp64, index order) of the fp32 payloads of granules p[0 .. n) once every one carries `tag`.  Each pass issues its
-// loads in batches of 8 before it looks at any of them (a dependent load per granule would cost a round trip each).
-__device__ __forceinline__ double fz_poll_sum_f32(const unsigned long long* p, int n, unsigned int tag, long max_spins, bool& bad) {
-  for (long spin = 0;; ++spin) {
-    double s = 0.0;
-    bool ok = true;
-    for (int i = 0; i < n; i += 8) {
-      unsigned long long v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fz_ld(p + (i + j < n ? i + j : n - 1));
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (i + j < n) {
-          ok = ok && (unsigned int)(v[j] >> 32) == tag;
-          s += (double)__uint_as_float((unsigned int)v[j]);
-        }
-    }
-    if (ok) return s;
-    if (spin >= max_spins) { bad = true; return s; }
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
-// the same over fp64 values travelling as two granules each (lo, hi)
-__device__ __forceinline__ double fz_poll_sum_f64(const unsigned long long* p, int n, unsigned int tag, long max_spins, bool& bad) {
-  for (long spin = 0;; ++spin) {
-    double s = 0.0;
-    bool ok = true;
-    for (int i = 0; i < n; i += 4) {
-      unsigned long long v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fz_ld(p + (2 * i + j < 2 * n ? 2 * i + j : 2 * n - 1));
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (i + j < n) {
-          ok = ok && (unsigned int)(v[2 * j] >> 32) == tag && (unsigned int)(v[2 * j + 1] >> 32) == tag;
-          s += __longlong_as_double((long long)((v[2 * j + 1] << 32) | (v[2 * j] & 0xffffffffull)));
-        }
-    }
-    if (ok) return s;
-    if (spin >= max_spins) { bad = true; return s; }
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
 
 // launch bounds: 4 blocks per CU (one wave of each on every SIMD) => at most 128 VGPRs, so that one block's LDS /
 // global phases overlap another block's MFMA phase (measured: the phases of a single block do not overlap)
@@ -219,7 +132,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   static_assert(!ROW3 || (FAST && BM == 128), "ROW3 is a FAST-path form for 128-pixel tiles");
   constexpr int A3_ROWS = BM + 16;                   // ROW3: staged source rows (BM + 2 used)
   static_assert(!STEM || (FAST && BM == 128 && !ROW3 && MODE == MODE_RAW), "STEM is a forward FAST-path form for 128-pixel tiles");
-  static_assert(MODE != MODE_RAW_FUSED || (FAST && !STEM), "the fused forward is a FAST-path form");
   constexpr int AS_ROWS = BM + 64;                   // STEM: staged 16-byte pair rows (BM + 3 used): 3 DMA instructions
   constexpr int STAGE_ELEMS = STEM ? AS_ROWS * 8 + BN * LDS_ROW : (ROW3 ? (A3_ROWS + 3 * BN) * LDS_ROW : (BM + BN) * LDS_ROW);
   constexpr int CS_ROW = BN + 8;            // epilogue staging row (bf16)
@@ -228,13 +140,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   // stage costs 128x128 its 4th block, and measured nothing on the narrow tiles, whose 3x3 layers are bound by the
   // 9x im2col re-read through L2 instead).
   constexpr int NST = (FAST && BM == 256 && !ROW3) ? 3 : 2;
-  // MODE_RAW_FUSED: the staged output tile stays in LDS until the batch statistics are known; the block's partial sums
-  // (NW * BN * 2 floats, then 2 * BN doubles) live behind it
-  constexpr int FZ_TAIL = (MODE == MODE_RAW_FUSED) ? NW * BN * 4 : 0;
-  constexpr int EPI_ELEMS = BM * CS_ROW + FZ_TAIL;
-  constexpr int LDS_ELEMS = (NST * STAGE_ELEMS > EPI_ELEMS) ? NST * STAGE_ELEMS : EPI_ELEMS;
+  constexpr int LDS_ELEMS = (NST * STAGE_ELEMS > BM * CS_ROW) ? NST * STAGE_ELEMS : BM * CS_ROW;
   __shared__ __attribute__((aligned(16))) bf16_t lds[LDS_ELEMS];
-  float* sred = reinterpret_cast<float*>(MODE == MODE_RAW_FUSED ? lds + BM * CS_ROW : lds);     // BN partial statistics reuse the staging area after the tile loop
+  float* sred = reinterpret_cast<float*>(lds);     // BN partial statistics reuse the staging area after the tile loop
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -249,7 +157,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   const int gm = (j / a.tiles_n) * 8 + xcd;
   if (gm >= a.groups_m) return;
   const int n0 = nt * BN;
-  FZ_STAMP_B(7);
 
   // staging assignment
   const int a_chunk = tid & 3;              // which 8-element k chunk of the 32-wide K tile
@@ -699,7 +606,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       }
     };
 
-    FZ_STAMP_B(8);
     if constexpr (STEM) {
       dma_tileS(0);
       for (int kt = 0; kt < nk; ++kt) {
@@ -774,7 +680,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       }
     }
 
-    FZ_STAMP_B(9);
     // ---- epilogue.  acc[i][jj][e]: pixel = wm*WM + jj*32 + (lane&31),
     //      channel = wn*WN + i*32 + 8*(e>>2) + 4*(lane>>5) + (e&3)
     if constexpr (MODE == MODE_HEAD) {
@@ -954,145 +859,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
               ssq[e] += f * f;
             }
           }
-          // (fused forward: the tile leaves the chip only after the statistics hand-off, together with the activated
-          //  tile - stores queued here would sit in this CU's memory pipeline in front of every granule of the hand-off)
-          if constexpr (MODE != MODE_RAW_FUSED) *reinterpret_cast<bf16x8*>(dst) = v;
+          *reinterpret_cast<bf16x8*>(dst) = v;
         }
       }
       __syncthreads();
-      if constexpr (MODE == MODE_RAW_FUSED) {
-        // ---- the block's ONE tile is stored (pre-BN, for the backward pass) and still staged in Cs; its column sums are
-        //      in ssum / ssq.  Statistics hand-off, then BatchNorm + SiLU from LDS (header comment of FuseArgs).
-        const FuseArgs& z = a.fz;
-        // (thread / block indices re-read behind an opaque barrier: otherwise the address arithmetic of this tail is hoisted
-        //  in front of the K loop and spills in the 128-register tiles)
-        int ftid = tid, fgm = gm, fnt = nt;
-        asm volatile("" : "+v"(ftid), "+s"(fgm), "+s"(fnt));
-        const int G = a.groups_m, Gp = (G + 7) & ~7;
-        unsigned long long* part = z.ws + FZ_PART;
-        unsigned long long* gpart = part + (size_t)a.tiles_n * 2 * BN * Gp;
-        const unsigned int tag = (unsigned int)z.ws[FZ_CTR + fnt] + 1u;       // this launch's number (bumped by the tile's finalizer)
-        FZ_STAMP(0);
-#pragma unroll
-        for (int o = CPR; o < 64; o <<= 1)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            ssum[e] += __shfl_xor(ssum[e], o, 64);
-            ssq[e] += __shfl_xor(ssq[e], o, 64);
-          }
-        if (lane < CPR) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            sred[(wave * BN + lane * 8 + e) * 2 + 0] = ssum[e];
-            sred[(wave * BN + lane * 8 + e) * 2 + 1] = ssq[e];
-          }
-        }
-        __syncthreads();
-        const int fch = ftid >> 1, fst = ftid & 1;                 // threads tid < 2 * BN own (channel, statistic)
-        const size_t prow = ((size_t)(fnt * 2 + fst) * BN + fch);
-        bool bad = false;
-        if (ftid < BN * 2) {
-          float sblk = 0.f;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) sblk += sred[(w * BN + fch) * 2 + fst];
-          fz_st(part + prow * Gp + fgm, tag, __float_as_uint(sblk));
-        }
-        FZ_STAMP(1);
-        __syncthreads();                                         // sred is reused below (fp64 totals)
-        double* dtot = reinterpret_cast<double*>(sred);
-        if (fgm % z.S == 0 && ftid < BN * 2) {
-          // level 1: this block sums its group's partials (blocks gm .. gm + S - 1 of the channel tile)
-          const int grp = fgm / z.S;
-          const int cnt = (G - fgm < z.S) ? G - fgm : z.S;
-          double s1 = fz_poll_sum_f32(part + prow * Gp + fgm, cnt, tag, z.max_spins, bad);
-          if (z.NG > 1) {
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(s1);
-            fz_st(gpart + (prow * z.NG + grp) * 2 + 0, tag, (unsigned int)bits);
-            fz_st(gpart + (prow * z.NG + grp) * 2 + 1, tag, (unsigned int)(bits >> 32));
-            if (fgm == 0) s1 = fz_poll_sum_f64(gpart + prow * z.NG * 2, z.NG, tag, z.max_spins, bad);     // level 2
-          }
-          if (fgm == 0) dtot[ftid] = bad ? __longlong_as_double(0x7ff8000000000000ll) : s1;
-        }
-        FZ_STAMP(2);
-        if (fgm == 0) {
-          // the channel tile's finalizer: sums -> BatchNorm constants (arithmetic of bn_finalize_fused_kernel, bn_act.hip)
-          __syncthreads();
-          const int nn = fnt * BN + ftid;
-          if (ftid < BN && nn < a.N) {
-            const double mean = dtot[2 * ftid] / z.count;
-            double var = dtot[2 * ftid + 1] / z.count - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)z.eps));
-            const float sc = z.gamma[nn] * rstd;
-            const float sh = z.beta[nn] - (float)mean * sc;
-            __hip_atomic_store(z.aff + nn, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(z.aff + a.N + nn, sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            z.aff[2 * a.N + nn] = (float)mean;
-            z.aff[3 * a.N + nn] = rstd;
-            if (z.update_running) {
-              const double unbiased = z.count > 1.0 ? var * z.count / (z.count - 1.0) : var;
-              z.rmean[nn] = (1.f - z.momentum) * z.rmean[nn] + z.momentum * (float)mean;
-              z.rvar[nn] = (1.f - z.momentum) * z.rvar[nn] + z.momentum * (float)unbiased;
-            }
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the flag goes up
-          __syncthreads();
-          FZ_STAMP(3);
-          if (ftid == 0) {
-            z.ws[FZ_CTR + fnt] = tag;                             // (plain: read by the NEXT launch, behind a kernel boundary)
-            fz_st(z.ws + FZ_FLAG + fnt, tag, 1u);
-          }
-        }
-        if (ftid == 0) {
-          long spin = 0;
-          while ((unsigned int)(fz_ld(z.ws + FZ_FLAG + fnt) >> 32) != tag) {
-            if (++spin > z.max_spins) { bad = true; break; }
-            __builtin_amdgcn_s_sleep(2);
-          }
-        }
-        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) *z.err = 1;
-        __syncthreads();
-        FZ_STAMP(4);
-        const int fc = ftid % CPR, fr0 = ftid / CPR, fn = fnt * BN + fc * 8;
-        const bool fcol_ok = fn < a.N;
-        float fsc[8], fsh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int nn = (fn + e < a.N) ? fn + e : a.N - 1;
-          fsc[e] = __hip_atomic_load(z.aff + nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          fsh[e] = __hip_atomic_load(z.aff + a.N + nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("" :: "v"(fsc[0]), "v"(fsh[7]));
-        FZ_STAMP(5);
-#pragma unroll
-        for (int p = 0; p < BM / RPP; ++p) {
-          const int row = fr0 + p * RPP;
-          const int m = m0 + row;
-          if (m < a.M && fcol_ok) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS_ROW + fc * 8);
-            bf16x8 o;
-            if (z.res) {
-              const bf16x8 rv = *reinterpret_cast<const bf16x8*>(z.res + (size_t)m * z.ldr + z.rcoff + fn);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {          // arithmetic of bn_silu_apply_kernel (bn_act.hip)
-                const float zz = __builtin_fmaf((float)v[e], fsc[e], fsh[e]);
-                const float sg = kod_sigmoid_l2(KOD_NEG_LOG2E * zz);
-                o[e] = (bf16_t)__builtin_fmaf(zz, sg, (float)rv[e]);
-              }
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float zz = __builtin_fmaf((float)v[e], fsc[e], fsh[e]);
-                o[e] = (bf16_t)(zz * kod_sigmoid_l2(KOD_NEG_LOG2E * zz));
-              }
-            }
-            *reinterpret_cast<bf16x8*>(a.y + (size_t)m * a.ldy + a.ycoff + fn) = v;
-            *reinterpret_cast<bf16x8*>(z.out + (size_t)m * z.ldo + z.ocoff + fn) = o;
-          }
-        }
-        __syncthreads();
-        FZ_STAMP(6);
-      }
       if constexpr (MODE == MODE_PLAIN_BN) {
         // fold this tile's sums into one running value per (channel, statistic), held by thread tid < 2*BN: the
         // 16 per-thread accumulators then live only inside the epilogue, where the MFMA accumulators are dead
@@ -1478,35 +1248,6 @@ Plan plan_conv(const ConvArgs& a, bool fast, bool& row3, int mode) {
   return make_plan(a.M, a.N, a.nk1 ? 2 * a.K : a.K, fast, row3, fold_bn_cap(a));
 }
 
-// Launches of fewer blocks than the chip holds (strides 16 / 32: 100 - 800 tiles for 256 CUs x 2 - 4 resident blocks): the
-// dispatcher fills a CU up to its occupancy before it moves on, so half of the CUs would run 2 - 4 blocks each while the
-// others idle.  A dynamic-LDS pad that lowers the occupancy to ceil(blocks / 256) per CU spreads the grid over all CUs.
-// KODHIP_SPREAD=0 switches it off (A/B).
-template <typename K>
-unsigned spread_pad(K kernel, long active_blocks) {
-  static int mode = -1;
-  if (mode < 0) { const char* e = getenv("KODHIP_SPREAD"); mode = e ? atoi(e) : 1; }
-  if (!mode || active_blocks <= 0) return 0;
-  static const void* known[64];
-  static int known_lds[64], n_known = 0;
-  int st = -1;
-  for (int i = 0; i < n_known; ++i) if (known[i] == (const void*)kernel) st = known_lds[i];
-  if (st < 0) {
-    hipFuncAttributes at;
-    if (hipFuncGetAttributes(&at, (const void*)kernel) != hipSuccess) return 0;
-    st = (int)at.sharedSizeBytes;
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
-    if (n_known < 64) { known[n_known] = (const void*)kernel; known_lds[n_known++] = st; }
-  }
-  const int lds_cu = 160 * 1024;
-  long per_cu = (active_blocks + 255) / 256;
-  if (per_cu > 8) return 0;
-  const int want = lds_cu / (int)(per_cu + 1) + 1024;       // just too large for per_cu + 1 blocks
-  if (want <= st || want > lds_cu / (int)per_cu) return 0;
-  return (unsigned)((want - st + 1023) & ~1023);
-}
-#define KOD_LAUNCH_SPREAD(KERNEL, THREADS, ACTIVE, ARGS) hipLaunchKernelGGL(KERNEL, g, dim3(THREADS), spread_pad(KERNEL, ACTIVE), stream, ARGS)
-
 template <int MODE, bool F32ACC = false>
 int launch(const ConvArgs& a, hipStream_t stream) {
   if constexpr ((MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) && !F32ACC) {
@@ -1548,22 +1289,21 @@ int launch(const ConvArgs& a, hipStream_t stream) {
       return KOD_OK;
     }
   }
-  const long active = (long)p.groups_m * p.tiles_n;
   if constexpr (MODE != MODE_HEAD) {
     if (row3) {
-      if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<128, 2, 2, MODE, F32ACC>), 256, active, args);
-      else if (p.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<64, 2, 2, MODE, F32ACC>), 256, active, args);
-      else KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<32, 4, 1, MODE, F32ACC>), 256, active, args);
+      if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_row3_kernel<128, 2, 2, MODE, F32ACC>), g, dim3(256), 0, stream, args);
+      else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_row3_kernel<64, 2, 2, MODE, F32ACC>), g, dim3(256), 0, stream, args);
+      else hipLaunchKernelGGL((conv_igemm_row3_kernel<32, 4, 1, MODE, F32ACC>), g, dim3(256), 0, stream, args);
       KOD_LAUNCH_CHECK("conv_igemm_row3");
       return KOD_OK;
     }
   }
   if (fast) {
-    if (p.bm == 256 && p.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_kernel<256, 64, 4, 2, MODE, true, F32ACC>), 512, active, args);
-    else if (p.bm == 256) KOD_LAUNCH_SPREAD((conv_igemm_kernel<256, 128, 4, 2, MODE, true, F32ACC>), 512, active, args);
-    else if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 128, 2, 2, MODE, true, F32ACC>), 256, active, args);
-    else if (p.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 64, 2, 2, MODE, true, F32ACC>), 256, active, args);
-    else KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 32, 4, 1, MODE, true, F32ACC>), 256, active, args);
+    if (p.bm == 256 && p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<256, 64, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, args);
+    else if (p.bm == 256) hipLaunchKernelGGL((conv_igemm_kernel<256, 128, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, args);
+    else if (p.bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, args);
+    else if (p.bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, 32, 4, 1, MODE, true, F32ACC>), g, dim3(256), 0, stream, args);
   } else if constexpr (F32ACC) {
     KOD_CHECK_ARG(false, "conv: fp32 accumulation across producers needs the FAST path");
   } else if constexpr (MODE == MODE_PLAIN_BN) {
@@ -1600,82 +1340,12 @@ int launch_x4(ConvArgs c[4], hipStream_t stream) {
   static const bool interleave = getenv("KODHIP_S2_INTERLEAVE") != nullptr;
   p.per_class = pl.grid; p.interleave = interleave;
   dim3 g(pl.grid * 4);
-  if (pl.bm == 256 && pl.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true, F32ACC>), 512, 4l * pl.groups_m * pl.tiles_n, p);
-  else if (pl.bm == 256) KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true, F32ACC>), 512, 4l * pl.groups_m * pl.tiles_n, p);
-  else if (pl.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true, F32ACC>), 256, 4l * pl.groups_m * pl.tiles_n, p);
-  else if (pl.bn == 64) KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<128, 64, 2, 2, MODE, true, F32ACC>), 256, 4l * pl.groups_m * pl.tiles_n, p);
-  else KOD_LAUNCH_SPREAD((conv_igemm_x4_kernel<128, 32, 4, 1, MODE, true, F32ACC>), 256, 4l * pl.groups_m * pl.tiles_n, p);
+  if (pl.bm == 256 && pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 64, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, p);
+  else if (pl.bm == 256) hipLaunchKernelGGL((conv_igemm_x4_kernel<256, 128, 4, 2, MODE, true, F32ACC>), g, dim3(512), 0, stream, p);
+  else if (pl.bn == 128) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 128, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, p);
+  else if (pl.bn == 64) hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 64, 2, 2, MODE, true, F32ACC>), g, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((conv_igemm_x4_kernel<128, 32, 4, 1, MODE, true, F32ACC>), g, dim3(256), 0, stream, p);
   KOD_LAUNCH_CHECK("conv_igemm_x4");
-  return KOD_OK;
-}
-
-// ---- MODE_RAW_FUSED launch: only where every tile of the layer is resident at once (one tile per block, grid within
-// what the chip holds of this kernel) - the blocks wait for each other inside the launch.
-template <typename K>
-int resident_blocks(K kernel, int threads) {
-  int per_cu = 0, dev = 0;
-  hipDeviceProp_t prop;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) return 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  return per_cu * prop.multiProcessorCount;
-}
-
-struct FusePlan { Plan p; bool row3; int S, NG; size_t ws_words; };
-
-// plan + eligibility (no launch).  resident: capacity check against the device (off for host-only queries in tests)
-bool plan_fused(const ConvArgs& a, FusePlan& f) {
-  static const bool off = getenv("KODHIP_NO_FUSE_FWD") != nullptr;
-  if (off || !fast_eligible(a) || a.wide_px != 1) return false;
-  f.p = plan_conv(a, true, f.row3, MODE_RAW);
-  const Plan& p = f.p;
-  if (p.groups_m != p.tiles_m || p.tiles_n > FZ_MAX_TILES_N) return false;         // one tile per block
-  static int cap[6] = {-1, -1, -1, -1, -1, -1};
-  int idx, threads = 256;
-  if (f.row3) idx = p.bn == 128 ? 0 : (p.bn == 64 ? 1 : -1);
-  else if (p.bm == 256) { idx = p.bn == 128 ? 2 : (p.bn == 64 ? 3 : -1); threads = 512; }
-  else idx = p.bn == 128 ? 4 : (p.bn == 64 ? 5 : -1);
-  if (idx < 0) return false;                                                       // (32-column tiles: shallow layers only)
-  if (cap[idx] < 0) {
-    switch (idx) {
-      case 0: cap[idx] = resident_blocks(conv_igemm_row3_kernel<128, 2, 2, MODE_RAW_FUSED>, 256); break;
-      case 1: cap[idx] = resident_blocks(conv_igemm_row3_kernel<64, 2, 2, MODE_RAW_FUSED>, 256); break;
-      case 2: cap[idx] = resident_blocks(conv_igemm_kernel<256, 128, 4, 2, MODE_RAW_FUSED, true>, 512); break;
-      case 3: cap[idx] = resident_blocks(conv_igemm_kernel<256, 64, 4, 2, MODE_RAW_FUSED, true>, 512); break;
-      case 4: cap[idx] = resident_blocks(conv_igemm_kernel<128, 128, 2, 2, MODE_RAW_FUSED, true>, 256); break;
-      default: cap[idx] = resident_blocks(conv_igemm_kernel<128, 64, 2, 2, MODE_RAW_FUSED, true>, 256); break;
-    }
-  }
-  (void)threads;
-  static const bool force = getenv("KODHIP_FUSE_FORCE") != nullptr;          // (tools/fused_census.py: what is resident in fact)
-  if ((long)p.tiles_m * p.tiles_n > cap[idx] && !force) return false;
-  const int G = p.groups_m;
-  int S = 8;
-  while (S * S < G) S += 4;                         // ~sqrt(G), at least 8: both levels poll <= 32 granules per thread
-  if (G <= 32) S = G;
-  f.S = S; f.NG = (G + S - 1) / S;
-  const int Gp = (G + 7) & ~7;
-  f.ws_words = FZ_PART + (size_t)p.tiles_n * 2 * p.bn * Gp + (size_t)p.tiles_n * 2 * p.bn * f.NG * 2;
-  return true;
-}
-
-int launch_fused(const ConvArgs& a, const FusePlan& f, hipStream_t stream) {
-  ConvArgs args = a;
-  const Plan& p = f.p;
-  args.x_bytes = (uint32_t)((long)a.B * a.Hs * a.Ws * a.ldx * 2); args.w_bytes = (uint32_t)((long)a.N * a.Kp * 2);
-  args.tiles_n = p.tiles_n; args.tiles_m = p.tiles_m; args.groups_m = p.groups_m;
-  args.fz.S = f.S; args.fz.NG = f.NG;
-  dim3 g(p.grid);
-  if (f.row3) {
-    if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<128, 2, 2, MODE_RAW_FUSED>), 256, (long)p.groups_m * p.tiles_n, args);
-    else KOD_LAUNCH_SPREAD((conv_igemm_row3_kernel<64, 2, 2, MODE_RAW_FUSED>), 256, (long)p.groups_m * p.tiles_n, args);
-  } else if (p.bm == 256) {
-    if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_kernel<256, 128, 4, 2, MODE_RAW_FUSED, true>), 512, (long)p.groups_m * p.tiles_n, args);
-    else KOD_LAUNCH_SPREAD((conv_igemm_kernel<256, 64, 4, 2, MODE_RAW_FUSED, true>), 512, (long)p.groups_m * p.tiles_n, args);
-  } else {
-    if (p.bn == 128) KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 128, 2, 2, MODE_RAW_FUSED, true>), 256, (long)p.groups_m * p.tiles_n, args);
-    else KOD_LAUNCH_SPREAD((conv_igemm_kernel<128, 64, 2, 2, MODE_RAW_FUSED, true>), 256, (long)p.groups_m * p.tiles_n, args);
-  }
-  KOD_LAUNCH_CHECK("conv_igemm_fused");
   return KOD_OK;
 }
 
@@ -1739,62 +1409,6 @@ int kodhip_conv_fwd_raw(const void* x, const void* w_packed, void* y, float* sta
   a.stats_slots = kodhip_conv_stats_slots(a.M, N);
   a.mul_h = SH; a.mul_w = SW; a.add_h = -PH; a.add_w = -PW; a.tap_sign = 1; a.sh_shift = 0; a.sw_shift = 0;
   return launch<MODE_RAW>(a, stream);
-}
-
-static int prep_fwd(ConvArgs& a, const void* x, const void* w_packed, int B, int H, int W, int ldx, int xcoff, int Cin,
-                    int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp) {
-  a = ConvArgs{};
-  const int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
-  if (int rc = fill_common(a, x, w_packed, B, H, W, ldx, xcoff, Cin, Ho, Wo, N, KH, KW, Kp)) return rc;
-  a.mul_h = SH; a.mul_w = SW; a.add_h = -PH; a.add_w = -PW; a.tap_sign = 1; a.sh_shift = 0; a.sw_shift = 0;
-  return KOD_OK;
-}
-
-// Forward conv + train-mode BatchNorm + SiLU (+ residual) of a unit as ONE launch (MODE_RAW_FUSED, see FuseArgs).
-// kodhip_conv_fwd_bn_silu_ws_bytes: bytes of the workspace a launch of this geometry needs - the caller allocates it,
-// zeroes it ONCE and passes the same workspace to every launch of the unit; 0 = this geometry cannot take the fused form
-// (its tiles are not all resident at once, or it is not on the LDS-DMA path): run kodhip_conv_fwd_raw +
-// kodhip_bn_finalize_partials + kodhip_bn_silu_apply instead.  Needs a device (occupancy query).
-long kodhip_conv_fwd_bn_silu_ws_bytes(int B, int H, int W, int ldx, int Cin, int N, int KH, int KW, int SH, int SW,
-                                      int PH, int PW) {
-  const void* fake = (const void*)64;
-  ConvArgs a;
-  const int Kp = KH * KW * ((Cin + 31) / 32 * 32);
-  if (Cin > ldx || prep_fwd(a, fake, fake, B, H, W, ldx, 0, Cin, N, KH, KW, SH, SW, PH, PW, Kp)) return 0;
-  FusePlan f;
-  if (!plan_fused(a, f)) return 0;
-  return (long)(f.ws_words * 8);
-}
-
-// y_raw[M][ldy] (+ycoff): the pre-BN output (bf16, kept for the backward pass); aff = scale | shift | mean | rstd (4 * N
-// floats); out[M][ldo] (+ocoff) = silu(bn(y_raw)) (+ residual[M][ldr] (+rcoff)).  Statistics over the launch's own M
-// pixels (no SyncBN form).  err_flag: device-visible int, set to 1 if a hand-off inside the launch gave up (the
-// constants are then NaN); max_spins: polls before giving up (0 = default, ~2 s).
-int kodhip_conv_fwd_bn_silu(const void* x, const void* w_packed, void* y_raw, void* workspace,
-                            int B, int H, int W, int ldx, int xcoff, int Cin,
-                            int N, int KH, int KW, int SH, int SW, int PH, int PW, int Kp, int ldy, int ycoff,
-                            const float* gamma, const float* beta, float* running_mean, float* running_var,
-                            float momentum, float eps, float* aff, int update_running,
-                            const void* residual, int ldr, int rcoff, void* out, int ldo, int ocoff,
-                            int* err_flag, long max_spins, hipStream_t stream) {
-  ConvArgs a;
-  if (int rc = prep_fwd(a, x, w_packed, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp)) return rc;
-  KOD_CHECK_ARG(y_raw && workspace && gamma && beta && aff && out && err_flag, "conv_fwd_bn_silu: null pointer");
-  KOD_CHECK_ARG(!update_running || (running_mean && running_var), "conv_fwd_bn_silu: running stats missing");
-  KOD_CHECK_ARG(N % 8 == 0 && ldy % 8 == 0 && ycoff % 8 == 0 && ycoff + N <= ldy, "conv_fwd_bn_silu: bad pre-BN output slice");
-  KOD_CHECK_ARG(ldo % 8 == 0 && ocoff % 8 == 0 && ocoff + N <= ldo, "conv_fwd_bn_silu: bad output slice");
-  KOD_CHECK_ARG(!residual || (ldr % 8 == 0 && rcoff % 8 == 0 && rcoff + N <= ldr), "conv_fwd_bn_silu: bad residual slice");
-  a.y = (bf16_t*)y_raw; a.ldy = ldy; a.ycoff = ycoff;
-  FusePlan f;
-  KOD_CHECK_ARG(plan_fused(a, f), "conv_fwd_bn_silu: this geometry cannot take the fused form (query the workspace bytes first)");
-  FuseArgs& z = a.fz;
-  z.ws = (unsigned long long*)workspace;
-  z.gamma = gamma; z.beta = beta; z.rmean = running_mean; z.rvar = running_var; z.aff = aff;
-  z.momentum = momentum; z.eps = eps; z.count = (double)a.M; z.update_running = update_running;
-  z.res = (const bf16_t*)residual; z.ldr = ldr; z.rcoff = rcoff;
-  z.out = (bf16_t*)out; z.ldo = ldo; z.ocoff = ocoff;
-  z.err = err_flag; z.max_spins = max_spins > 0 ? max_spins : 4000000l;
-  return launch_fused(a, f, stream);
 }
 
 // Fused detection head of one level: out[B][A][Ho*Wo][P] fp32 = 1x1 conv (N = A*(5+nc) packed as

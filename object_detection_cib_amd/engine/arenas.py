@@ -156,9 +156,6 @@ class ArenaMixin:
         self.pack_blocks = blk
         self.exec_units = exec_units
         self.device = device
-        # raised by a fused forward launch whose in-launch hand-off gave up (kodhip_conv_fwd_bn_silu); pinned host memory,
-        # written through its device mapping: check_fused() reads it without a device synchronisation
-        self.fz_err = torch.zeros(4, dtype=torch.int32).pin_memory()
         self.hyper = torch.zeros(12, dtype=torch.float32, device=device)      # lr[3] | momentum[3] | wd[3] | grad scale | nesterov | -
         self.sgd_nesterov = True          # FusedSGD(nesterov=...): smart_sgd.yaml's default, kod/configs/nn/optimizers/smart_sgd.yaml
         # pinned staging ring: the H2D copy is asynchronous, so a slot is not rewritten for the next 15 uploads
@@ -230,14 +227,6 @@ class ArenaMixin:
                                                 self.m_arena.data_ptr(), self.gid.data_ptr(), self.n_arena,
                                                 self.hyper.data_ptr(), self._stream()), "sgd")
         self.param_version += 1
-
-    def check_fused(self):
-        """Raises if a fused forward launch gave up waiting for its own blocks (the grid was not resident after all: the
-        constants of that unit are NaN).  Reads a pinned host word: no device synchronisation; call it behind one to be
-        sure about the steps already queued."""
-        if int(self.fz_err[0]) != 0:
-            raise RuntimeError("libkodhip: a fused conv + BatchNorm launch gave up waiting for its blocks (KODHIP_FUSE_FWD=0 "
-                               "restores the three-launch form)")
 
     def mark_params_changed(self):
         self.param_version += 1

@@ -25,7 +25,7 @@ from .plan import backward_writes, plan_f32_accumulation, plan_dual_dgrads, plan
 class BufferMixin:
     # ------------------------------------------------------------------ activations
     _UNIT_FIELDS = ("stats", "T", "sums", "aff", "bsums", "bsums_g", "bpart", "T2", "coef", "raw", "M", "H", "W", "Ho",
-                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld", "wg_splits", "wg_off", "stem_fused", "wg_dual", "pair", "pair_raw", "fz_ws")
+                    "Wo", "fused_red", "segs", "seg_slots", "raw_ld", "wg_splits", "wg_off", "stem_fused", "wg_dual", "pair", "pair_raw")
     _HEAD_FIELDS = ("H", "W", "M", "dy", "ws", "wg_splits", "wg_off")
 
     def _export_set(self) -> dict:
@@ -106,13 +106,6 @@ class BufferMixin:
             st.bsums = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
             st.bsums_g = torch.empty(2 * u.cout, dtype=torch.float64, device=dev)
             st.coef = torch.empty(3 * u.cout, dtype=torch.float32, device=dev)
-            # conv + statistics + BatchNorm / SiLU apply as one launch where every tile of the layer is resident at once
-            # (kodhip_conv_fwd_bn_silu): the hand-off workspace, zeroed once (its granules carry launch numbers)
-            st.fz_ws = None
-            if self.opt.fuse_fwd and not u.stem:
-                nb = lib.kodhip_conv_fwd_bn_silu_ws_bytes(B, st.H, st.W, u.src.buf.C, u.cin, u.cout, u.k, u.k, u.s, u.s, u.p, u.p)
-                if nb > 0:
-                    st.fz_ws = torch.zeros(nb // 8, dtype=torch.int64, device=dev)
             wgeo = (B, st.H, st.W, 8, 8, u.cout, 6, 3, 2, 1, 2, 1) if u.stem else \
                 (B, st.H, st.W, u.src.buf.C, u.cin, u.cout, u.k, u.k, u.s, u.s, u.p, u.p)
             st.wg_splits = lib.kodhip_conv_wgrad_splits_geo(*wgeo, st.Kp, u.cout)

@@ -76,7 +76,6 @@ class Engine(ArenaMixin, BufferMixin, ForwardMixin, BackwardMixin):
         self.head_stream = None       # side stream of the P3 / P4 head convolutions in forward()
         self.aux_stream = None        # side stream of work that only depends on the step's inputs (label assignment)
         self.branch_overlap = self.opt.branch_overlap
-        self.fz_err = None            # device flag raised by a fused forward launch whose hand-off gave up (check_fused)
         self.profile = None           # list of (family, start_event, end_event, algorithmic bytes), see _t0 / _t1
         # KODHIP_DEBUG_STAMPS=1: device clock stamps at named points of the step, also inside a replayed hipGraph
         # (bench.py stamp_report): stamp_names[i] <-> stamp_buf[i]

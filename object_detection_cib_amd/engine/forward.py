@@ -144,36 +144,6 @@ class ForwardMixin:
             in_px = B * H * W if u.stem else B * st.H * st.W
             self._t1(e0, "conv_fwd", 2 * (in_px * cin_true + st.M * C_), name=u.name)
 
-        def fused_ok(u: ConvUnit, side=False):
-            """conv + batch statistics + BatchNorm / SiLU apply of this unit as one launch (csrc/conv_igemm.hip MODE_RAW_FUSED):
-            training, local statistics, and only one such launch in flight at a time - its blocks wait for each other, so
-            two of them on two streams could each hold part of the chip (side branches: EngineOptions.fuse_fwd == 2)."""
-            return (training and not sync and self.ustate[u.name].fz_ws is not None and
-                    self.ustate[u.name].pair is None and (not side or self.opt.fuse_fwd >= 2))
-
-        def fused_stage(u: ConvUnit, s=s):
-            st, C_ = self.ustate[u.name], u.cout
-            aff, res = st.aff.data_ptr(), u.residual
-            e0 = self._t0()
-            chk(lib.kodhip_conv_fwd_bn_silu(self._ptr(u.src), fp + 2 * st.f_off, st.raw.data_ptr(), st.fz_ws.data_ptr(),
-                                            B, st.H, st.W, u.src.buf.C, u.src.coff, u.cin, C_, u.k, u.k, u.s, u.s, u.p, u.p,
-                                            st.Kp_f, st.raw_ld, 0, pa + 4 * st.g_off, pa + 4 * st.b_off,
-                                            rm + 4 * st.rs_off, rv + 4 * st.rs_off, BN_MOMENTUM, BN_EPS, aff, 1,
-                                            self._ptr(res) if res else None, res.buf.C if res else 0, res.coff if res else 0,
-                                            self._ptr(u.dst), u.dst.buf.C, u.dst.coff, self.fz_err.data_ptr(), 0, s), u.name)
-            self._t1(e0, "conv_fwd+bn_apply", 2 * (B * st.H * st.W * u.cin + 2 * st.M * C_) + (2.0 * st.M * C_ if res else 0.0),
-                     name=u.name)
-
-        def unit_stage(u: ConvUnit, s=s, side=False):
-            """one conv + BatchNorm + SiLU unit: the single fused launch where it applies, else conv -> statistics -> apply"""
-            if fused_ok(u, side):
-                fused_stage(u, s)
-                return
-            conv_stage(u, s)
-            if training:
-                stats_stage([u], s)
-            apply_stage(u, s)
-
         def pair_stage(mu: ConvUnit, su: ConvUnit, s=s):
             """A CSP layer's main_conv + short_conv (same input): one convolution with N = 2 * mid columns, one launch for
             both units' BatchNorm constants, one apply pass writing each half to its own destination slice."""
@@ -306,14 +276,20 @@ class ForwardMixin:
                 # graph executor keeps a node's first captured successor on its queue (see backward())
                 fork = torch.cuda.Event()
                 fork.record(main_stream)
-                unit_stage(op.unit)
+                conv_stage(op.unit)
+                stats_stage([op.unit])
+                apply_stage(op.unit)
                 self.br_stream.wait_event(fork)
                 bs = self.br_stream.cuda_stream
-                unit_stage(short, bs, side=True)
+                conv_stage(short, bs)
+                stats_stage([short], bs)
+                apply_stage(short, bs)
                 joined_buf = short.dst.buf.name
                 continue
             if op.kind == "conv" and op.unit.dst.buf.name in head_src and not (branch and op.unit.sibling is not None):
-                unit_stage(op.unit)
+                conv_stage(op.unit)
+                stats_stage([op.unit])
+                apply_stage(op.unit)
                 ev = torch.cuda.Event()
                 ev.record(main_stream)
                 head_src[op.unit.dst.buf.name] = ev
@@ -327,15 +303,12 @@ class ForwardMixin:
                 if sync and self.peer is None and op.unit.sibling is not None and i < len(ops) and ops[i].unit is op.unit.sibling:
                     group.append(ops[i].unit)
                     i += 1
-                if len(group) == 1:
-                    unit_stage(group[0])
-                else:
-                    for u in group:
-                        conv_stage(u)
-                    if training:
-                        stats_stage(group)
-                    for u in group:
-                        apply_stage(u)
+                for u in group:
+                    conv_stage(u)
+                if training:
+                    stats_stage(group)
+                for u in group:
+                    apply_stage(u)
             elif op.kind == "pool":
                 h, w = H // op.src.stride, W // op.src.stride
                 chk(lib.kodhip_maxpool5_fwd(self._ptr(op.src), op.src.buf.C, op.src.coff, self._ptr(op.dst),

@@ -17,7 +17,7 @@ from typing import Dict
 NATIVE_KNOBS = ("KODHIP_NO_FAST", "KODHIP_FORCE_BM", "KODHIP_FORCE_BN", "KODHIP_S2_SEPARATE", "KODHIP_S2_FOLD_MAXC",
                 "KODHIP_S2_INTERLEAVE", "KODHIP_ROW3", "KODHIP_ROW3_MODES", "KODHIP_WGRAD_DMA", "KODHIP_WGRAD_SLOTS", "KODHIP_WGRAD_ROW3", "KODHIP_STEM_ROW", "KODHIP_STEM_BWD_BLOCKS", "KODHIP_STEM_BWD_TW", "KODHIP_STEM_BWD_STREAM",
                 "KODHIP_PLAN_WIDE96", "KODHIP_WGRAD_TN192", "KODHIP_WGRAD_LINEAR", "KODHIP_WGRAD_ROW3_SLOTS", "KODHIP_DEBUG_STAMPS", "KODHIP_S2F_SKIP", "KODHIP_S2F_BN_CAP",
-                "KODHIP_NO_FUSE_FWD", "KODHIP_LIB")
+                "KODHIP_LIB")
 
 
 def _flag(name: str, default: bool) -> bool:
@@ -44,8 +44,6 @@ class EngineOptions:
     pair_fwd: int = 0                 # KODHIP_PAIR_FWD: a CSP layer's main_conv + short_conv forward as ONE conv launch (N = 2 * mid):
                                       # 0 off (default: measured 1.5 % slower) | 1 one apply launch for both
                                       # halves | 2 the short half's apply on the side stream
-    fuse_fwd: int = 1                 # KODHIP_FUSE_FWD: conv + BatchNorm statistics + apply of a deep unit (every tile resident at once) as ONE
-                                      # launch (kodhip_conv_fwd_bn_silu): 0 off | 1 main-stream units | 2 also the CSP short_conv branches
     stem_bwd_fused: bool = True       # KODHIP_STEM_BWD_FUSED: the stem's BN/SiLU backward inside its weight gradient (dY never written)
     wgrad_reduce_batched: bool = False  # KODHIP_WGRAD_REDUCE=bucket: one slab-reduction launch per gradient bucket (slower: see DESIGN)
     debug_plan: bool = False          # KODHIP_DEBUG_PLAN
@@ -70,7 +68,6 @@ class EngineOptions:
             dx_accum_fp32=_flag("KODHIP_DX_FP32", False),
             dual_wgrad=not _flag("KODHIP_NO_DUAL_WGRAD", False),
             pair_fwd=int(e.get("KODHIP_PAIR_FWD", "0")),
-            fuse_fwd=int(e.get("KODHIP_FUSE_FWD", "1")),
             stem_bwd_fused=_flag("KODHIP_STEM_BWD_FUSED", True),
             wgrad_reduce_batched=e.get("KODHIP_WGRAD_REDUCE", "layer") == "bucket",
             debug_plan=_flag("KODHIP_DEBUG_PLAN", False),

@@ -664,100 +664,3 @@ def test_wgrad_row3_form_on_every_eligible_layer():
                         "-k", "test_conv_fwd_dgrad_wgrad"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "passed" in r.stdout
-
-
-def _three_launch_unit(xb, pk, Cin, Cout, k, s, p, gamma, beta, rm, rv, res, out, ocoff):
-    """conv -> finalize -> apply through the three separate C-ABI calls; returns (raw, aff)"""
-    lib = _lib.lib()
-    raw, stats = conv_fwd_raw(xb, (0, Cin), pk, s, p)
-    M = raw.numel() // Cout
-    T = stats.shape[-1]
-    aff = torch.zeros(4 * Cout, device="cuda")
-    _lib.check(lib.kodhip_bn_finalize_partials(stats.data_ptr(), T, float(M), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
-                                               rv.data_ptr(), 0.03, 1e-3, aff.data_ptr(), aff.data_ptr() + 4 * Cout,
-                                               aff.data_ptr() + 8 * Cout, aff.data_ptr() + 12 * Cout, Cout, 1, stream()), "fin")
-    _lib.check(lib.kodhip_bn_silu_apply(raw.data_ptr(), Cout, aff.data_ptr(), aff.data_ptr() + 4 * Cout,
-                                        res.data_ptr() if res is not None else None, res.shape[-1] if res is not None else 0, 0,
-                                        out.data_ptr(), out.shape[-1], ocoff, M, Cout, stream()), "apply")
-    return raw, aff
-
-
-FUSED_CASES = [
-    # B, Cin, H, W, Cout, k, s, p, residual
-    (64, 512, 20, 20, 256, 1, 1, 0, False),     # stride-32 pointwise (256-pixel tiles, 100 blocks per channel tile: two levels)
-    (64, 256, 20, 20, 256, 3, 1, 1, True),      # CSPBlock conv2 with the residual (ROW3 form, 128-pixel tiles)
-    (64, 128, 40, 40, 128, 1, 1, 0, False),     # stride 16: 800 blocks on one channel tile
-    (64, 256, 40, 40, 512, 3, 2, 1, False),     # stride-2 entry of stage 4: four channel tiles
-    (3, 128, 9, 7, 192, 1, 1, 0, True),         # ragged rows, a half-used channel tile, few blocks (single level)
-    (8, 1024, 20, 20, 512, 1, 1, 0, False),
-]
-
-
-@pytest.mark.parametrize("case", FUSED_CASES)
-def test_conv_fwd_bn_silu_one_launch_equals_three(case):
-    """kodhip_conv_fwd_bn_silu (conv + batch statistics + BatchNorm / SiLU apply in ONE launch, the blocks exchanging
-    their partial sums through tagged granules) against conv_fwd_raw -> bn_finalize_partials -> bn_silu_apply: the
-    pre-BN output bit for bit, the constants to summation order (1e-6), the activated output to one bf16 ulp; launched
-    several times on one workspace (the granule tags are launch numbers) and beside a streaming kernel."""
-    lib = _lib.lib()
-    B, Cin, H, W, Cout, k, s, p, with_res = case
-    nb = lib.kodhip_conv_fwd_bn_silu_ws_bytes(B, H, W, Cin, Cin, Cout, k, k, s, s, p, p)
-    assert nb > 0, "this geometry must take the fused form"
-    g = torch.Generator().manual_seed(7)
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
-    xb = nhwc(x)
-    pk = pack([w])
-    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-    M = B * Ho * Wo
-    gamma = (torch.rand(Cout, generator=g) + 0.5).cuda()
-    beta = (torch.randn(Cout, generator=g) * 0.1).cuda()
-    res = nhwc(torch.randn(B, Cout, Ho, Wo, generator=g)) if with_res else None
-    ld_out, ocoff = Cout + 16, 8                       # the output is a channel slice of a wider buffer
-    rm0, rv0 = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
-    out_ref = torch.zeros(B, Ho, Wo, ld_out, dtype=torch.bfloat16, device="cuda")
-    raw_ref, aff_ref = _three_launch_unit(xb, pk, Cin, Cout, k, s, p, gamma, beta, rm0, rv0, res, out_ref, ocoff)
-    ws = torch.zeros(nb // 8, dtype=torch.int64, device="cuda")
-    err = torch.zeros(4, dtype=torch.int32, device="cuda")
-    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
-    big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
-    side = torch.cuda.Stream()
-    for rep in range(4):
-        raw = torch.zeros(B, Ho, Wo, Cout, dtype=torch.bfloat16, device="cuda")
-        out = torch.zeros(B, Ho, Wo, ld_out, dtype=torch.bfloat16, device="cuda")
-        aff = torch.zeros(4 * Cout, device="cuda")
-        if rep >= 2:                                   # a streaming kernel beside it takes CU slots and memory bandwidth
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                big.add_(1)
-        _lib.check(lib.kodhip_conv_fwd_bn_silu(xb.data_ptr(), pk["f"].data_ptr(), raw.data_ptr(), ws.data_ptr(),
-                                               B, H, W, Cin, 0, Cin, Cout, k, k, s, s, p, p, pk["Kp"], Cout, 0,
-                                               gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.03, 1e-3,
-                                               aff.data_ptr(), 1, res.data_ptr() if with_res else None, Cout if with_res else 0, 0,
-                                               out.data_ptr(), ld_out, ocoff, err.data_ptr(), 0, stream()), "fused")
-        torch.cuda.synchronize()
-        assert int(err[0]) == 0, "a hand-off inside the launch gave up"
-        assert torch.equal(raw, raw_ref), f"rep {rep}: pre-BN output differs"
-        _close(aff, aff_ref, 2e-6, 1e-6, f"rep {rep}: BatchNorm constants")
-        d = (out.float() - out_ref.float()).abs()
-        tol = 2.0 ** -7 * out_ref.float().abs() + 1e-6          # one bf16 ulp where a constant's last bit moved
-        assert (d <= tol).all(), f"rep {rep}: activated output off by {d.max().item()}"
-        assert (d != 0).float().mean().item() < 1e-3
-        assert torch.equal(out[..., :ocoff], torch.zeros_like(out[..., :ocoff])) and torch.equal(out[..., ocoff + Cout:], torch.zeros_like(out[..., ocoff + Cout:]))
-    # running statistics moved four times with the same batch statistics
-    rm_ref, rv_ref = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
-    mean, var = aff_ref[2 * Cout:3 * Cout], 1.0 / aff_ref[3 * Cout:] ** 2 - 1e-3
-    for _ in range(4):
-        rm_ref = 0.97 * rm_ref + 0.03 * mean
-        rv_ref = 0.97 * rv_ref + 0.03 * var * M / (M - 1)
-    _close(rm, rm_ref, 1e-5, 1e-6, "running mean")
-    _close(rv, rv_ref, 1e-4, 1e-6, "running var")
-
-
-def test_conv_fwd_bn_silu_refuses_layers_that_are_not_resident():
-    lib = _lib.lib()
-    assert lib.kodhip_conv_fwd_bn_silu_ws_bytes(64, 160, 160, 64, 64, 64, 1, 1, 1, 1, 0, 0) == 0      # 12 800 tiles
-    assert lib.kodhip_conv_fwd_bn_silu_ws_bytes(64, 40, 40, 256, 256, 256, 1, 1, 1, 1, 0, 0) == 0     # 1 600 tiles of 128 x 128
-    rc = lib.kodhip_conv_fwd_bn_silu(64, 64, 64, 64, 64, 160, 160, 64, 0, 64, 64, 1, 1, 1, 1, 0, 0, 64, 64, 0,
-                                     64, 64, 64, 64, 0.03, 1e-3, 64, 1, None, 0, 0, 64, 64, 0, 64, 0, None)
-    assert rc < 0 and b"fused form" in lib.kodhip_last_error()
