@@ -268,39 +268,63 @@ def augment_hsv_u8(img: np.ndarray, r3: np.ndarray) -> np.ndarray:
 
 # ----------------------------------------------------------------------------- whole-sample protocol
 def augment_sample(canvas, boxes, labels, border, S, rng: np.random.Generator, hsv=(0.015, 0.7, 0.4),
-                   flip_prob=0.5, translate=0.1, scale=0.5):
+                   flip_prob=0.5, translate=0.1, scale=0.5, degrees=0.0, shear=0.0, log=None):
     """TrainSampleAugmentor.__call__ (default.py:440-488) without the four p=0.01 albumentations colour ops
-    (image_color_transforms=False, kod/configs/data/augmentations/no_aug_params.yaml:15)."""
-    draws = affine_draws(rng, translate=translate, scale=scale)
+    (image_color_transforms=False, kod/configs/data/augmentations/no_aug_params.yaml:15).  Draw order of the augmentor's
+    generator: 8 affine uniforms, 3 HSV uniforms (one call), 1 flip draw - the flip draw only when flip_prob > 0
+    (AugParams.should_flip short-circuits, default.py:98-99).  log: dict that receives M / LUTs / flip."""
+    draws = affine_draws(rng, degrees=degrees, translate=translate, scale=scale, shear=shear)
     M, (wo, ho) = affine_matrix(draws, canvas.shape[1], canvas.shape[0], border)
     img = warp_affine_u8(canvas, M[:2], wo, ho)
     if len(labels):
         nb, keep = affine_boxes(boxes, M, wo, ho, draws[3])
         boxes, labels = nb[keep], labels[keep]
-    r3 = rng.uniform(-1, 1, 3) * np.array(hsv) + 1
-    img = augment_hsv_u8(img, r3)
-    if flip_prob > 0.0 and rng.random() < flip_prob:
+    luts = None
+    if not (hsv[0] == 0.0 and hsv[1] == 0.0 and hsv[2] == 0.0):
+        r3 = rng.uniform(-1, 1, 3) * list(hsv) + 1
+        luts = hsv_luts(r3)
+        img = augment_hsv_u8(img, r3)
+    flip = bool(flip_prob > 0.0 and rng.random() < flip_prob)
+    if flip:
         img = np.fliplr(img)
         boxes = flip_boxes(boxes, img.shape[1])
+    if log is not None:
+        log.update(M=M, dsize=(wo, ho), luts=luts, flip=flip)
     chw = np.ascontiguousarray(img.transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0)
     return chw, boxes, labels
 
 
-def train_sample(cache, idx, S, rng: np.random.Generator, mixup_prob=0.0, rnd=random, nprnd=np.random):
-    """DetectionDataset.__getitem__ with mosaic on (detection.py:102-156).  cache: list of (u8 HWC, boxes, labels)."""
-    n = len(cache)
-    indices = [idx] + rnd.choices(range(n), k=3, weights=None)
+def train_sample(cache, idx, S, rng: np.random.Generator, mixup_prob=0.0, rnd=random, nprnd=np.random, weights=None,
+                 sampler_indices=None, aug=None, log=None):
+    """DetectionDataset.__getitem__ with mosaic on (detection.py:102-156).  cache: list of (u8 HWC, boxes, labels);
+    weights / sampler_indices: the sampler's image_repeat_factors / sampler_indices side channel (detection.py:78-80,
+    114-122); aug: keyword overrides of augment_sample (degrees, shear, hsv, flip_prob, ...); log: dict that receives
+    the protocol's intermediate values (what tests/golden/protocol.npz records from the reference)."""
+    pool = range(len(cache)) if sampler_indices is None else sampler_indices
+    aug = aug or {}
+    indices = [idx] + rnd.choices(pool, k=3, weights=weights)
     rnd.shuffle(indices)
     canvas, bb, lb, border, _ = mosaic([cache[i] for i in indices], S, rnd)
-    img, bb, lb = augment_sample(canvas, bb, lb, border, S, rng)
+    l1 = {}
+    mbb = bb
+    img, bb, lb = augment_sample(canvas, bb, lb, border, S, rng, log=l1, **aug)
+    if log is not None:
+        log.update(indices=list(indices), mosaic_boxes=[mbb], stages=[l1], mixup_r=None)
     if rnd.random() < mixup_prob:
-        m_idx = rnd.choices(range(n), k=4, weights=None)
+        m_idx = rnd.choices(pool, k=4, weights=weights)
         canvas2, bb2, lb2, border2, _ = mosaic([cache[i] for i in m_idx], S, rnd)
-        img2, bb2, lb2 = augment_sample(canvas2, bb2, lb2, border2, S, rng)
+        l2 = {}
+        mbb2 = bb2
+        img2, bb2, lb2 = augment_sample(canvas2, bb2, lb2, border2, S, rng, log=l2, **aug)
         r = nprnd.beta(32.0, 32.0)
         import torch
         img = mixup_blend(torch.from_numpy(img), torch.from_numpy(img2), r).numpy()
         bb, lb = np.concatenate((bb, bb2), 0), np.concatenate((lb, lb2), 0)
+        if log is not None:
+            log["indices"] += list(m_idx)
+            log["mosaic_boxes"].append(mbb2)
+            log["stages"].append(l2)
+            log["mixup_r"] = float(r)
     return img, bb, lb
 
 

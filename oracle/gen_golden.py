@@ -318,13 +318,126 @@ def gen_affine_boxes():
     np.savez_compressed(os.path.join(OUT, "affine.npz"), **out)
 
 
+def gen_protocol():
+    """The reference's REAL per-sample data path - DetectionDataset.__getitem__ (kod/data/detection.py:102-156) with the
+    real MosaicAugmentor and TrainSampleAugmentor(rng_seed=51) (kod/data/augmentations/default.py:411-488) - run for 64
+    consecutive samples per configuration over a synthetic pool, with recording stand-ins for cv2 / albumentations
+    (oracle/ref_import.py install_recording).  Stored per sample: the indices read (shuffled mosaic partners, mixup
+    partners), the mosaic's boxes, every affine matrix and output size handed to cv2.warpAffine (+ the CRC of the canvas it
+    was handed), the three HSV look-up tables, the flip outcome, the mixup ratio, final boxes / labels and the CRC of the
+    final image (pixels through the oracle's OpenCV restatement: composition pinned, OpenCV's arithmetic not)."""
+    import datetime
+    import zlib
+    rec = R.Recorder()
+    R.install_recording(rec)
+    D = R.ref("kod.data.augmentations.default")
+    Det = R.ref("kod.data.detection")
+    Mo = R.ref("kod.data.mosaic")
+    C = R.ref("kod.data.cache")
+    AS = R.ref("kod.data.types").AugmentedSample
+    S, n, N = synth.PROTOCOL_S, synth.PROTOCOL_POOL, synth.PROTOCOL_N
+    pool = synth.protocol_pool()
+    samples = [C.SampleInfo(id=str(i), image_path=f"/nowhere/{i}.jpg",
+                            image_metadata=C.ImageMetadata(width=im.shape[1], height=im.shape[0], num_channels=3,
+                                                           mime_type="image/jpeg", size_bytes=1), targets=[])
+               for i, (im, _, _) in enumerate(pool)]
+    ds_info = C.DatasetInfo(name="synthetic", date=datetime.datetime(2023, 1, 1), classes=[str(c) for c in range(10)], samples=samples)
+    flip_fn, beta_fn = D.horizontal_flip, np.random.beta
+
+    def rec_flip(data):
+        rec("flip")
+        return flip_fn(data)
+
+    def rec_beta(a, b):
+        r = beta_fn(a, b)
+        rec("beta", r=float(r))
+        return r
+
+    def reader(sample, letter_box):
+        assert letter_box is False                    # mosaic on => the reader is asked for the un-letter-boxed image
+        i = int(sample.id)
+        rec("read", index=i)
+        im, bb, lb = pool[i]
+        return AS(image=im, bboxes=bb.copy(), labels=lb.copy())
+
+    out = {}
+    D.horizontal_flip, np.random.beta = rec_flip, rec_beta
+    try:
+        for name, (mixup_prob, side, over) in synth.PROTOCOL_CASES.items():
+            hsv = over.get("hsv", (0.015, 0.7, 0.4))
+            params = D.AugParams(affine_params=D.AffineParams(degrees=over.get("degrees", 0.0), shear=over.get("shear", 0.0)),
+                                 hsv_params=D.HSVParams(*hsv), flip_lr_prob=over.get("flip", 0.5), image_color_transforms=False)
+            aug = D.TrainSampleAugmentor(params, rng_seed=51)
+
+            def augmentor(sample, border=(0, 0), _aug=aug):
+                rec("augment", boxes=np.array(sample.bboxes), labels=np.array(sample.labels), border=tuple(border),
+                    canvas_crc=zlib.crc32(np.ascontiguousarray(sample.image).tobytes()))
+                return _aug(sample, border)
+
+            sampler = None
+            if side:
+                w, si = synth.protocol_side_channel()
+                sampler = type("SideChannel", (), dict(image_repeat_factors=w, sampler_indices=si))()
+            ds = Det.DetectionDataset(ds_info, reader, augmentor, enable_ram_cache=False,
+                                      mosaic_augmentor=Mo.MosaicAugmentor(S), mixup_prob=mixup_prob, sampler=sampler)
+            random.seed(2023)
+            np.random.seed(2023)
+            idx = np.full((N, 8), -1, np.int64)
+            Ms = np.full((N, 2, 3, 3), np.nan)
+            dsize = np.zeros((N, 2, 2), np.int64)
+            luts = np.zeros((N, 2, 3, 256), np.uint8)
+            n_lut = np.zeros((N, 2), np.int64)
+            flips = np.full((N, 2), -1, np.int64)
+            rr = np.full(N, np.nan)
+            ccrc = np.zeros((N, 2), np.int64)
+            icrc = np.zeros(N, np.int64)
+            mb, mbn, fb, fl, fn = [], np.zeros((N, 2), np.int64), [], [], np.zeros(N, np.int64)
+            for k in range(N):
+                rec.take()
+                smp = ds[k % n]
+                ev = rec.take()
+                assert smp.image_info is None
+                reads = [p["index"] for e, p in ev if e == "read"]
+                idx[k, :len(reads)] = reads
+                stage = -1
+                for e, p in ev:
+                    if e == "augment":
+                        stage += 1
+                        assert p["border"] == (-S // 2, -S // 2)
+                        mb.append(p["boxes"]); mbn[k, stage] = len(p["boxes"]); ccrc[k, stage] = p["canvas_crc"]
+                        flips[k, stage] = 0
+                    elif e == "warpAffine":
+                        assert p["src_crc"] == ccrc[k, stage] and p["src_shape"] == (2 * S, 2 * S, 3)
+                        M = np.eye(3); M[:2] = p["M"]
+                        Ms[k, stage] = M; dsize[k, stage] = p["dsize"]
+                    elif e == "LUT":
+                        luts[k, stage, n_lut[k, stage]] = p["lut"]; n_lut[k, stage] += 1
+                    elif e == "flip":
+                        flips[k, stage] = 1
+                    elif e == "beta":
+                        rr[k] = p["r"]
+                img = smp.img.numpy() if hasattr(smp.img, "numpy") else np.asarray(smp.img)
+                assert img.dtype == np.float32 and img.shape == (3, S, S)
+                icrc[k] = zlib.crc32(np.ascontiguousarray(img).tobytes())
+                fb.append(_np(smp.target.boxes)); fl.append(_np(smp.target.labels)); fn[k] = len(fl[-1])
+            p = name + "."
+            out.update({p + "indices": idx, p + "M": Ms, p + "dsize": dsize, p + "luts": luts, p + "n_lut": n_lut, p + "flip": flips,
+                        p + "mixup_r": rr, p + "canvas_crc": ccrc, p + "image_crc": icrc,
+                        p + "mosaic_boxes": np.concatenate(mb, 0), p + "mosaic_counts": mbn,
+                        p + "boxes": np.concatenate(fb, 0).astype(np.float64), p + "labels": np.concatenate(fl, 0).astype(np.int64),
+                        p + "counts": fn})
+    finally:
+        D.horizontal_flip, np.random.beta = flip_fn, beta_fn
+    np.savez_compressed(os.path.join(OUT, "protocol.npz"), **out)
+
+
 def main():
     import sys
     assert R.available(), "reference checkout not found"
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])                      # e.g. `python -m oracle.gen_golden gen_iou gen_samplers`
     for fn in (gen_iou, gen_assigner, gen_loss, gen_network, gen_decode_nms, gen_optim, gen_mosaic,
-               gen_affine_boxes, gen_samplers):
+               gen_affine_boxes, gen_samplers, gen_protocol):
         if only and fn.__name__ not in only:
             continue
         try:

@@ -10,7 +10,18 @@ the hot path; they are restated below with torchvision 0.15.2 semantics
 (the version pinned by the reference's requirements.txt:17-18).  ``absl``,
 ``cv2`` and ``albumentations`` are import-only placeholders: any reference
 function that really calls into them (warpAffine, cvtColor, ...) is NOT
-reachable through this shim and stays "parity unpinned".
+reachable through ``install()`` and stays "parity unpinned".
+
+``install_recording()`` (used by ``gen_golden.gen_protocol``) fills those two
+placeholders with RECORDING stand-ins so that the reference's real
+``DetectionDataset.__getitem__`` / ``TrainSampleAugmentor.__call__`` can run
+end to end: every ``cv2`` call is logged with its arguments (the affine
+matrices, output sizes, HSV look-up tables) and the pixel work itself is
+delegated to the oracle's own restatements (``oracle/datapath.py``).  That
+pins everything AROUND the pixels - index draws, mosaic geometry, RNG draw
+order, matrices, LUTs, flips, the mixup ratio, boxes and labels, the order
+in which the stages are composed - to the reference; the pixel arithmetic
+of OpenCV itself stays unpinned.
 """
 from __future__ import annotations
 
@@ -100,10 +111,15 @@ def _placeholder(name: str, **attrs):
     return m
 
 
+_installed = False
+
+
 def install():
     """Register the shim modules and put the reference on sys.path (idempotent)."""
-    if "kod" in sys.modules:
+    global _installed
+    if _installed or "kod" in sys.modules:
         return
+    _installed = True
     sys.dont_write_bytecode = True
     tv = types.ModuleType("torchvision")
     ops = types.ModuleType("torchvision.ops")
@@ -128,3 +144,104 @@ def install():
 def ref(module: str):
     install()
     return importlib.import_module(module)
+
+
+# ----------------------------------------------------------------------------- recording stand-ins (gen_protocol)
+class Recorder:
+    """Event log of one run of the reference's data path: (name, payload) in call order."""
+
+    def __init__(self):
+        self.events = []
+
+    def __call__(self, name, **payload):
+        self.events.append((name, payload))
+
+    def take(self):
+        ev, self.events = self.events, []
+        return ev
+
+
+def install_recording(rec: Recorder):
+    """cv2 / albumentations stand-ins that log what the reference asks of them and hand the pixel work to the oracle's
+    restatements.  Call after install(); idempotent per recorder."""
+    import zlib
+
+    import numpy as np
+
+    install()
+    from oracle import datapath as DP
+
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_LINEAR, cv2.BORDER_CONSTANT, cv2.COLOR_BGR2HSV, cv2.COLOR_HSV2BGR = 1, 0, 40, 54
+
+    def getRotationMatrix2D(angle, center, scale):
+        # OpenCV documentation, cv::getRotationMatrix2D: alpha = scale cos(angle), beta = scale sin(angle) (degrees),
+        # [[alpha, beta, (1 - alpha) cx - beta cy], [-beta, alpha, beta cx + (1 - alpha) cy]]
+        import math
+        a = math.radians(angle)
+        al, be = scale * math.cos(a), scale * math.sin(a)
+        cx, cy = center
+        return np.array([[al, be, (1 - al) * cx - be * cy], [-be, al, be * cx + (1 - al) * cy]], dtype=np.float64)
+
+    def warpAffine(im, M, dsize, borderValue=(0, 0, 0), flags=1, borderMode=0):
+        assert flags == cv2.INTER_LINEAR and borderMode == cv2.BORDER_CONSTANT and tuple(borderValue) == (114, 114, 114)
+        rec("warpAffine", M=np.array(M, dtype=np.float64), dsize=tuple(int(v) for v in dsize),
+            src_shape=tuple(im.shape), src_crc=zlib.crc32(np.ascontiguousarray(im).tobytes()))
+        return DP.warp_affine_u8(im, np.asarray(M, dtype=np.float64), int(dsize[0]), int(dsize[1]), 114)
+
+    def warpPerspective(*a, **k):
+        raise NotImplementedError("perspective warps are not part of the recorded protocol")
+
+    def cvtColor(img, code):
+        rec("cvtColor", code=int(code))
+        return DP.bgr2hsv_u8(img) if code == cv2.COLOR_BGR2HSV else DP.hsv2bgr_u8(img)
+
+    def LUT(ch, lut):
+        rec("LUT", lut=np.array(lut))
+        return np.asarray(lut)[ch]
+
+    cv2.getRotationMatrix2D, cv2.warpAffine, cv2.warpPerspective, cv2.cvtColor, cv2.LUT = \
+        getRotationMatrix2D, warpAffine, warpPerspective, cvtColor, LUT
+    cv2.split = lambda img: tuple(img[..., i] for i in range(img.shape[-1]))
+    cv2.merge = lambda chs: np.stack(chs, -1)
+
+    A = sys.modules["albumentations"]
+
+    class Compose:                       # albumentations.Compose: transforms applied in order to data["image"]
+        def __init__(self, transforms, *a, **k):
+            self.transforms = list(transforms)
+
+        def __call__(self, **data):
+            for t in self.transforms:
+                data = t(**data)
+            return data
+
+    class ToFloat:                       # albumentations ToFloat: img.astype("float32") / max_value
+        def __init__(self, max_value=None, **k):
+            self.max_value = max_value
+
+        def __call__(self, **data):
+            rec("ToFloat", max_value=self.max_value)
+            return dict(data, image=data["image"].astype("float32") / self.max_value)
+
+    class ToTensorV2:                    # albumentations.pytorch.ToTensorV2: torch.from_numpy(img.transpose(2, 0, 1))
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, **data):
+            return dict(data, image=torch.from_numpy(data["image"].transpose(2, 0, 1)))
+
+    def _colour_op(name):
+        class Op:
+            def __init__(self, *a, **k):
+                pass
+
+            def __call__(self, **data):
+                raise NotImplementedError(f"albumentations.{name} is not part of the recorded protocol "
+                                          "(image_color_transforms=False)")
+        return Op
+
+    A.Compose, A.ToFloat = Compose, ToFloat
+    for n in ("Blur", "MedianBlur", "ToGray", "CLAHE"):
+        setattr(A, n, _colour_op(n))
+    sys.modules["albumentations.pytorch"].ToTensorV2 = ToTensorV2

@@ -186,3 +186,27 @@ def dataset_info_spec(n: int, n_classes: int, seed: int):
             tg.append(((float(x1), float(y1), float(x1 + rng.uniform(3, 20)), float(y1 + rng.uniform(3, 15))), classes[c]))
         samples.append((str(1000 + i), tg))
     return {"classes": classes, "samples": samples}
+
+
+# ----------------------------------------------------------------------------- per-sample protocol fixture (tests/golden/protocol.npz)
+PROTOCOL_CASES = {
+    # name: (mixup_prob, sampler side channel, AugParams overrides)
+    "plain": (0.0, False, {}),
+    "mix03": (0.3, False, {}),
+    "mix10": (1.0, False, {}),
+    "rfs03": (0.3, True, {}),                                        # image_repeat_factors + sampler_indices (detection.py:78-80,114-122)
+    "rot": (0.0, False, dict(degrees=10.0, shear=5.0, flip=0.0)),    # all matrix factors live; flip_lr_prob = 0: no flip draw
+    "nohsv": (0.0, False, dict(hsv=(0.0, 0.0, 0.0))),                # HSVParams.should_aug() False: no HSV draws (default.py:359-364)
+}
+PROTOCOL_S, PROTOCOL_POOL, PROTOCOL_N = 64, 12, 64
+
+
+def protocol_pool():
+    """the synthetic sample pool of the protocol fixture (regenerated identically by the tests)"""
+    return source_samples(PROTOCOL_POOL, PROTOCOL_S, seed=9)
+
+
+def protocol_side_channel():
+    """(image_repeat_factors, sampler_indices) of the 'rfs03' case: what a RepeatFactorSampler exposes"""
+    rng = np.random.default_rng(4)
+    return list(rng.uniform(0.5, 3.0, PROTOCOL_POOL)), [int(i) for i in rng.permutation(PROTOCOL_POOL)]

@@ -421,3 +421,54 @@ def test_bench_ranks_under_an_external_launcher_supervise_and_walk_the_ladder():
         assert f"attempt {k} " in err0, err0[-1500:]
     assert "giving up" in err0
     assert not [ln for o in outs for ln in o[0].splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("case", ["plain", "mix03", "mix10", "rfs03", "rot", "nohsv"])
+def test_host_protocol_vs_reference_recording(case):
+    """The PRODUCT's host side of the data protocol (data/host_protocol.HostProtocol: numpy only) against the recording of
+    the reference's real DetectionDataset.__getitem__ + TrainSampleAugmentor (tests/golden/protocol.npz, made by
+    oracle/gen_golden.gen_protocol from the imported reference): mosaic partner / mixup partner indices in the
+    descriptors' tile order, the inverse of every recorded affine matrix, the HSV tables, flip flags, mixup ratios and
+    the final boxes / labels, bit for bit."""
+    import os
+    import random
+    from oracle import synth
+    from object_detection_cib_amd.data.host_protocol import HostProtocol, AugParams, AffineParams, HSVParams, invert_affine
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "protocol.npz"))
+    g = {k[len(case) + 1:]: g[k] for k in g.files if k.startswith(case + ".")}
+    mixup_prob, side, over = synth.PROTOCOL_CASES[case]
+    w, si = synth.protocol_side_channel() if side else (None, None)
+    S, n, N = synth.PROTOCOL_S, synth.PROTOCOL_POOL, synth.PROTOCOL_N
+    pool = synth.protocol_pool()
+    shapes = [im.shape[:2] for im, _, _ in pool]
+    offsets = np.concatenate(([0], np.cumsum([h * w_ * 3 for h, w_ in shapes])[:-1]))
+    aug = AugParams(affine_params=AffineParams(degrees=over.get("degrees", 0.0), shear=over.get("shear", 0.0)),
+                    hsv_params=HSVParams(*over.get("hsv", (0.015, 0.7, 0.4))), flip_lr_prob=over.get("flip", 0.5))
+    random.seed(2023)
+    np.random.seed(2023)
+    host = HostProtocol(shapes, offsets, [b for _, b, _ in pool], [l for _, _, l in pool], S, aug_params=aug,
+                        mixup_prob=mixup_prob, rng_seed=51, image_repeat_factors=w, sampler_indices=si)
+    descs, mix, per = host.batch([k % n for k in range(N)])
+    ob = 0
+    for k in range(N):
+        stages = 2 if g["flip"][k, 1] >= 0 else 1
+        want_idx = [int(i) for i in g["indices"][k] if i >= 0]
+        for st in range(stages):
+            d = descs[k, st]
+            assert [int(np.searchsorted(offsets, t["off"])) for t in d["tile"]] == want_idx[4 * st:4 * st + 4], (case, k, st)
+            assert np.array_equal(d["im"].reshape(2, 3), invert_affine(g["M"][k, st])), (case, k, st)
+            if g["n_lut"][k, st]:
+                assert d["hsv_on"] == 1 and all(np.array_equal(d[f], g["luts"][k, st, c]) for c, f in enumerate(("lut_h", "lut_s", "lut_v")))
+            else:
+                assert d["hsv_on"] == 0
+            assert d["flip"] == g["flip"][k, st] and d["canvas"] == 2 * S
+        if stages == 2:
+            r = g["mixup_r"][k]
+            assert mix[k, 0] == np.float32(r) and mix[k, 1] == np.float32(1 - r)
+        else:
+            assert mix[k, 0] == -1.0 and np.isnan(g["mixup_r"][k])
+        cnt = int(g["counts"][k])
+        bb, lb = per[k]
+        assert np.array_equal(bb, g["boxes"][ob:ob + cnt]) and np.array_equal(lb, g["labels"][ob:ob + cnt]), (case, k)
+        ob += cnt
+    assert ob == len(g["boxes"])

@@ -203,3 +203,63 @@ def test_val_preprocessing_restatement_properties():
     assert out[0, 0, 0] == np.float32(114) / np.float32(255)           # padded border row
     nh, nw, top, left = D.val_geometry(37, 53, 64)
     np.testing.assert_allclose(b, [[1.0 / 53 * nw + left, 2.0 / 37 * nh + top, 30.0 / 53 * nw + left, 20.0 / 37 * nh + top]])
+
+
+def _protocol_case(golden, case):
+    """(mixup_prob, weights, sampler_indices, aug overrides, {field: array}) of one recorded configuration"""
+    g = golden("protocol")
+    mixup_prob, side, over = synth.PROTOCOL_CASES[case]
+    w, si = synth.protocol_side_channel() if side else (None, None)
+    return mixup_prob, w, si, over, {k[len(case) + 1:]: g[k] for k in g.files if k.startswith(case + ".")}
+
+
+@pytest.mark.parametrize("case", list(synth.PROTOCOL_CASES))
+def test_per_sample_protocol_vs_reference(golden, case):
+    """oracle.datapath.train_sample against what the reference's REAL DetectionDataset.__getitem__ +
+    TrainSampleAugmentor(rng_seed=51) did on the same pool and seeds (tests/golden/protocol.npz, recorded through the cv2
+    / albumentations stand-ins of oracle/ref_import.py): per sample the indices read, the mosaic's boxes, every affine
+    matrix, the HSV look-up tables, the flip outcome, the mixup ratio, the final boxes / labels - bit for bit - and the CRC
+    of the final image (the composition of the stages; OpenCV's own pixel arithmetic is the oracle's restatement on
+    both sides)."""
+    import zlib
+    mixup_prob, w, si, over, g = _protocol_case(golden, case)
+    S, n, N = synth.PROTOCOL_S, synth.PROTOCOL_POOL, synth.PROTOCOL_N
+    pool = synth.protocol_pool()
+    aug = {}
+    if "degrees" in over:
+        aug.update(degrees=over["degrees"], shear=over["shear"])
+    if "flip" in over:
+        aug["flip_prob"] = over["flip"]
+    if "hsv" in over:
+        aug["hsv"] = over["hsv"]
+    random.seed(2023)
+    np.random.seed(2023)
+    rng = np.random.default_rng(51)
+    ob = om = 0
+    for k in range(N):
+        log = {}
+        img, bb, lb = datapath.train_sample(pool, k % n, S, rng, mixup_prob=mixup_prob, weights=w, sampler_indices=si,
+                                            aug=aug, log=log)
+        want_idx = [int(i) for i in g["indices"][k] if i >= 0]
+        assert log["indices"] == want_idx, (case, k)
+        for st, stage in enumerate(log["stages"]):
+            cnt = int(g["mosaic_counts"][k, st])
+            assert np.array_equal(log["mosaic_boxes"][st], g["mosaic_boxes"][om:om + cnt]), (case, k, st)
+            om += cnt
+            assert np.array_equal(stage["M"], g["M"][k, st]), (case, k, st)
+            assert tuple(stage["dsize"]) == tuple(g["dsize"][k, st])
+            if stage["luts"] is None:
+                assert g["n_lut"][k, st] == 0
+            else:
+                assert g["n_lut"][k, st] == 3 and all(np.array_equal(stage["luts"][c], g["luts"][k, st, c]) for c in range(3))
+            assert int(stage["flip"]) == g["flip"][k, st]
+        assert (len(log["stages"]) == 2) == bool(g["flip"][k, 1] >= 0)
+        if log["mixup_r"] is None:
+            assert np.isnan(g["mixup_r"][k])
+        else:
+            assert log["mixup_r"] == g["mixup_r"][k]
+        cnt = int(g["counts"][k])
+        assert np.array_equal(bb, g["boxes"][ob:ob + cnt]) and np.array_equal(lb, g["labels"][ob:ob + cnt]), (case, k)
+        ob += cnt
+        assert img.dtype == np.float32 and zlib.crc32(np.ascontiguousarray(img).tobytes()) == g["image_crc"][k], (case, k)
+    assert ob == len(g["boxes"]) and om == len(g["mosaic_boxes"])
