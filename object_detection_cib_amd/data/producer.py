@@ -9,13 +9,15 @@ step rate (a producer THREAD was slower still: the GIL).  The worker owns the th
 `numpy.random`, the augmentor's `default_rng(51)`) for its whole stream of batches, so the stream is bit-identical to the
 in-process one, and it emits only descriptors + boxes through a shared-memory ring: no pixels, no torch, no GPU.
 
-It is started with the `spawn` method - a fresh interpreter, safe before or after this process has initialised the GPU
-(a fork after HIP initialisation is not) - and never touches a GPU itself.  One producer per rank: every rank's stream has
-its own generators, as every DataLoader worker of the reference has.
+It is a plain child process - `python -m object_detection_cib_amd.data.producer`, a fresh interpreter that imports
+numpy and this package's host-side modules only (no torch, not the trainer's `__main__`), safe before or after this
+process has initialised the GPU (a fork after HIP initialisation is not) - and never touches a GPU itself.  Its job
+description travels over stdin (pickle), its results through a shared-memory ring with two counters (single producer,
+single consumer).  One producer per rank: every rank's stream has its own generators, as every DataLoader worker of the
+reference has.  The worker dies with the trainer (PR_SET_PDEATHSIG + a parent check before every slot it fills).
 """
 from __future__ import annotations
 
-import multiprocessing as mp
 from multiprocessing import shared_memory
 from typing import List, Sequence
 
@@ -44,12 +46,26 @@ def _views(buf, base: int, lay: dict, B: int, cap: int):
                 labels=f("labels", np.int64, cap), samples=f("samples", np.int32, cap), counts=f("counts", np.int32, B))
 
 
+CTRL_BYTES = 64          # ring control block: int64 produced | consumed | stop
+
+
+def _ctrl(buf):
+    return np.frombuffer(buf, dtype=np.int64, count=3, offset=0)
+
+
 def _worker(shm_name: str, slots: int, B: int, cap: int, host_args: dict, rng_seed: int, py_seed, np_seed,
-            schedule: List[List[int]], free, filled, stop):
+            schedule: List[List[int]], parent: int):
     import random
+    import time
     from .host_protocol import HostProtocol, pack_targets
     shm = shared_memory.SharedMemory(name=shm_name)
-    parent = os.getppid()
+    try:
+        from multiprocessing import resource_tracker          # the segment belongs to the trainer: it unlinks it
+        resource_tracker.unregister(shm._name, "shared_memory")
+    except Exception:      # noqa: BLE001
+        pass
+    ctrl = _ctrl(shm.buf)
+    gone = lambda: bool(ctrl[2]) or os.getppid() != parent         # (a trainer that was killed cannot raise `stop`)
     try:
         if py_seed is not None:
             random.seed(py_seed)
@@ -58,12 +74,17 @@ def _worker(shm_name: str, slots: int, B: int, cap: int, host_args: dict, rng_se
         host = HostProtocol(rng_seed=rng_seed, **host_args)
         lay = _layout(B, cap)
         for seq, idx in enumerate(schedule):
+            if gone():
+                return
             descs, mix, per_sample = host.batch(idx)
             pt = pack_targets(per_sample)
-            while not free.acquire(timeout=0.2):
-                if stop.is_set() or os.getppid() != parent:       # (a trainer that was killed cannot set `stop`)
+            while seq - int(ctrl[1]) >= slots:                     # ring full: the consumer has not freed the slot yet
+                if gone():
                     return
-            v = _views(shm.buf, (seq % slots) * lay["size"], lay, B, cap)
+                time.sleep(0.0005)
+            if gone():
+                return
+            v = _views(shm.buf, CTRL_BYTES + (seq % slots) * lay["size"], lay, B, cap)
             n = len(pt.labels)
             v["header"][0], v["header"][1], v["header"][2] = seq, n, 1 if n > cap else 0
             n = min(n, cap)
@@ -72,9 +93,26 @@ def _worker(shm_name: str, slots: int, B: int, cap: int, host_args: dict, rng_se
             v["boxes"][:n], v["labels"][:n], v["samples"][:n] = pt.boxes[:n], pt.labels[:n], pt.samples[:n]
             v["counts"][...] = pt.counts
             del v
-            filled.release()
+            ctrl[0] = seq + 1                                      # published after the slot's contents
     finally:
+        del ctrl
         shm.close()
+
+
+def _main():
+    """child entry point: the job description (a pickled dict) arrives on stdin"""
+    import pickle
+    import sys
+    try:
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, 9, 0, 0, 0)      # PR_SET_PDEATHSIG, SIGKILL
+    except Exception:      # noqa: BLE001
+        pass
+    job = pickle.load(sys.stdin.buffer)
+    if os.getppid() != job["parent"]:                  # the trainer died before the death signal was armed
+        return
+    _worker(job["shm"], job["slots"], job["B"], job["cap"], job["host_args"], job["rng_seed"], job["py_seed"], job["np_seed"],
+            job["schedule"], job["parent"])
 
 
 class DescriptorProducer:
@@ -85,30 +123,40 @@ class DescriptorProducer:
 
     def __init__(self, host_args: dict, batch_size: int, schedule: Sequence[Sequence[int]], rng_seed: int = 51, py_seed=None,
                  np_seed=None, max_boxes: int = 16384, slots: int = 4):
+        import pickle
+        import subprocess
+        import sys
         assert all(len(b) == batch_size for b in schedule)
         self.B, self.cap, self.slots = int(batch_size), int(max_boxes), int(slots)
         self.lay = _layout(self.B, self.cap)
-        self.shm = shared_memory.SharedMemory(create=True, size=self.lay["size"] * self.slots)
-        ctx = mp.get_context("spawn")
-        self.free, self.filled, self.stop = ctx.Semaphore(self.slots), ctx.Semaphore(0), ctx.Event()
+        self.shm = shared_memory.SharedMemory(create=True, size=CTRL_BYTES + self.lay["size"] * self.slots)
+        self.ctrl = _ctrl(self.shm.buf)
+        self.ctrl[:] = 0
         self.n, self.seq = len(schedule), 0
-        self.proc = ctx.Process(target=_worker, daemon=True,
-                                args=(self.shm.name, self.slots, self.B, self.cap, host_args, rng_seed, py_seed, np_seed,
-                                      [list(map(int, b)) for b in schedule], self.free, self.filled, self.stop))
-        self.proc.start()
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        self.proc = subprocess.Popen([sys.executable, "-m", "object_detection_cib_amd.data.producer"], stdin=subprocess.PIPE, env=env)
+        job = dict(shm=self.shm.name, slots=self.slots, B=self.B, cap=self.cap, host_args=host_args, rng_seed=rng_seed,
+                   py_seed=py_seed, np_seed=np_seed, schedule=[list(map(int, b)) for b in schedule], parent=os.getpid())
+        try:
+            pickle.dump(job, self.proc.stdin, protocol=pickle.HIGHEST_PROTOCOL)
+            self.proc.stdin.close()
+        except BrokenPipeError:
+            pass
 
     def next(self, timeout: float = 120.0):
         """(descs [B][2], mix [B][2], PackedTargets) of the next batch of the schedule - copies, the slot is free again."""
+        import time
         if self.seq >= self.n:
             raise StopIteration
-        waited = 0.0
-        while not self.filled.acquire(timeout=0.5):
-            waited += 0.5
-            if not self.proc.is_alive():
-                raise RuntimeError(f"the descriptor producer died (exit code {self.proc.exitcode}) before batch {self.seq}")
-            if waited >= timeout:
+        t0 = time.monotonic()
+        while int(self.ctrl[0]) <= self.seq:
+            if self.proc.poll() is not None and int(self.ctrl[0]) <= self.seq:
+                raise RuntimeError(f"the descriptor producer died (exit code {self.proc.returncode}) before batch {self.seq}")
+            if time.monotonic() - t0 >= timeout:
                 raise RuntimeError(f"no batch from the descriptor producer for {timeout:.0f} s")
-        v = _views(self.shm.buf, (self.seq % self.slots) * self.lay["size"], self.lay, self.B, self.cap)
+            time.sleep(0.0002)
+        v = _views(self.shm.buf, CTRL_BYTES + (self.seq % self.slots) * self.lay["size"], self.lay, self.B, self.cap)
         seq, n, overflow = (int(x) for x in v["header"][:3])
         if seq != self.seq:
             raise RuntimeError(f"descriptor ring out of order: slot holds batch {seq}, expected {self.seq}")
@@ -119,18 +167,19 @@ class DescriptorProducer:
                PackedTargets(v["boxes"][:n].copy(), v["labels"][:n].copy(), v["samples"][:n].copy(), v["counts"].copy()))
         del v
         self.seq += 1
-        self.free.release()
+        self.ctrl[1] = self.seq                                    # the slot is free again
         return out
 
     def close(self):
         if self.shm is None:
             return
-        self.stop.set()
-        self.free.release()
-        self.proc.join(5.0)
-        if self.proc.is_alive():
-            self.proc.terminate()
-            self.proc.join(5.0)
+        self.ctrl[2] = 1
+        try:
+            self.proc.wait(5.0)
+        except Exception:          # noqa: BLE001
+            self.proc.kill()
+            self.proc.wait(5.0)
+        self.ctrl = None
         self.shm.close()
         self.shm.unlink()
         self.shm = None
@@ -140,3 +189,7 @@ class DescriptorProducer:
             self.close()
         except Exception:          # noqa: BLE001 - interpreter shutdown
             pass
+
+
+if __name__ == "__main__":
+    _main()

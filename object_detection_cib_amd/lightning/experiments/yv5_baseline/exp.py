@@ -180,7 +180,27 @@ class DefaultYolov5Experiment:
             for b in batches:
                 targets, dets = self.validation_step(b)
                 ev.add_batch(targets, dets)
-        return ev.get_report(self._val_group(), self.val_sync)
+        pg = self._val_group()
+        if pg is not None and self.val_process_group == "auto":
+            self._all_ranks_validate(pg)
+        return ev.get_report(pg, self.val_sync)
+
+    def _all_ranks_validate(self, pg, timeout_s: float = 300.0):
+        """The default cross-rank report ("auto") is a collective: every rank of the data-parallel group must call
+        validate().  A caller that validates on a subset of ranks (set val_process_group = None for that) would otherwise
+        hang in the report's all-reduce with no message; where the group's backend can time a barrier (gloo) it is
+        checked here first and the error says what to change."""
+        import datetime
+        import torch.distributed as dist
+        if dist.get_backend(pg) != "gloo":
+            return
+        try:
+            dist.monitored_barrier(pg, timeout=datetime.timedelta(seconds=timeout_s))
+        except RuntimeError as e:
+            raise RuntimeError("validate(): not every rank of the data-parallel group entered validation within "
+                               f"{timeout_s:.0f} s. The default val_process_group='auto' averages the report over that group "
+                               "(the reference's log_dict(sync_dist=True)); to validate on a subset of ranks set "
+                               "experiment.val_process_group = None.") from e
 
     def _val_group(self):
         pg = self.val_process_group

@@ -468,7 +468,9 @@ def test_bench_under_torch_distributed_run_and_attempt_ladder(die_rank):
     127.0.0.1 --master-port P bench.py --gpus N ...` - on the one GPU of the test box (KODHIP_BENCH_ONE_GPU=1, two ranks):
     the launcher's processes supervise, their children are the ranks (launcher's env contract, agent store rendezvous),
     rank 0 prints the job's one line.  With a rank that dies in attempt 0 (test hook) every supervisor stops its child and
-    the job runs again on the next rung of bench.ATTEMPTS; the line then says which attempt produced it.  The same when a
+    the job runs again on the next rung of bench.ATTEMPTS; the line then says which attempt produced it, carries
+    "degraded": true and what ended the earlier attempt (a crash and a stall are told apart), and the job's exit code is
+    non-zero unless --allow-fallback was given.  The same when a
     rank hangs: no rank reaches a new phase (heartbeat files, bench._beat) for STALL_S seconds."""
     import json
     import socket
@@ -488,15 +490,25 @@ def test_bench_under_torch_distributed_run_and_attempt_ladder(die_rank):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "4", "--size", "256", "--no-cpu-baseline",
-                        "--timeout", "300"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-3000:]
+                        "--timeout", "300"] + (["--allow-fallback"] if die_rank == "hang" else []),
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    # a result measured down the ladder is not a successful run of the job as asked: the supervisors exit EXIT_DEGRADED (the
+    # launcher then reports failure) unless --allow-fallback was given; the line itself is printed either way and says so
+    if die_rank == 1:
+        assert r.returncode != 0, "a degraded result must not look like a successful scaling run"
+    else:
+        assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["launcher"] == "external" and len(d["per_rank_images_per_sec"]) == 2
     assert d["config"]["attempt"] == (0 if die_rank is None else 1)
+    assert d["degraded"] is (die_rank is not None)
     if die_rank is not None:
         assert "attempt 0" in r.stderr and d["config"]["fallback"] == {"KODHIP_BENCH_NO_GRAPH": "1"}
+        assert ("stalled" if die_rank == "hang" else "crashed") in d["earlier_attempts"]
+    else:
+        assert d["earlier_attempts"] is None
     assert np.isfinite(d["final_loss"])
 
 
