@@ -148,18 +148,23 @@ class _Builder:
             cur = out
         self.run(last, self.full(cat), dst)
 
-    def sppf(self, name, src: View, dst: View, cin, cout, mid_channels_scale: float = 0.5):
-        """SPPFBottleneck (sppf.py:14-84), kernel 5: conv2(cat[x, p(x), p(p(x)), p(p(p(x)))]), x = conv1(in)."""
+    def sppf(self, name, src: Optional[View], dst: View, cin, cout, mid_channels_scale: float = 0.5, use_conv_first: bool = True):
+        """SPPFBottleneck (sppf.py:14-84), kernel 5: conv2(cat[x, p(x), p(p(x)), p(p(p(x)))]), x = conv1(in).
+        use_conv_first=False (sppf.py:37-39): no conv1, the module's input IS the first slice of the concat buffer
+        (src = None: the caller takes the returned view as its input)."""
         pre = name + "." if name else ""
         name = name or "_"
-        mid = int(cin * mid_channels_scale)
-        s1 = self.unit(f"{pre}conv1", cin, mid)
+        mid = int(cin * mid_channels_scale) if use_conv_first else cin
+        s1 = self.unit(f"{pre}conv1", cin, mid) if use_conv_first else None
         s2 = self.unit(f"{pre}conv2", 4 * mid, cout)
-        scat = self.buf(f"{name}.cat", src.stride, 4 * mid)
-        self.run(s1, src, View(scat, 0, mid))
+        stride = src.stride if src is not None else dst.stride
+        scat = self.buf(f"{name}.cat", stride, 4 * mid)
+        if s1 is not None:
+            self.run(s1, src, View(scat, 0, mid))
         for q in range(3):
             self.g.ops.append(Op("pool", None, View(scat, q * mid, mid), View(scat, (q + 1) * mid, mid)))
         self.run(s2, self.full(scat), dst)
+        return View(scat, 0, mid)
 
 
 def _backbone(b: _Builder, g: Graph, pre: str, stages, widen_factor: float, deepen_factor: float, stage_dst: dict,
@@ -272,13 +277,18 @@ def build_csp_layer_graph(cin: int, cout: int, expand_ratio: float = 0.5, add_id
     return g
 
 
-def build_sppf_graph(cin: int, cout: int, mid_channels_scale: float = 0.5) -> Graph:
-    """SPPFBottleneck (sppf.py:14-84) with one kernel size 5 and the leading 1x1 conv."""
+def build_sppf_graph(cin: int, cout: int, mid_channels_scale: float = 0.5, use_conv_first: bool = True) -> Graph:
+    """SPPFBottleneck (sppf.py:14-84): kernel size 5 in cascade - which is also what the parallel pools of sizes
+    (5, 9, 13) compute (a stride-1 max-pool of 5 applied j times is a max-pool of 4 j + 1) - with or without the
+    leading 1x1 conv."""
     g = Graph(0, 0)
     b = _Builder(g)
-    x = b.full(b.buf("in", 1, cin))
     y = b.full(b.buf("out", 1, cout))
-    b.sppf("", x, y, cin, cout, mid_channels_scale)
+    if use_conv_first:
+        x = b.full(b.buf("in", 1, cin))
+        b.sppf("", x, y, cin, cout, mid_channels_scale)
+    else:
+        x = b.sppf("", None, y, cin, cout, mid_channels_scale, use_conv_first=False)
     g.inputs, g.outputs = [x], [y]
     return g
 

@@ -115,10 +115,14 @@ class GraphModule(nn.Module):
         if self._engine is None or self._engine_device != dev:
             if dev.type != "cuda":
                 raise RuntimeError(f"{type(self).__name__} (HIP) must be on an MI355X: call .cuda() first; no CPU fallback")
-            eng = Engine(self.graph, dict(self.named_parameters()), dict(self.named_buffers()), self.engine_options)
+            eng = Engine(self.graph, self._engine_params(), dict(self.named_buffers()), self.engine_options)
             eng._build_arenas(dev)
             self._engine, self._engine_device = eng, dev
         return self._engine
+
+    def _engine_params(self):
+        """engine parameter path -> tensor (the module's own parameters; a piece of a fused head adds the absent pieces)"""
+        return dict(self.named_parameters())
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)

@@ -431,13 +431,37 @@ def gen_protocol():
     np.savez_compressed(os.path.join(OUT, "protocol.npz"), **out)
 
 
+def gen_sppf():
+    """kod.nn.layers.sppf.SPPFBottleneck in its three forms (cascade of one kernel size; parallel pools of a kernel-size
+    sequence; without the leading conv): seeded weights, output, input gradient and parameter gradients."""
+    L = R.ref("kod.nn.layers.sppf")
+    N = R.ref("kod.nn.networks.yolov5")
+    A = R.ref("kod.nn.layers.activations")
+    out = {}
+    for name, (cin, cout, ks, first, B, H, W, seed) in synth.sppf_cases().items():
+        torch.manual_seed(seed)
+        m = L.SPPFBottleneck(cin, cout, kernel_sizes=ks, use_conv_first=first, norm_layer=N.Yolov5BatchNorm2d,
+                             activation_layer=A.SiLUInplace).train()
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, cin, H, W, generator=g).requires_grad_(True)
+        y = m(x)
+        w = torch.randn(y.shape, generator=g)
+        (y * w).sum().backward()
+        p = name + "."
+        out[p + "keys"] = np.array(list(m.state_dict().keys()))
+        out[p + "y"], out[p + "dx"] = _np(y), _np(x.grad)
+        for k, v in m.named_parameters():
+            out[p + "param." + k], out[p + "grad." + k] = _np(v), _np(v.grad)
+    np.savez_compressed(os.path.join(OUT, "sppf.npz"), **out)
+
+
 def main():
     import sys
     assert R.available(), "reference checkout not found"
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])                      # e.g. `python -m oracle.gen_golden gen_iou gen_samplers`
     for fn in (gen_iou, gen_assigner, gen_loss, gen_network, gen_decode_nms, gen_optim, gen_mosaic,
-               gen_affine_boxes, gen_samplers, gen_protocol):
+               gen_affine_boxes, gen_samplers, gen_protocol, gen_sppf):
         if only and fn.__name__ not in only:
             continue
         try:

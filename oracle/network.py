@@ -84,19 +84,30 @@ class CSP(nn.Module):                                        # CSPLayer, csp.py:
         return self.last_conv(torch.cat([self.blocks(self.main_conv(x)), self.short_conv(x)], 1))
 
 
-class SPPF(nn.Module):                                       # sppf.py:14-84 (int kernel path)
-    def __init__(self, cin: int, cout: int, k: int = 5):
+class SPPF(nn.Module):                                       # sppf.py:14-84
+    def __init__(self, cin: int, cout: int, k=5, use_conv_first: bool = True, mid_channels_scale: float = 0.5):
+        """k: int = the cascade cat[x, p(x), p(p(x)), p(p(p(x)))] (sppf.py:49-55,74-77); a sequence = parallel pools
+        cat[x, p_k0(x), p_k1(x), ...] (sppf.py:56-63,78-82); use_conv_first=False: no conv1, mid = cin (sppf.py:37-39)"""
         super().__init__()
-        mid = int(cin * 0.5)
-        self.conv1 = cba(cin, mid)
-        self.poolings = nn.MaxPool2d(k, 1, k // 2)
-        self.conv2 = cba(4 * mid, cout)
+        mid = int(cin * mid_channels_scale) if use_conv_first else cin
+        self.conv1 = cba(cin, mid) if use_conv_first else None
+        self.k = k
+        if isinstance(k, int):
+            self.poolings = nn.MaxPool2d(k, 1, k // 2)
+            n = 4
+        else:
+            self.poolings = nn.ModuleList([nn.MaxPool2d(q, 1, q // 2) for q in k])
+            n = len(k) + 1
+        self.conv2 = cba(n * mid, cout)
 
     def forward(self, x):
-        x = self.conv1(x)
-        y1 = self.poolings(x)
-        y2 = self.poolings(y1)
-        return self.conv2(torch.cat([x, y1, y2, self.poolings(y2)], 1))
+        if self.conv1 is not None:
+            x = self.conv1(x)
+        if isinstance(self.k, int):
+            y1 = self.poolings(x)
+            y2 = self.poolings(y1)
+            return self.conv2(torch.cat([x, y1, y2, self.poolings(y2)], 1))
+        return self.conv2(torch.cat([x] + [p(x) for p in self.poolings], 1))
 
 
 class Stage(nn.Module):                                      # backbones/yolov5.py:27-82

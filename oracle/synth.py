@@ -105,6 +105,7 @@ def network_cases():
         "yv5s_64": (0.50, 0.33, 10, 2, 64, 7),
         "yv5s_160": (0.50, 0.33, 10, 2, 160, 2023),
         "yv5s_640": (0.50, 0.33, 10, 2, 640, 2023),
+        "yv5s_416": (0.50, 0.33, 10, 4, 416, 2023),       # the reference's default geometry (kod/configs/data/default.yaml:10): 52 / 26 / 13 maps
     }
 
 
@@ -210,3 +211,9 @@ def protocol_side_channel():
     """(image_repeat_factors, sampler_indices) of the 'rfs03' case: what a RepeatFactorSampler exposes"""
     rng = np.random.default_rng(4)
     return list(rng.uniform(0.5, 3.0, PROTOCOL_POOL)), [int(i) for i in rng.permutation(PROTOCOL_POOL)]
+
+
+def sppf_cases():
+    """name -> (cin, cout, kernel_sizes, use_conv_first, B, H, W, seed): SPPFBottleneck's three forms (sppf.py:27-83)"""
+    return {"k5": (16, 24, 5, True, 2, 12, 10, 31), "k5_9_13": (16, 24, (5, 9, 13), True, 2, 12, 10, 32),
+            "k5_9_13_noconv": (8, 24, (5, 9, 13), False, 2, 12, 10, 33)}

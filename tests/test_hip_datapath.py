@@ -44,6 +44,34 @@ def test_batch_matches_oracle_protocol(S, mixup, seed):
     np.testing.assert_array_equal(p[..., :3], want)
 
 
+@pytest.mark.parametrize("S,degrees,shear,mixup,seed", [(64, 10.0, 5.0, 0.0, 11), (128, 25.0, 0.0, 0.5, 12), (96, 0.0, 8.0, 0.0, 13),
+                                                        (640, 10.0, 5.0, 0.5, 14)])
+def test_rotated_and_sheared_batches_match_oracle(S, degrees, shear, mixup, seed):
+    """AffineParams.degrees / shear switched on (kod/data/augmentations/default.py:31-36,168-181: the reference's defaults
+    are 0, its configs may set them): the general 2 x 3 inverse map through csrc/compose.hip against the oracle's warp
+    (oracle/datapath.warp_affine_u8, the restatement of OpenCV's fixed-point warpAffine) - pixels, boxes and labels bit for
+    bit, also at 640 px.  (The matrices themselves are pinned to the reference by the 'rot' case of protocol.npz.)"""
+    cache = _cache(10, S, seed)
+    idxs = [3, 0, 7, 9, 5, 2] if S < 640 else [3, 0, 7]
+    aug = AugParams(affine_params=AffineParams(degrees=degrees, translate=0.1, scale=0.5, shear=shear, perspective=0.0))
+    random.seed(seed); np.random.seed(seed)
+    rng = np.random.default_rng(51)
+    ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup, aug=dict(degrees=degrees, shear=shear)) for i in idxs]
+    random.seed(seed); np.random.seed(seed)
+    pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda", aug,
+                               mixup_prob=mixup, rng_seed=51)
+    img, _, targets = pipe.make_batch(idxs, out_f32=True)
+    img = img.cpu().numpy()
+    moved = 0
+    for k, (rimg, rbb, rlb) in enumerate(ref):
+        np.testing.assert_array_equal(targets[k].boxes.numpy(), rbb)
+        np.testing.assert_array_equal(targets[k].labels.numpy(), rlb)
+        diff = np.abs(img[k] - rimg)
+        assert diff.max() == 0.0, (k, diff.max(), (diff > 0).mean())
+        moved += int((rimg != np.float32(114 / 255)).any())
+    assert moved == len(idxs)           # (every image shows pool pixels, not only the border value)
+
+
 def test_full_size_properties():
     """640 px, batch 16: finite, in [0,1], deterministic, no-augmentation identity composite."""
     S = 640

@@ -287,7 +287,8 @@ def test_first_epoch_map_vs_cpu_trainer(golden):
         backward as one kernel | two launches} - EngineOptions, no other difference).  The two samples are compared by Welch's
         t (unequal variances): |t| <= 2.5 for mAP, mAP30 and mAP50 (measured about -1.7 for mAP50: 0.061 vs 0.072); every
         single run must stay above 0.4 x the CPU mean (a collapsed run) and below mean + 6 sigma; the z of the HIP mean
-        against the fp32 runs and against the bf16-emulation runs is printed separately.  (Round 4, 24 HIP trajectories on the
+        against the fp32 runs and against the bf16-emulation runs is printed separately, and the latter is held to >= -2
+        (one-sided: the emulation is what the HIP trainer is claimed to match, so a downward drift must fail).  (Round 4, 24 HIP trajectories on the
         final kernels - eight kernel variants + sixteen bf16-ulp draws, profiles/r04_first_epoch_samples.txt: mAP50 0.0689
         against 0.0678 for the twelve emulation runs, t = +0.2, and 0.0764 for the twelve fp32 runs, t = -1.4: the HIP trainer
         sits on the CPU trainer's bf16-storage emulation; what separates both from the fp32 trainer is bf16 storage.)
@@ -374,6 +375,10 @@ def test_first_epoch_map_vs_cpu_trainer(golden):
     for k in ("map", "map30", "map50"):
         i = keys.index(k)
         assert abs(welch[i]) <= 2.5, (k, welch[i], hmean[i], mean[i])
+        # one-sided, against the runs the HIP trainer is CLAIMED to match (the CPU trainer's bf16-storage emulation): a
+        # downward drift of 15 - 20 % that the two-sided test above would let through fails here (ADVICE round 4;
+        # measured about -0.9 for mAP50)
+        assert z_emu[i] >= -2.0, (k, z_emu[i], hmean[i], samples[emu].mean(0)[i])
         assert (runs[:, i] >= 0.4 * mean[i]).all() and (runs[:, i] <= mean[i] + 6 * sd[i]).all(), (k, runs[:, i], mean[i], sd[i])
 
 

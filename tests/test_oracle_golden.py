@@ -263,3 +263,28 @@ def test_per_sample_protocol_vs_reference(golden, case):
         ob += cnt
         assert img.dtype == np.float32 and zlib.crc32(np.ascontiguousarray(img).tobytes()) == g["image_crc"][k], (case, k)
     assert ob == len(g["boxes"]) and om == len(g["mosaic_boxes"])
+
+
+@pytest.mark.parametrize("case", list(synth.sppf_cases()))
+def test_sppf_forms_vs_reference(golden, case):
+    """oracle.network.SPPF in the reference's three forms (kod/nn/layers/sppf.py:27-83: one kernel size = the cascade,
+    a kernel-size sequence = parallel pools, use_conv_first=False) against the reference module's own output and
+    gradients under the same seed (tests/golden/sppf.npz)."""
+    from oracle.network import SPPF
+    g = golden("sppf")
+    cin, cout, ks, first, B, H, W, seed = synth.sppf_cases()[case]
+    torch.manual_seed(seed)
+    m = SPPF(cin, cout, ks, first).train()
+    p = case + "."
+    assert list(m.state_dict().keys()) == [str(k) for k in g[p + "keys"]]
+    for k, v in m.named_parameters():
+        assert np.array_equal(v.detach().numpy(), g[p + "param." + k]), k
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=gen).requires_grad_(True)
+    y = m(x)
+    w = torch.randn(y.shape, generator=gen)
+    (y * w).sum().backward()
+    np.testing.assert_allclose(y.detach().numpy(), g[p + "y"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), g[p + "dx"], rtol=1e-5, atol=1e-6)
+    for k, v in m.named_parameters():
+        np.testing.assert_allclose(v.grad.numpy(), g[p + "grad." + k], rtol=1e-5, atol=1e-6, err_msg=k)
