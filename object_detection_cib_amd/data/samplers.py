@@ -15,28 +15,30 @@ from .filter import filter_dataset
 
 
 class RandomCycleSampler:
-    """samplers.py:17-38: endless shuffled cycle over a list."""
+    """Endless iterator over `data` in shuffled passes (kod/data/samplers.py:17-38).  RNG protocol of the reference: one
+    `torch.randperm(len(data))` when the object is built and one more each time a pass is used up - drawn lazily, by the
+    `next()` that starts the new pass - from `generator` (None = torch's global generator)."""
 
     def __init__(self, data: Sequence[int], generator: Optional[torch.Generator] = None):
-        self.data = data
-        self.length = len(data)
-        self.indices = torch.randperm(self.length, generator=generator)
-        self.current_index = 0
-        self.generator = generator
+        self.data, self.generator = data, generator
+        self._pass = self._draw_pass()
+        self._served = 0                    # items handed out from the current pass
+
+    def _draw_pass(self):
+        return torch.randperm(len(self.data), generator=self.generator).tolist()
+
+    def __len__(self) -> int:
+        return len(self.data)
 
     def __iter__(self):
         return self
 
-    def __len__(self) -> int:
-        return self.length
-
     def __next__(self) -> int:
-        if self.current_index == self.length:
-            self.indices = torch.randperm(self.length, generator=self.generator)
-            self.current_index = 0
-        index = self.data[int(self.indices[self.current_index].item())]
-        self.current_index += 1
-        return index
+        if self._served >= len(self._pass):
+            self._pass, self._served = self._draw_pass(), 0
+        item = self.data[self._pass[self._served]]
+        self._served += 1
+        return item
 
 
 class ClassAwareSampler(Sampler):
