@@ -507,7 +507,7 @@ def supervise_rank(args) -> int:
             signal.signal(sig, lambda *_a, _c=child: (_stop_group(_c), os._exit(143)))
         t_start, t_pub = time.time(), 0.0
         deadline = time.monotonic() + (args.timeout if k == 0 else min(args.timeout, 600.0)) + 30.0
-        mine, verdict = None, None
+        mine, verdict, stalled = None, None, False
         while verdict is None:
             if mine is None and child.poll() is not None:
                 mine = child.returncode
@@ -530,6 +530,7 @@ def supervise_rank(args) -> int:
             elif all(c == "0" for c in codes):
                 verdict = "ok"
             elif time.monotonic() > deadline:
+                stalled = True
                 try:
                     store.set(f"sup/{k}/code/{rank}", "hang")    # every supervisor sees it on its next poll
                 except Exception:
@@ -553,7 +554,7 @@ def supervise_rank(args) -> int:
         _stop_group(child)
         last = mine if mine not in (None, 0) else 1
         # what ended this attempt travels into the next one's JSON line: a crash and a stall are different findings
-        kind = "stalled / hung" if any(c == "hang" for c in codes) else "a rank crashed"
+        kind = "stalled / hung" if (stalled or any(c == "hang" for c in codes)) else "a rank crashed"
         os.environ["KODHIP_BENCH_PREV_FAILURES"] = (os.environ.get("KODHIP_BENCH_PREV_FAILURES", "") + f"attempt {k}: {kind} (rank codes {codes}); ").strip()
         if rank == 0:
             print(f"bench.py --gpus {world}: attempt {k} ({ATTEMPTS[k] or 'as asked'}) failed "

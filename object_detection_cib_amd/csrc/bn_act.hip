@@ -7,6 +7,7 @@
 // constants live in registers; reductions are wavefront shuffles -> LDS -> fixed-order partial slabs
 // (deterministic, no float atomics).
 #include "kodhip_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -262,10 +263,11 @@ __global__ void bn_bwd_coeffs_fused2_kernel(CoefJob j0, CoefJob j1) {
 // The elementwise passes are pure HBM streams: each thread keeps U rows (U x 16 B per operand) in flight before it
 // touches the first one - with a single load per iteration the chip holds too few bytes in flight to cover the
 // HBM latency (measured 3.5-4.5 TB/s; Little's law wants >= 12 MB outstanding for 8 TB/s).
-constexpr int U = 4;
+constexpr int U = 4;          // (the reduce / pair kernels; the two apply passes take it as a template parameter)
 
 // ---------------------------------------------------------------- forward apply
 // out[m][ocoff + c] = silu(y[m][c]*scale[c] + shift[c]) (+ res[m][rcoff + c])
+template <int U>
 __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, int ldy, const float* scale, const float* shift,
                                      const bf16_t* res, int ldr, int rcoff,
                                      bf16_t* out, int ldo, int ocoff, long M, int C, int rows_per_block_iter) {
@@ -438,6 +440,7 @@ __global__ void bn_bwd_coeffs_kernel(const double* sums_local, const double* sum
 }
 
 // dY (bf16, written in place over y) ; optional identity gradient: dI[m][c] (+)= dA[m][c]
+template <int U>
 __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, bf16_t* y, int ldy,
                                          const float* scale, const float* shift, const float* coef,
                                          bf16_t* dI, int ldi, int dicoff, int di_accum,
@@ -490,6 +493,12 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA
     }
   }
 }
+
+// Launch shape of the two apply passes, measured per tensor size in round 5 (tools/bench_bn.py, profiles/r05_bn_apply_sweep.txt):
+// ONE row in flight per thread and many blocks beat four rows per thread and 4 096 blocks on every size (the chip holds the
+// bytes in flight as resident waves instead of as registers: 6.5 M x 32 forward 191 -> 149 us, 1.6 M x 64 backward 134 ->
+// 111 us, 25 600 x 256 7.6 -> 6.2 us); tensors of >= 128 MB take 16 384 blocks, smaller ones 4 096 (more only adds ramp).
+static int apply_grid_cap(long M, int C) { return (M * C * 2 >= (128l << 20)) ? 16384 : 4096; }
 
 struct Geo { int threads, rpb, grid; };
 Geo geo(long M, int C, int max_blocks) {
@@ -632,10 +641,14 @@ int kodhip_bn_silu_apply(const void* y, int ldy, const float* scale, const float
   KOD_CHECK_ARG(y && scale && shift && out && M > 0, "bn_silu_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldo % 8 == 0 && ocoff % 8 == 0 && ocoff + C <= ldo, "bn_silu_apply: bad channel geometry");
   KOD_CHECK_ARG(!residual || (ldr % 8 == 0 && rcoff % 8 == 0 && rcoff + C <= ldr), "bn_silu_apply: bad residual slice");
-  Geo g = geo(M, C, 4096);
+  static int tu = -1, tg = -1;            // A/B knobs: rows in flight per thread (KODHIP_BN_U = 2 | 4 | 8), grid cap (KODHIP_BN_GRID)
+  if (tu < 0) { const char* e = getenv("KODHIP_BN_U"); tu = e ? atoi(e) : 1; const char* f = getenv("KODHIP_BN_GRID"); tg = f ? atoi(f) : 0; }
+  Geo g = geo(M, C, tg ? tg : apply_grid_cap(M, C));
   KOD_CHECK_ARG(ldy % 8 == 0 && ldy >= C, "bn_silu_apply: bad row stride of y");
-  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, ldy, scale, shift,
-                     (const bf16_t*)residual, ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb);
+#define KOD_APPLY(UU) hipLaunchKernelGGL(bn_silu_apply_kernel<UU>, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, ldy, scale, shift, \
+                     (const bf16_t*)residual, ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb)
+  if (tu == 8) KOD_APPLY(8); else if (tu == 2) KOD_APPLY(2); else if (tu == 1) KOD_APPLY(1); else if (tu == 3) KOD_APPLY(3); else KOD_APPLY(4);
+#undef KOD_APPLY
   KOD_LAUNCH_CHECK("bn_silu_apply");
   return KOD_OK;
 }
@@ -698,10 +711,14 @@ int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout,
   KOD_CHECK_ARG(dA && y_inout && scale && shift && coef && M > 0, "bn_silu_bwd_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda, "bn_silu_bwd_apply: bad geometry");
   KOD_CHECK_ARG(!dI || (ldi % 8 == 0 && dicoff % 8 == 0 && dicoff + C <= ldi), "bn_silu_bwd_apply: bad identity slice");
-  Geo g = geo(M, C, 4096);
+  static int tu = -1, tg = -1;
+  if (tu < 0) { const char* e = getenv("KODHIP_BN_U"); tu = e ? atoi(e) : 1; const char* f = getenv("KODHIP_BN_GRID"); tg = f ? atoi(f) : 0; }
+  Geo g = geo(M, C, tg ? tg : apply_grid_cap(M, C));
   KOD_CHECK_ARG(ldy % 8 == 0 && ldy >= C, "bn_silu_bwd_apply: bad row stride of y");
-  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)dA, lda, dacoff,
-                     (bf16_t*)y_inout, ldy, scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb);
+#define KOD_BAPPLY(UU) hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<UU>, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)dA, lda, dacoff, \
+                     (bf16_t*)y_inout, ldy, scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb)
+  if (tu == 8) KOD_BAPPLY(8); else if (tu == 2) KOD_BAPPLY(2); else if (tu == 1) KOD_BAPPLY(1); else if (tu == 3) KOD_BAPPLY(3); else KOD_BAPPLY(4);
+#undef KOD_BAPPLY
   KOD_LAUNCH_CHECK("bn_silu_bwd_apply");
   return KOD_OK;
 }

@@ -14,7 +14,9 @@ def _as_cascade(kernel_sizes) -> bool:
     """True when the configuration is computed by three cascaded 5 x 5 / stride 1 max-pools: kernel_sizes = 5 (the
     cascade itself, sppf.py:49-55) or the parallel pools (5, 9, 13) (sppf.py:56-63) - a stride-1 max-pool of 5 applied
     j times IS the max-pool of 4 j + 1 (-inf padding), values and argmax routing alike."""
-    return kernel_sizes == 5 or tuple(kernel_sizes) == (5, 9, 13)
+    if isinstance(kernel_sizes, int):
+        return kernel_sizes == 5
+    return tuple(kernel_sizes) == (5, 9, 13)
 
 
 class SPPFBottleneck(GraphModule):
@@ -28,7 +30,7 @@ class SPPFBottleneck(GraphModule):
                  activation_layer: Callable[..., nn.Module] = None):
         super().__init__()
         check_norm_act(norm_layer, activation_layer)
-        if not _as_cascade(kernel_sizes if isinstance(kernel_sizes, int) else tuple(kernel_sizes)):
+        if not _as_cascade(kernel_sizes):
             raise NotImplementedError("the HIP SPPF implements kernel_sizes = 5 and the parallel form (5, 9, 13) "
                                       "(both are three cascaded 5 x 5 pools, sppf.py:49-63); other window sizes are not built")
         self.kernel_sizes = kernel_sizes
