@@ -794,6 +794,76 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
   }
 }
 
+// The same reduction with 16-byte accesses: a thread owns FOUR consecutive k of one slab row (K and Kp are multiples of 4, so
+// a quad never crosses rows) for its split lane; per (n, k) the additions and their order are exactly wgrad_reduce_kernel's
+// (four chains over the lane's splits, (s0 + s1) + (s2 + s3), then the eight lanes in order) => bit-identical gradients,
+// a quarter of the load instructions and 4 x the bytes in flight per thread.  KODHIP_WGRAD_REDUCE_V4=0: the scalar kernel.
+constexpr int RED_Q = 32;                // k quads per block (128 consecutive k)
+__global__ __launch_bounds__(256) void wgrad_reduce_v4_kernel(const float* part, float* grad, int splits, int Nfull,
+                                                              int N, int K, int Kp, int Cin, int KK, int stem,
+                                                              float scale, float* grad2 = nullptr, int n_first = 1 << 30) {
+  __shared__ f32x4 sm[RED_L][RED_Q];
+  const int qx = threadIdx.x % RED_Q, sl = threadIdx.x / RED_Q;
+  const int KQ = K >> 2;
+  const long q = (long)blockIdx.x * RED_Q + qx;
+  const long total = (long)N * KQ;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int n = 0, k = 0;
+  if (q < total) {
+    n = (int)(q / KQ);
+    k = (int)(q - (long)n * KQ) * 4;
+    const float* p = part + (size_t)n * Kp + k;
+    const size_t slab = (size_t)Nfull * Kp;
+    f32x4 s0 = s, s1 = s, s2 = s, s3 = s;
+    int i = sl;
+    for (; i + 3 * RED_L < splits; i += 4 * RED_L) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)i * slab);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(i + RED_L) * slab);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(i + 2 * RED_L) * slab);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(i + 3 * RED_L) * slab);
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; i < splits; i += RED_L) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)i * slab);
+    s = (s0 + s1) + (s2 + s3);
+  }
+  sm[sl][qx] = s;
+  __syncthreads();
+  if (sl == 0 && q < total) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < RED_L; ++i) t += sm[i][qx];
+    float* dst = n >= n_first ? grad2 : grad;            // dual form: slab rows n_first .. belong to the second layer
+    if (n >= n_first) n -= n_first;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kk = k + e;
+      if (stem) {
+        const int c = kk & 3, dx = (kk >> 2) & 1, tt = kk >> 3;
+        const int kh = tt / 3, kwp = tt - kh * 3;
+        if (c < 3) dst[(size_t)n * 108 + c * 36 + kh * 6 + 2 * kwp + dx] = t[e] * scale;
+      } else {
+        const int tap = kk / Cin;
+        const int ci = kk - tap * Cin;
+        dst[(size_t)n * Cin * KK + ci * KK + tap] = t[e] * scale;
+      }
+    }
+  }
+}
+
+static int launch_wgrad_reduce(const float* part, float* grad, int splits, int Nfull, int N, int K, int Kp, int Cin, int KK,
+                               int stem, float scale, float* grad2, int n_first, hipStream_t stream) {
+  static int v4 = -1;
+  if (v4 < 0) { const char* e = getenv("KODHIP_WGRAD_REDUCE_V4"); v4 = e ? atoi(e) : 1; }
+  if (v4 && K % 4 == 0 && Kp % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0)
+    hipLaunchKernelGGL(wgrad_reduce_v4_kernel, dim3(cdiv((long)N * (K >> 2), RED_Q)), dim3(256), 0, stream, part, grad, splits, Nfull, N, K,
+                       Kp, Cin, KK, stem, scale, grad2, n_first);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)N * K, RED_K)), dim3(256), 0, stream, part, grad, splits, Nfull, N, K, Kp, Cin,
+                       KK, stem, scale, grad2, n_first);
+  KOD_LAUNCH_CHECK("wgrad_reduce");
+  return KOD_OK;
+}
+
 // ---- the same reduction for MANY layers in one launch.  A training step has ~60 weight gradients; their slab
 // reductions are 5-30 us kernels of a few hundred blocks each (1.0 ms per step as separate launches, mostly launch
 // ramps and tails).  Every layer keeps its own slab region, and ONE launch per gradient bucket reduces them all: block
@@ -1247,11 +1317,8 @@ int kodhip_conv_wgrad(const void* x, const void* dy, float* partials, float* gra
   KOD_CHECK_ARG(n_valid > 0 && n_valid <= N, "conv_wgrad: bad n_valid");
   WgradArgs a;
   if (int rc = wgrad_partial(a, x, dy, partials, B, H, W, ldx, xcoff, Cin, N, KH, KW, SH, SW, PH, PW, Kp, ldy, ycoff, stream)) return rc;
-  int total = n_valid * a.K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, RED_K)), dim3(256), 0, stream,
-                     (const float*)partials, grad, a.splits, N, n_valid, a.K, Kp, stem ? 8 : Cin, KH * KW, stem, scale);
-  KOD_LAUNCH_CHECK("wgrad_reduce");
-  return KOD_OK;
+  return launch_wgrad_reduce((const float*)partials, grad, a.splits, N, n_valid, a.K, Kp, stem ? 8 : Cin, KH * KW, stem, scale,
+                             nullptr, 1 << 30, stream);
 }
 
 // The split-K half alone: fp32 slabs partials[kodhip_conv_wgrad_splits(M, N, Kp)][N][Kp]; kodhip_wgrad_reduce_batched
@@ -1328,10 +1395,7 @@ int kodhip_conv_wgrad_dual(const void* x, const void* dy1, const void* dy2, floa
   else if (tn == 64 && tk == 32) rc = launch_cfg<2, 1, 1, 1>(a, stream);
   else rc = launch_cfg<1, 1, 1, 1>(a, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(2 * N * a.K, RED_K)), dim3(256), 0, stream,
-                     (const float*)partials, grad1, a.splits, 2 * N, 2 * N, a.K, Kp, Cin, 1, 0, scale, grad2, N);
-  KOD_LAUNCH_CHECK("wgrad_reduce (dual)");
-  return KOD_OK;
+  return launch_wgrad_reduce((const float*)partials, grad1, a.splits, 2 * N, 2 * N, a.K, Kp, Cin, 1, 0, scale, grad2, N, stream);
 }
 
 // The stem's BatchNorm/SiLU backward + weight gradient as one kernel (conv_stem_bwd_fused_kernel) followed by the slab
@@ -1381,10 +1445,7 @@ int kodhip_stem_bwd_fused(const void* x, const void* dA, int lda, int dacoff, co
   else if (TW == 160) hipLaunchKernelGGL((conv_stem_bwd_fused_kernel<160, 1>), dim3(blocks), dim3(320), 0, stream, a);
   else hipLaunchKernelGGL((conv_stem_bwd_fused_kernel<80, 1>), dim3(blocks), dim3(320), 0, stream, a);
   KOD_LAUNCH_CHECK("stem_bwd_fused");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(N * 144, RED_K)), dim3(256), 0, stream,
-                     (const float*)partials, grad, blocks, N > 32 ? 64 : 32, N, 144, 160, 8, 18, 1, gscale);
-  KOD_LAUNCH_CHECK("stem_bwd_fused reduce");
-  return KOD_OK;
+  return launch_wgrad_reduce((const float*)partials, grad, blocks, N > 32 ? 64 : 32, N, 144, 160, 8, 18, 1, gscale, nullptr, 1 << 30, stream);
 }
 
 int kodhip_wgrad_reduce_desc_bytes(void) { return (int)sizeof(ReduceDesc); }
