@@ -78,6 +78,7 @@ struct ConvArgs {
   const bf16_t* w2;
   int nk1;
   int wide_px;                 // FAST path: a tap reads Cin = wide_px * ldx channels = wide_px consecutive pixels (stem)
+  int pointwise;               // FAST path: 1x1 / stride 1 / no padding - gather row m is input pixel m (set by the launcher)
   // MODE_PLAIN_BN (stats_slots = slot capacity of every seg_part buffer)
   int nseg, slot_base, slot_used;
   int seg_begin[MAX_SEG], seg_end[MAX_SEG], seg_ldr[MAX_SEG], seg_C[MAX_SEG];
@@ -252,11 +253,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         int m = m0 + row;
         bool valid = m < a.M;
         int mm = valid ? m : 0;
+        int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        if (a.pointwise) {
+          // 1x1 / stride 1 / no padding (39 of the 57 convs and their data gradients): output pixel m reads input pixel m -
+          // no (b, oy, ox) decomposition, no tap masks (the two float-reciprocal divisions and the mask loops below are
+          // most of a tile's set-up, which a one- or two-K-step tile of the shallow layers pays as often as it computes)
+          dvoff[i] = (uint32_t)(((long)mm * a.ldx + a.xcoff + chunk * 8) * 2);
+          dmask[i] = valid ? 1u : 0u;
+          continue;
+        }
         int b, rem, oy, ox;
         fast_divmod(mm, HWo, a.rcp_hwo, b, rem);
         fast_divmod(rem, a.Wo, a.rcp_wo, oy, ox);
         int by = oy * a.mul_h + a.add_h, bx = ox * a.mul_w + a.add_w;
-        int chunk = (lane & 3) ^ ((row >> 2) & 3);
         dvoff[i] = (uint32_t)(((long)(b * HWs + by * a.Ws + bx) * a.ldx + a.xcoff + chunk * 8) * 2);
         // wide pixels (stem: a 32-value K step spans 4 consecutive 8-channel pixel pairs): this lane's 16-byte
         // chunk belongs to pixel bx + chunk*8/ldx, which has its own left/right padding test
@@ -1258,6 +1267,9 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   const bool fast = fast_eligible(a);
   KOD_CHECK_ARG(fast || a.wide_px == 1, "conv: wide-pixel taps need the FAST path");
   args.x_bytes = (uint32_t)xb; args.w_bytes = (uint32_t)wb;
+  static const bool pw_on = !(getenv("KODHIP_POINTWISE") && getenv("KODHIP_POINTWISE")[0] == '0');     // A/B knob
+  args.pointwise = (pw_on && fast && a.KH == 1 && a.KW == 1 && a.mul_h == 1 && a.mul_w == 1 && a.add_h == 0 && a.add_w == 0 &&
+                    a.Ho == a.Hs && a.Wo == a.Ws && a.wide_px == 1 && (a.sh_shift | a.sw_shift) == 0) ? 1 : 0;
   bool row3;
   const Plan p = plan_conv(a, fast, row3, MODE);
   args.tiles_n = p.tiles_n; args.tiles_m = p.tiles_m; args.groups_m = p.groups_m;
