@@ -53,7 +53,7 @@ FAMILY_KERNELS = {
     "conv_fwd": "conv_igemm_kernel / conv_igemm_row3_kernel <MODE_RAW> (forward conv + BN statistics, 57 layers)",
     "dgrad": "conv_igemm[_x4|_row3]_kernel<MODE_PLAIN> (data gradient)",
     "dgrad+bn_reduce": "conv_igemm[_x4|_row3]_kernel<MODE_PLAIN_BN> (data gradient + fused BatchNorm-backward reduction)",
-    "wgrad": "conv_wgrad_dma_kernel + wgrad_reduce_kernel (weight gradient)",
+    "wgrad": "conv_wgrad_dma_kernel + wgrad_reduce_v4_kernel (weight gradient)",
     "bn_silu_apply": "bn_silu_apply_kernel (BatchNorm + SiLU forward, residual add)",
     "bn_silu_bwd_apply": "bn_silu_bwd_apply_kernel (BatchNorm + SiLU backward)",
     "bn_finalize": "bn_finalize_fused_kernel", "bn_bwd_coeffs": "bn_bwd_coeffs_fused_kernel",

@@ -17,7 +17,7 @@ FAMILIES = {   # name -> regex on the demangled kernel name
     "dgrad": r"conv_igemm(_x4)?_kernel<\d+, \d+, \d+, \d+, 1, |conv_igemm_row3_kernel<\d+, \d+, \d+, 1[,>]",
     "dgrad+bn_reduce": r"conv_igemm(_x4)?_kernel<\d+, \d+, \d+, \d+, 3, |conv_igemm_row3_kernel<\d+, \d+, \d+, 3[,>]",
     "wgrad": r"conv_wgrad(_dma|_row3)?_kernel<|conv_stem_bwd_fused_kernel",
-    "wgrad_reduce": r"wgrad_reduce_kernel",
+    "wgrad_reduce": r"wgrad_reduce(_v4)?_kernel",
     "bn_silu_apply": r"bn_silu_apply_kernel",
     "bn_silu_bwd_apply": r"bn_silu_bwd_apply_kernel",
 }
@@ -59,7 +59,7 @@ def family_durations(bench):
     if len(idx) < 8:
         return
     wins = {"eager": tr[idx[-2]:idx[-1]], "replay": tr[idx[len(idx) - 6]:idx[len(idx) - 5]]}
-    fams = dict(FAMILIES); fams["wgrad"] = r"conv_wgrad(_dma|_row3)?_kernel<|conv_stem_bwd_fused_kernel|wgrad_reduce_kernel"
+    fams = dict(FAMILIES); fams["wgrad"] = r"conv_wgrad(_dma|_row3)?_kernel<|conv_stem_bwd_fused_kernel|wgrad_reduce(_v4)?_kernel"
     bt = {r["family"]: r for r in bench.get("families", [])}
     lines = ["family                 launches(bench)  bench event-timed us/launch | rocprof eager step: us/launch (kernels) | rocprof replayed step: us/launch"]
     for fam, pat in fams.items():
