@@ -1,7 +1,7 @@
 """The two BatchNorm / SiLU apply passes at the step's tensor sizes (yv5s, B=64): us and GB/s per launch.
 A/B knobs: KODHIP_BN_U (rows in flight per thread), KODHIP_BN_GRID (grid cap)."""
 import sys, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os; _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [_R, os.path.join(_R, "tests")]
 from object_detection_cib_amd import _lib
 from hip_helpers import stream
 lib = _lib.lib()
