@@ -3,6 +3,7 @@
 // Reference (per sample, in DataLoader workers, numpy / OpenCV):
 //   mosaic   kod/data/mosaic.py:58-132          4 u8 HWC images pasted on a 2S x 2S canvas filled with 114
 //   affine   kod/data/augmentations/default.py:279-320   cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT 114) -> S x S
+//            (or cv2.warpPerspective when a perspective draw is non-zero, default.py:306-313)
 //   hsv      default.py:354-383                 cvtColor(BGR2HSV) -> 3 LUTs -> cvtColor(HSV2BGR) (on RGB data: kept)
 //   flip     default.py:386-397                 np.fliplr
 //   tensor   default.py:433-438,482             ToFloat(255) + HWC->CHW
@@ -25,11 +26,13 @@ struct TileDesc {            // one mosaic tile
 };
 struct SampleDesc {
   TileDesc tile[4];
-  double im[6];              // inverse affine matrix (row major 2x3), as OpenCV computes it
+  double im[6];              // inverse affine matrix (row major 2x3), as OpenCV computes it; persp: rows 0 - 1 of the inverse 3x3
+  double pw[3];              // persp: row 2 of the inverse 3x3 matrix
   unsigned char lut_h[256], lut_s[256], lut_v[256];
   int hsv_on;
   int flip;
   int canvas;                // 2S
+  int persp;                 // 1: cv2.warpPerspective's mapping (default.py:306-313) instead of cv2.warpAffine's
 };
 
 __constant__ short c_tab_dummy;   // (keeps the TU non-empty for some toolchains)
@@ -91,13 +94,27 @@ __device__ __forceinline__ void composite(const unsigned char* pool, const Sampl
                                           const int* sdiv_tab, const int* hdiv_tab, int y, int xo, int S, int out[3]) {
   const int x = d.flip ? S - 1 - xo : xo;
   // cv::warpAffine: X0 = round((M01*y + M02)*1024) + 16, adelta = round(M00*x*1024); coords in 1/32 px
-  const long AB = 1024;
-  long X0 = __double2ll_rn((d.im[1] * y + d.im[2]) * (double)AB) + 16;
-  long Y0 = __double2ll_rn((d.im[4] * y + d.im[5]) * (double)AB) + 16;
-  long ad = __double2ll_rn(d.im[0] * x * (double)AB);
-  long bd = __double2ll_rn(d.im[3] * x * (double)AB);
-  int X = (int)((X0 + ad) >> 5), Y = (int)((Y0 + bd) >> 5);
+  int X, Y;
+  if (d.persp) {
+    // cv::warpPerspective: X0 = M00 x + M01 y + M02, W = M20 x + M21 y + M22 in doubles, W = W ? 32 / W : 0,
+    // X = saturate_cast<int>(clamp(X0 W)) (half to even), source pixel X >> 5 saturated to int16, weights index X & 31
+    const double dx = (double)x, dy = (double)y;
+    const double X0 = (d.im[0] * dx + d.im[1] * dy) + d.im[2];
+    const double Y0 = (d.im[3] * dx + d.im[4] * dy) + d.im[5];
+    double W = (d.pw[0] * dx + d.pw[1] * dy) + d.pw[2];
+    W = W != 0.0 ? 32.0 / W : 0.0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, X0 * W)), fY = fmax(-2147483648.0, fmin(2147483647.0, Y0 * W));
+    X = (int)__double2ll_rn(fX); Y = (int)__double2ll_rn(fY);
+  } else {
+    const long AB = 1024;
+    long X0 = __double2ll_rn((d.im[1] * y + d.im[2]) * (double)AB) + 16;
+    long Y0 = __double2ll_rn((d.im[4] * y + d.im[5]) * (double)AB) + 16;
+    long ad = __double2ll_rn(d.im[0] * x * (double)AB);
+    long bd = __double2ll_rn(d.im[3] * x * (double)AB);
+    X = (int)((X0 + ad) >> 5); Y = (int)((Y0 + bd) >> 5);
+  }
   int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+  if (d.persp) { sx = min(max(sx, -32768), 32767); sy = min(max(sy, -32768), 32767); }
   const short* w = tab + (fy * 32 + fx) * 4;
   // each of the four taps is resolved to its source pixel ONCE (not once per channel), and its three channel bytes come
   // with ONE unaligned 4-byte load (the pool carries 4 bytes of slack behind the last image: kodhip_compose_batch's contract)

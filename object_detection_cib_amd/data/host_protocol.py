@@ -5,7 +5,7 @@ compositing descriptor per sample for the HIP kernel (csrc/compose.hip).  Mirror
   DetectionDataset.__getitem__          kod/data/detection.py:102-156
   MosaicAugmentor.__call__              kod/data/mosaic.py:51-161
   TrainSampleAugmentor.__call__         kod/data/augmentations/default.py:440-488
-  random_perspective / boxes / flip     kod/data/augmentations/default.py:111-351,386-397
+  random_perspective / boxes / flip     kod/data/augmentations/default.py:111-351,386-397 (affine and perspective warps)
   mixup                                 kod/data/augmentations/default.py:400-408
 data/device_pipeline.py runs HostProtocol in-process and owns the device half; data/producer.py runs it in a worker process.
 """
@@ -110,11 +110,13 @@ def invert_affine(M):
     return m
 
 
-def affine_boxes(boxes, M, w_out, h_out, scale):
+def affine_boxes(boxes, M, w_out, h_out, scale, perspective: bool = False):
+    """_process_affine_bboxes + _box_candidates (default.py:249-276,323-345); perspective: the corners' divide by w"""
     n = len(boxes)
     xy = np.ones((n * 4, 3))
     xy[:, :2] = boxes[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)
-    xy = (xy @ M.T)[:, :2].reshape(n, 8)
+    xy = xy @ M.T
+    xy = (xy[:, :2] / xy[:, 2:3] if perspective else xy[:, :2]).reshape(n, 8)
     x, y = xy[:, [0, 2, 4, 6]], xy[:, [1, 3, 5, 7]]
     nb = np.concatenate((x.min(1), y.min(1), x.max(1), y.max(1))).reshape(4, n).T
     nb[:, [0, 2]] = nb[:, [0, 2]].clip(0, w_out - 1)
@@ -124,8 +126,8 @@ def affine_boxes(boxes, M, w_out, h_out, scale):
 
 _TILE = np.dtype([("off", "<i8"), ("h", "<i4"), ("w", "<i4"), ("x1a", "<i4"), ("y1a", "<i4"), ("x2a", "<i4"),
                   ("y2a", "<i4"), ("x1b", "<i4"), ("y1b", "<i4")], align=True)
-SAMPLE_DESC = np.dtype([("tile", _TILE, (4,)), ("im", "<f8", (6,)), ("lut_h", "u1", (256,)), ("lut_s", "u1", (256,)),
-                        ("lut_v", "u1", (256,)), ("hsv_on", "<i4"), ("flip", "<i4"), ("canvas", "<i4")], align=True)
+SAMPLE_DESC = np.dtype([("tile", _TILE, (4,)), ("im", "<f8", (6,)), ("pw", "<f8", (3,)), ("lut_h", "u1", (256,)), ("lut_s", "u1", (256,)),
+                        ("lut_v", "u1", (256,)), ("hsv_on", "<i4"), ("flip", "<i4"), ("canvas", "<i4"), ("persp", "<i4")], align=True)
 
 
 def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas: int, border, always_warp: bool = False):
@@ -134,8 +136,7 @@ def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas:
     matrix, HSV LUTs, flip flag) into the compositing descriptor and returns the transformed boxes / labels and the
     output image side."""
     ap = aug.affine_params
-    if ap.perspective != 0.0:
-        raise NotImplementedError("perspective warps are not on the HIP path (reference default is 0)")
+    desc["persp"] = 0
     if not always_warp and ap.degrees == 0.0 and ap.translate == 0.0 and ap.scale == 0.0 and ap.shear == 0.0:
         # AffineParams.should_aug() is False (default.py:38-48,445-457): no draws, no warp, the image keeps its size
         wo = ho = canvas
@@ -146,9 +147,14 @@ def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas:
                  rng.uniform(-ap.shear, ap.shear), rng.uniform(-ap.shear, ap.shear),
                  rng.uniform(0.5 - ap.translate, 0.5 + ap.translate), rng.uniform(0.5 - ap.translate, 0.5 + ap.translate))
         M, wo, ho = affine_matrix(draws, canvas, canvas, border)
-        desc["im"] = invert_affine(M).reshape(-1)
+        persp = draws[0] != 0 or draws[1] != 0            # default.py:306-320: cv2.warpPerspective iff a perspective draw is non-zero
+        if persp:
+            inv = np.linalg.inv(M)                        # (cv2.warpPerspective inverts the 3 x 3 matrix; oracle/datapath.py does the same call)
+            desc["im"], desc["pw"], desc["persp"] = inv[:2].reshape(-1), inv[2], 1
+        else:
+            desc["im"] = invert_affine(M).reshape(-1)
         if len(lb):
-            nb, keep = affine_boxes(bb, M, wo, ho, draws[3])
+            nb, keep = affine_boxes(bb, M, wo, ho, draws[3], perspective=persp)
             bb, lb = nb[keep], lb[keep]
     hp = aug.hsv_params
     if hp.hue == 0.0 and hp.saturation == 0.0 and hp.value == 0.0:

@@ -126,6 +126,22 @@ def affine_boxes(boxes: np.ndarray, M: np.ndarray, w_out: int, h_out: int, scale
     return nb, keep
 
 
+def perspective_boxes(boxes: np.ndarray, M: np.ndarray, w_out: int, h_out: int, scale: float):
+    """_process_affine_bboxes(perspective=True) + _box_candidates (default.py:249-276,323-345): corners through the full
+    3 x 3 matrix with the perspective divide."""
+    n = len(boxes)
+    xy = np.ones((n * 4, 3))
+    xy[:, :2] = boxes[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)
+    xy = xy @ M.T
+    xy = (xy[:, :2] / xy[:, 2:3]).reshape(n, 8)
+    x, y = xy[:, [0, 2, 4, 6]], xy[:, [1, 3, 5, 7]]
+    nb = np.concatenate((x.min(1), y.min(1), x.max(1), y.max(1))).reshape(4, n).T
+    nb[:, [0, 2]] = nb[:, [0, 2]].clip(0, w_out - 1)
+    nb[:, [1, 3]] = nb[:, [1, 3]].clip(0, h_out - 1)
+    keep = _candidates(boxes.T * scale, nb.T, eps=1e-16)
+    return nb, keep
+
+
 def flip_boxes(boxes: np.ndarray, width: int):
     """horizontal_flip (default.py:386-397)."""
     out = boxes.copy()
@@ -184,6 +200,42 @@ def warp_affine_u8(src: np.ndarray, M23: np.ndarray, w_out: int, h_out: int, bor
            + fetch(sy + 1, sx) * wts[..., 2:3] + fetch(sy + 1, sx + 1) * wts[..., 3:4])
     out[:] = ((acc + (1 << 14)) >> 15).astype(np.uint8)
     return out
+
+
+def warp_perspective_u8(src: np.ndarray, M33: np.ndarray, w_out: int, h_out: int, border_value: int = 114):
+    """cv2.warpPerspective(src, M, (w_out, h_out), borderValue=114) (default flags: INTER_LINEAR, BORDER_CONSTANT) for u8 HWC.
+
+    OpenCV imgwarp.cpp (WarpPerspectiveInvoker): M is inverted (here: numpy.linalg.inv, the same call on the product's host
+    side); per destination pixel, in doubles, X0 = M00 x + M01 y + M02, Y0 likewise, W = M20 x + M21 y + M22;
+    W = W ? 32 / W : 0; X = saturate_cast<int>(clamp(X0 W)), Y likewise (cvRound: half to even); source pixel
+    (X >> 5, Y >> 5) saturated to int16, bilinear weights from the same 32 x 32 fixed-point table as warpAffine.
+    PARITY UNPINNED like warp_affine_u8 (and OpenCV evaluates the three sums block-wise: the last bit of X0 W may differ)."""
+    iM = np.linalg.inv(np.asarray(M33, dtype=np.float64))
+    xs = np.arange(w_out, dtype=np.float64)[None, :]
+    ys = np.arange(h_out, dtype=np.float64)[:, None]
+    X0 = (iM[0, 0] * xs + iM[0, 1] * ys) + iM[0, 2]
+    Y0 = (iM[1, 0] * xs + iM[1, 1] * ys) + iM[1, 2]
+    W = (iM[2, 0] * xs + iM[2, 1] * ys) + iM[2, 2]
+    with np.errstate(divide="ignore"):
+        W = np.where(W != 0, 32.0 / W, 0.0)
+    lim = lambda v: np.maximum(-2147483648.0, np.minimum(2147483647.0, v))
+    X = np.rint(lim(X0 * W)).astype(np.int64)
+    Y = np.rint(lim(Y0 * W)).astype(np.int64)
+    sx = np.clip(X >> 5, -32768, 32767)
+    sy = np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    wts = _bilinear_tab()[fy, fx]
+    h, w = src.shape[:2]
+
+    def fetch(yy, xx):
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        v = src[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)].astype(np.int64)
+        v[~ok] = border_value
+        return v
+
+    acc = (fetch(sy, sx) * wts[..., 0:1] + fetch(sy, sx + 1) * wts[..., 1:2]
+           + fetch(sy + 1, sx) * wts[..., 2:3] + fetch(sy + 1, sx + 1) * wts[..., 3:4])
+    return ((acc + (1 << 14)) >> 15).astype(np.uint8)
 
 
 _TAB = None
@@ -268,16 +320,17 @@ def augment_hsv_u8(img: np.ndarray, r3: np.ndarray) -> np.ndarray:
 
 # ----------------------------------------------------------------------------- whole-sample protocol
 def augment_sample(canvas, boxes, labels, border, S, rng: np.random.Generator, hsv=(0.015, 0.7, 0.4),
-                   flip_prob=0.5, translate=0.1, scale=0.5, degrees=0.0, shear=0.0, log=None):
+                   flip_prob=0.5, translate=0.1, scale=0.5, degrees=0.0, shear=0.0, perspective=0.0, log=None):
     """TrainSampleAugmentor.__call__ (default.py:440-488) without the four p=0.01 albumentations colour ops
     (image_color_transforms=False, kod/configs/data/augmentations/no_aug_params.yaml:15).  Draw order of the augmentor's
     generator: 8 affine uniforms, 3 HSV uniforms (one call), 1 flip draw - the flip draw only when flip_prob > 0
     (AugParams.should_flip short-circuits, default.py:98-99).  log: dict that receives M / LUTs / flip."""
-    draws = affine_draws(rng, degrees=degrees, translate=translate, scale=scale, shear=shear)
+    draws = affine_draws(rng, degrees=degrees, translate=translate, scale=scale, shear=shear, perspective=perspective)
     M, (wo, ho) = affine_matrix(draws, canvas.shape[1], canvas.shape[0], border)
-    img = warp_affine_u8(canvas, M[:2], wo, ho)
+    persp = draws[0] != 0 or draws[1] != 0                      # default.py:306-320: warpPerspective iff a perspective draw is non-zero
+    img = warp_perspective_u8(canvas, M, wo, ho) if persp else warp_affine_u8(canvas, M[:2], wo, ho)
     if len(labels):
-        nb, keep = affine_boxes(boxes, M, wo, ho, draws[3])
+        nb, keep = (perspective_boxes if persp else affine_boxes)(boxes, M, wo, ho, draws[3])
         boxes, labels = nb[keep], labels[keep]
     luts = None
     if not (hsv[0] == 0.0 and hsv[1] == 0.0 and hsv[2] == 0.0):

@@ -365,7 +365,8 @@ def gen_protocol():
     try:
         for name, (mixup_prob, side, over) in synth.PROTOCOL_CASES.items():
             hsv = over.get("hsv", (0.015, 0.7, 0.4))
-            params = D.AugParams(affine_params=D.AffineParams(degrees=over.get("degrees", 0.0), shear=over.get("shear", 0.0)),
+            params = D.AugParams(affine_params=D.AffineParams(degrees=over.get("degrees", 0.0), shear=over.get("shear", 0.0),
+                                                              perspective=over.get("perspective", 0.0)),
                                  hsv_params=D.HSVParams(*hsv), flip_lr_prob=over.get("flip", 0.5), image_color_transforms=False)
             aug = D.TrainSampleAugmentor(params, rng_seed=51)
 
@@ -410,6 +411,9 @@ def gen_protocol():
                         assert p["src_crc"] == ccrc[k, stage] and p["src_shape"] == (2 * S, 2 * S, 3)
                         M = np.eye(3); M[:2] = p["M"]
                         Ms[k, stage] = M; dsize[k, stage] = p["dsize"]
+                    elif e == "warpPerspective":
+                        assert p["src_crc"] == ccrc[k, stage] and p["src_shape"] == (2 * S, 2 * S, 3) and p["M"].shape == (3, 3)
+                        Ms[k, stage] = p["M"]; dsize[k, stage] = p["dsize"]
                     elif e == "LUT":
                         luts[k, stage, n_lut[k, stage]] = p["lut"]; n_lut[k, stage] += 1
                     elif e == "flip":

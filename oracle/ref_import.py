@@ -189,8 +189,11 @@ def install_recording(rec: Recorder):
             src_shape=tuple(im.shape), src_crc=zlib.crc32(np.ascontiguousarray(im).tobytes()))
         return DP.warp_affine_u8(im, np.asarray(M, dtype=np.float64), int(dsize[0]), int(dsize[1]), 114)
 
-    def warpPerspective(*a, **k):
-        raise NotImplementedError("perspective warps are not part of the recorded protocol")
+    def warpPerspective(im, M, dsize, borderValue=(0, 0, 0), flags=1, borderMode=0):
+        assert flags == cv2.INTER_LINEAR and borderMode == cv2.BORDER_CONSTANT and tuple(borderValue) == (114, 114, 114)
+        rec("warpPerspective", M=np.array(M, dtype=np.float64), dsize=tuple(int(v) for v in dsize),
+            src_shape=tuple(im.shape), src_crc=zlib.crc32(np.ascontiguousarray(im).tobytes()))
+        return DP.warp_perspective_u8(im, np.asarray(M, dtype=np.float64), int(dsize[0]), int(dsize[1]), 114)
 
     def cvtColor(img, code):
         rec("cvtColor", code=int(code))

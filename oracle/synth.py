@@ -198,6 +198,7 @@ PROTOCOL_CASES = {
     "rfs03": (0.3, True, {}),                                        # image_repeat_factors + sampler_indices (detection.py:78-80,114-122)
     "rot": (0.0, False, dict(degrees=10.0, shear=5.0, flip=0.0)),    # all matrix factors live; flip_lr_prob = 0: no flip draw
     "nohsv": (0.0, False, dict(hsv=(0.0, 0.0, 0.0))),                # HSVParams.should_aug() False: no HSV draws (default.py:359-364)
+    "persp": (0.3, False, dict(degrees=5.0, shear=2.0, perspective=0.0008)),   # cv2.warpPerspective + the boxes' perspective divide (default.py:306-313,257-260)
 }
 PROTOCOL_S, PROTOCOL_POOL, PROTOCOL_N = 64, 12, 64
 

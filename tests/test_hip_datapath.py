@@ -44,19 +44,23 @@ def test_batch_matches_oracle_protocol(S, mixup, seed):
     np.testing.assert_array_equal(p[..., :3], want)
 
 
-@pytest.mark.parametrize("S,degrees,shear,mixup,seed", [(64, 10.0, 5.0, 0.0, 11), (128, 25.0, 0.0, 0.5, 12), (96, 0.0, 8.0, 0.0, 13),
-                                                        (640, 10.0, 5.0, 0.5, 14)])
-def test_rotated_and_sheared_batches_match_oracle(S, degrees, shear, mixup, seed):
+@pytest.mark.parametrize("S,degrees,shear,persp,mixup,seed", [(64, 10.0, 5.0, 0.0, 0.0, 11), (128, 25.0, 0.0, 0.0, 0.5, 12),
+                                                              (96, 0.0, 8.0, 0.0, 0.0, 13), (640, 10.0, 5.0, 0.0, 0.5, 14),
+                                                              (64, 5.0, 2.0, 0.0008, 0.3, 15), (128, 0.0, 0.0, 0.001, 0.0, 16),
+                                                              (640, 10.0, 5.0, 0.0005, 0.5, 17)])
+def test_rotated_and_sheared_batches_match_oracle(S, degrees, shear, persp, mixup, seed):
     """AffineParams.degrees / shear switched on (kod/data/augmentations/default.py:31-36,168-181: the reference's defaults
     are 0, its configs may set them): the general 2 x 3 inverse map through csrc/compose.hip against the oracle's warp
     (oracle/datapath.warp_affine_u8, the restatement of OpenCV's fixed-point warpAffine) - pixels, boxes and labels bit for
-    bit, also at 640 px.  (The matrices themselves are pinned to the reference by the 'rot' case of protocol.npz.)"""
+    bit, also at 640 px; with AffineParams.perspective != 0 the reference switches to cv2.warpPerspective and divides the
+    box corners by w (default.py:257-260,306-313): the projective map of csrc/compose.hip against oracle/datapath.
+    warp_perspective_u8.  (The matrices themselves are pinned to the reference by the 'rot' / 'persp' cases of protocol.npz.)"""
     cache = _cache(10, S, seed)
     idxs = [3, 0, 7, 9, 5, 2] if S < 640 else [3, 0, 7]
-    aug = AugParams(affine_params=AffineParams(degrees=degrees, translate=0.1, scale=0.5, shear=shear, perspective=0.0))
+    aug = AugParams(affine_params=AffineParams(degrees=degrees, translate=0.1, scale=0.5, shear=shear, perspective=persp))
     random.seed(seed); np.random.seed(seed)
     rng = np.random.default_rng(51)
-    ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup, aug=dict(degrees=degrees, shear=shear)) for i in idxs]
+    ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup, aug=dict(degrees=degrees, shear=shear, perspective=persp)) for i in idxs]
     random.seed(seed); np.random.seed(seed)
     pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda", aug,
                                mixup_prob=mixup, rng_seed=51)

@@ -423,7 +423,7 @@ def test_bench_ranks_under_an_external_launcher_supervise_and_walk_the_ladder():
     assert not [ln for o in outs for ln in o[0].splitlines() if ln.startswith("{")]
 
 
-@pytest.mark.parametrize("case", ["plain", "mix03", "mix10", "rfs03", "rot", "nohsv"])
+@pytest.mark.parametrize("case", ["plain", "mix03", "mix10", "rfs03", "rot", "nohsv", "persp"])
 def test_host_protocol_vs_reference_recording(case):
     """The PRODUCT's host side of the data protocol (data/host_protocol.HostProtocol: numpy only) against the recording of
     the reference's real DetectionDataset.__getitem__ + TrainSampleAugmentor (tests/golden/protocol.npz, made by
@@ -442,7 +442,8 @@ def test_host_protocol_vs_reference_recording(case):
     pool = synth.protocol_pool()
     shapes = [im.shape[:2] for im, _, _ in pool]
     offsets = np.concatenate(([0], np.cumsum([h * w_ * 3 for h, w_ in shapes])[:-1]))
-    aug = AugParams(affine_params=AffineParams(degrees=over.get("degrees", 0.0), shear=over.get("shear", 0.0)),
+    aug = AugParams(affine_params=AffineParams(degrees=over.get("degrees", 0.0), shear=over.get("shear", 0.0),
+                                               perspective=over.get("perspective", 0.0)),
                     hsv_params=HSVParams(*over.get("hsv", (0.015, 0.7, 0.4))), flip_lr_prob=over.get("flip", 0.5))
     random.seed(2023)
     np.random.seed(2023)
@@ -456,7 +457,11 @@ def test_host_protocol_vs_reference_recording(case):
         for st in range(stages):
             d = descs[k, st]
             assert [int(np.searchsorted(offsets, t["off"])) for t in d["tile"]] == want_idx[4 * st:4 * st + 4], (case, k, st)
-            assert np.array_equal(d["im"].reshape(2, 3), invert_affine(g["M"][k, st])), (case, k, st)
+            if over.get("perspective"):
+                inv = np.linalg.inv(g["M"][k, st])
+                assert d["persp"] == 1 and np.array_equal(d["im"].reshape(2, 3), inv[:2]) and np.array_equal(d["pw"], inv[2]), (case, k, st)
+            else:
+                assert d["persp"] == 0 and np.array_equal(d["im"].reshape(2, 3), invert_affine(g["M"][k, st])), (case, k, st)
             if g["n_lut"][k, st]:
                 assert d["hsv_on"] == 1 and all(np.array_equal(d[f], g["luts"][k, st, c]) for c, f in enumerate(("lut_h", "lut_s", "lut_v")))
             else:

@@ -227,7 +227,7 @@ def test_per_sample_protocol_vs_reference(golden, case):
     pool = synth.protocol_pool()
     aug = {}
     if "degrees" in over:
-        aug.update(degrees=over["degrees"], shear=over["shear"])
+        aug.update(degrees=over["degrees"], shear=over["shear"], perspective=over.get("perspective", 0.0))
     if "flip" in over:
         aug["flip_prob"] = over["flip"]
     if "hsv" in over:
