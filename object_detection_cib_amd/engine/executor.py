@@ -48,6 +48,7 @@ class Engine(ArenaMixin, BufferMixin, ForwardMixin, BackwardMixin):
         self._pinned = set()          # shapes a captured graph depends on: never evicted
         self.max_shape_sets = self.opt.max_shape_sets
         self.training_ready = False
+        self.bn_eps, self.bn_momentum = BN_EPS, BN_MOMENTUM     # the network's BatchNorm2d constants (set by the nn.Module that owns the engine)
         self.sync_bn = False
         self.process_group = None
         self.world_size = 1

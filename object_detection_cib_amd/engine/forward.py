@@ -158,7 +158,7 @@ class ForwardMixin:
                 e0 = self._t0()
                 peer = sync and self.peer is not None
                 chk(lib.kodhip_bn_finalize_partials_pair(
-                    mst.stats.data_ptr(), mst.T, float(mst.M) * (self.world_size if sync else 1), mid, BN_MOMENTUM, BN_EPS, 1,
+                    mst.stats.data_ptr(), mst.T, float(mst.M) * (self.world_size if sync else 1), mid, self.bn_momentum, self.bn_eps, 1,
                     pa + 4 * mst.g_off, pa + 4 * mst.b_off, rm + 4 * mst.rs_off, rv + 4 * mst.rs_off, ma,
                     pa + 4 * sst.g_off, pa + 4 * sst.b_off, rm + 4 * sst.rs_off, rv + 4 * sst.rs_off, sa,
                     self.peer.view_ptr() if peer else None,
@@ -198,7 +198,7 @@ class ForwardMixin:
                     aff = st.aff.data_ptr()
                     chk(lib.kodhip_bn_finalize_partials(st.stats.data_ptr(), st.T, float(st.M), pa + 4 * st.g_off,
                                                         pa + 4 * st.b_off, rm + 4 * st.rs_off, rv + 4 * st.rs_off,
-                                                        BN_MOMENTUM, BN_EPS, aff, aff + 4 * C_, aff + 8 * C_,
+                                                        self.bn_momentum, self.bn_eps, aff, aff + 4 * C_, aff + 8 * C_,
                                                         aff + 12 * C_, C_, 1, s), u.name)
             elif self.peer is not None:
                 # SyncBN over peer buffers: the same single launch per unit, the ranks' sums meet inside the kernel
@@ -207,7 +207,7 @@ class ForwardMixin:
                     aff = st.aff.data_ptr()
                     chk(lib.kodhip_bn_finalize_partials_peer(st.stats.data_ptr(), st.T, float(st.M) * self.world_size,
                                                              pa + 4 * st.g_off, pa + 4 * st.b_off, rm + 4 * st.rs_off,
-                                                             rv + 4 * st.rs_off, BN_MOMENTUM, BN_EPS, aff, aff + 4 * C_,
+                                                             rv + 4 * st.rs_off, self.bn_momentum, self.bn_eps, aff, aff + 4 * C_,
                                                              aff + 8 * C_, aff + 12 * C_, C_, 1, self.peer.view_ptr(),
                                                              self.peer_slots[(u.name, "f")], s), u.name)
             else:
@@ -219,8 +219,8 @@ class ForwardMixin:
                     st, C_ = self.ustate[u.name], u.cout
                     aff = st.aff.data_ptr()
                     chk(lib.kodhip_bn_finalize(st.sums.data_ptr(), float(st.M) * self.world_size, pa + 4 * st.g_off,
-                                               pa + 4 * st.b_off, rm + 4 * st.rs_off, rv + 4 * st.rs_off, BN_MOMENTUM,
-                                               BN_EPS, aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
+                                               pa + 4 * st.b_off, rm + 4 * st.rs_off, rv + 4 * st.rs_off, self.bn_momentum,
+                                               self.bn_eps, aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_, C_, 1, s), u.name)
             self._t1(e0, "bn_finalize", sum(8.0 * u.cout * self.ustate[u.name].T for u in group), name="+".join(u.name for u in group))
 
         def apply_stage(u: ConvUnit, s=s):
@@ -375,7 +375,7 @@ class ForwardMixin:
         if self._eval_key != key:
             gi, bi, ri = self._eval_idx
             n = self._eval_n
-            sc = self.p_arena[gi] * torch.rsqrt(self.rv_arena[ri] + BN_EPS)
+            sc = self.p_arena[gi] * torch.rsqrt(self.rv_arena[ri] + self.bn_eps)
             self._eval_aff[:n] = sc
             self._eval_aff[n:] = self.p_arena[bi] - self.rm_arena[ri] * sc
             self._eval_key = key

@@ -37,14 +37,23 @@ def ensure_path(root: nn.Module, path: str) -> nn.Module:
     return node
 
 
+def batchnorm_constants(norm_layer):
+    """(eps, momentum) of the BatchNorm2d a `norm_layer` callable builds.  The HIP path implements train / eval BatchNorm2d
+    with affine parameters and running statistics for any eps and any float momentum (the kernels take both as arguments;
+    the reference's default is eps 1e-3, momentum .03, kod/nn/networks/yolov5.py:24); other normalisations are refused
+    rather than silently replaced."""
+    if norm_layer is None:
+        return BN_EPS, BN_MOMENTUM
+    probe = norm_layer(8)
+    if not (isinstance(probe, nn.BatchNorm2d) and probe.affine and probe.track_running_stats and probe.momentum is not None):
+        raise ValueError("the HIP path implements nn.BatchNorm2d (affine, running statistics, float momentum) only")
+    return float(probe.eps), float(probe.momentum)
+
+
 def check_norm_act(norm_layer, activation_layer):
-    """The HIP path implements BatchNorm2d(eps=1e-3, momentum=0.03) + SiLU (kod/nn/networks/yolov5.py:24); anything else
-    is refused rather than silently replaced."""
-    if norm_layer is not None:
-        probe = norm_layer(8)
-        if not (isinstance(probe, nn.BatchNorm2d) and abs(probe.eps - BN_EPS) < 1e-12 and abs(probe.momentum - BN_MOMENTUM) < 1e-12):
-            raise ValueError("the HIP path implements BatchNorm2d(eps=1e-3, momentum=0.03) only "
-                             "(object_detection_cib_amd.nn.networks.yolov5.Yolov5BatchNorm2d)")
+    """BatchNorm2d (any eps / momentum, see batchnorm_constants) + SiLU; anything else is refused rather than silently
+    replaced."""
+    batchnorm_constants(norm_layer)
     if activation_layer is not None:
         probe = activation_layer()
         if not isinstance(probe, nn.SiLU) and type(probe).__name__ not in ("SiLU", "SiLUInplace"):
@@ -102,6 +111,7 @@ class GraphModule(nn.Module):
     def _init_graph(self, graph: Graph, norm_layer, use_yv5_init: bool = True, prior_probability: float = 0.01):
         from .networks.yolov5 import Yolov5BatchNorm2d
         self.graph = graph
+        self._bn_eps, self._bn_momentum = batchnorm_constants(norm_layer)
         add_unit_parameters(self, graph, norm_layer or Yolov5BatchNorm2d)
         if graph.heads:
             add_head_parameters(self, graph, use_yv5_init, prior_probability)
@@ -116,6 +126,7 @@ class GraphModule(nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError(f"{type(self).__name__} (HIP) must be on an MI355X: call .cuda() first; no CPU fallback")
             eng = Engine(self.graph, self._engine_params(), dict(self.named_buffers()), self.engine_options)
+            eng.bn_eps, eng.bn_momentum = getattr(self, "_bn_eps", BN_EPS), getattr(self, "_bn_momentum", BN_MOMENTUM)
             eng._build_arenas(dev)
             self._engine, self._engine_device = eng, dev
         return self._engine

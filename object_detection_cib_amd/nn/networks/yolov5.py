@@ -72,10 +72,10 @@ class Yolov5Network(nn.Module):
         deepen_factor: float = 1.0,
     ):
         super().__init__()
-        if norm_layer is not Yolov5BatchNorm2d:
-            probe = norm_layer(8)
-            if not (isinstance(probe, nn.BatchNorm2d) and probe.eps == BN_EPS and probe.momentum == BN_MOMENTUM):
-                raise ValueError("the HIP path implements BatchNorm2d(eps=1e-3, momentum=0.03) + SiLU only")
+        from ..graph_module import batchnorm_constants      # any BatchNorm2d eps / momentum; other normalisations are refused
+        self._bn_eps, self._bn_momentum = batchnorm_constants(norm_layer)
+        if activation_layer is not None and type(activation_layer()).__name__ not in ("SiLU", "SiLUInplace"):
+            raise ValueError("the HIP path implements SiLU only")
         self.num_classes = num_classes
         self.num_anchors_per_cell = num_anchors_per_cell
         self.widen_factor, self.deepen_factor = widen_factor, deepen_factor
@@ -106,6 +106,7 @@ class Yolov5Network(nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError("Yolov5Network (HIP) must be on an MI355X: call .cuda() first; no CPU fallback")
             eng = Engine(self.graph, dict(self.named_parameters()), dict(self.named_buffers()), self.engine_options)
+            eng.bn_eps, eng.bn_momentum = self._bn_eps, self._bn_momentum
             eng._build_arenas(dev)
             self._engine, self._engine_device = eng, dev
         return self._engine

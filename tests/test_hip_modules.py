@@ -102,8 +102,20 @@ def test_csp_block_and_layer():
     torch.manual_seed(4); hip = CSPLayer(64, 128, 0.5, True, 2, Yolov5BatchNorm2d, torch.nn.SiLU)
     torch.manual_seed(4); ref = N.CSP(64, 128, 2, True)
     _compare(hip, ref, [x])
+    # norm_layer = any nn.BatchNorm2d: torch's defaults (eps 1e-5, momentum 0.1) against the oracle with its modules set the same
+    torch.manual_seed(6); hip = CSPLayer(64, 64, norm_layer=torch.nn.BatchNorm2d)
+    torch.manual_seed(6); ref = N.CSP(64, 64, 1, True)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eps, m.momentum = 1e-5, 0.1
+    _compare(hip, ref, [x])
+    rv_h = torch.cat([v.cpu().flatten() for k, v in hip.state_dict().items() if k.endswith("running_var")])
+    rv_r = torch.cat([v.flatten() for k, v in ref.state_dict().items() if k.endswith("running_var")])
+    assert _rel(rv_h, rv_r) <= 2e-2                                  # the momentum-0.1 update of both
     with pytest.raises(ValueError):
-        CSPLayer(64, 64, norm_layer=torch.nn.BatchNorm2d)          # eps 1e-5: not what the kernels implement
+        CSPLayer(64, 64, norm_layer=lambda c: torch.nn.GroupNorm(4, c))
+    with pytest.raises(ValueError):
+        CSPLayer(64, 64, activation_layer=torch.nn.ReLU)
 
 
 def test_sppf_bottleneck():

@@ -103,6 +103,63 @@ def test_train_step_vs_oracle(case):
     assert all(int(sd_h[k]) == int(sd_r[k]) == 1 for k in sd_r if k.endswith("num_batches_tracked"))
 
 
+def test_batchnorm_eps_and_momentum_follow_norm_layer():
+    """`norm_layer` may build any nn.BatchNorm2d (kod/nn/networks/yolov5.py:47, kod/nn/layers/csp.py:16-46 take a callable): eps
+    and momentum reach the kernels as arguments.  torch's defaults (eps 1e-5, momentum 0.1) instead of the reference's (1e-3,
+    .03), one train step at 160 px / B=4 against the fp32 oracle with its BatchNorm modules set the same: losses, gradient
+    norm, running statistics (their update IS the momentum), then an eval-mode forward (the folded scale uses eps).  Other
+    normalisations and activations stay refused."""
+    from functools import partial
+    import torch.nn as nn
+    widen, deepen, nc, B, size, seed = 0.5, 0.33, 10, 4, 160, 77
+    eps, mom = 1e-5, 0.1
+    torch.manual_seed(seed)
+    ref = OracleYolov5(3, nc, widen, deepen).train()
+    for m in ref.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eps, m.momentum = eps, mom
+    torch.manual_seed(seed)
+    net = Yolov5Network(3, nc, norm_layer=partial(nn.BatchNorm2d, eps=eps, momentum=mom), widen_factor=widen, deepen_factor=deepen)
+    for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+        assert torch.equal(a, b), k
+    net = net.cuda().train()
+    assert (net.engine().bn_eps, net.engine().bn_momentum) == (eps, mom)
+    x, tg = synth.batch(B, size, nc, seed)
+    lr = D.yolo_loss(size, size, ref(x), [D.Target(b, l) for b, l in tg])
+    tot = D.train_step_total(lr, B)
+    tot.backward()
+    gn_r = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ref.parameters())).item()
+    _, lr_h, tot_h = _step(net, x.cuda(), tg, size, B)
+    got = np.array([lr_h.localization.item(), lr_h.objectness.item(), lr_h.classification.item(), tot_h.item()])
+    want = np.array([lr.localization.item(), lr.objectness.item(), lr.classification.item(), tot.item()])
+    np.testing.assert_allclose(got, want, rtol=2e-2)
+    gn_h = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())).item()
+    assert abs(gn_h - gn_r) <= 1.5e-1 * gn_r, (gn_h, gn_r)
+    sd_r, sd_h = ref.state_dict(), net.state_dict()
+    for suffix, tol in (("running_mean", 0.15), ("running_var", 2e-2)):
+        a = torch.cat([sd_h[k].cpu().flatten() for k in sd_r if k.endswith(suffix)])
+        b = torch.cat([sd_r[k].flatten() for k in sd_r if k.endswith(suffix)])
+        assert _rel(a, b) <= tol, (suffix, _rel(a, b))
+        # and they are NOT what momentum .03 would have left (running_var starts at 1: 0.9 + 0.1 var vs 0.97 + 0.03 var)
+    rv = torch.cat([sd_h[k].cpu().flatten() for k in sd_r if k.endswith("running_var")])
+    assert rv.max().item() <= 0.9 + 0.1 * 1e3 and (rv < 0.95).float().mean().item() > 0.5
+    # eval mode: the oracle on the HIP path's own running statistics
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        want_e, got_e = ref(x), net(x.cuda())
+    for lvl in ("ll", "ml", "hl"):
+        for part in ("box", "obj", "cls"):
+            a, b = getattr(getattr(got_e, lvl), part).float().cpu(), getattr(getattr(want_e, lvl), part)
+            assert _rel(a, b) <= 3e-2, (lvl, part, _rel(a, b))
+    with pytest.raises(ValueError):
+        Yolov5Network(3, nc, norm_layer=partial(nn.GroupNorm, 4))
+    with pytest.raises(ValueError):
+        Yolov5Network(3, nc, norm_layer=partial(nn.BatchNorm2d, momentum=None))
+    with pytest.raises(ValueError):
+        Yolov5Network(3, nc, activation_layer=nn.ReLU)
+
+
 def test_train_step_yv5m_640_vs_oracle():
     """BASELINE configs[4] scale (widen .75, deepen .67: 48 / 96 / 192 / 384 / 768 channels, 88 convs, 20.9 M parameters) at
     640 px, B=2, end to end against the fp32 oracle: the 48-channel layers run on the LDS-DMA path through the padded-tap

@@ -336,8 +336,13 @@ def test_submodule_classes_mirror_reference_parameters_and_refuse_cpu():
     assert torch.allclose(sp["cls_head.conv.bias"] - prior, sy["cls_head.conv.bias"] - math.log(0.6 / (10 - 0.99999)), atol=1e-6)
     with pytest.raises(RuntimeError, match="MI355X"):
         CSPLayer(64, 64)(torch.zeros(1, 64, 8, 8))
+    # any nn.BatchNorm2d is taken (eps / momentum reach the kernels as arguments); other normalisations / activations raise
+    blk = CSPBlock(32, 32, norm_layer=torch.nn.BatchNorm2d)
+    assert (blk._bn_eps, blk._bn_momentum) == (1e-5, 0.1)
     with pytest.raises(ValueError):
-        CSPBlock(32, 32, norm_layer=torch.nn.BatchNorm2d)
+        CSPBlock(32, 32, norm_layer=lambda c: torch.nn.GroupNorm(4, c))
+    with pytest.raises(ValueError):
+        CSPBlock(32, 32, activation_layer=torch.nn.ReLU)
 
 
 def test_descriptor_producer_process_equals_in_process_protocol():
