@@ -1,6 +1,6 @@
 """3x3/s2 data gradient: parity-class form vs folded form on the six stride-2 layers of yv5s (B=64, 640 px)."""
 import sys, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os; _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [_R, os.path.join(_R, "tests")]
 from object_detection_cib_amd import _lib
 from hip_helpers import pack, stream
 
