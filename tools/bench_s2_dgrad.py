@@ -6,7 +6,12 @@ from hip_helpers import pack, stream
 
 lib = _lib.lib()
 LAYERS = [("s1.conv 32->64 @320", 32, 320, 64), ("s2.conv 64->128 @160", 64, 160, 128), ("s3.conv 128->256 @80", 128, 80, 256),
-          ("s4.conv 256->512 @40", 256, 40, 512), ("neck.down0 128->128 @80", 128, 80, 128), ("neck.down1 256->256 @40", 256, 40, 256)]
+          ("s4.conv 256->512 @40", 256, 40, 512), ("neck.down0 128->128 @80", 128, 80, 128), ("neck.down1 256->256 @40", 256, 40, 256),
+          # yv5m widths (BASELINE configs[4])
+          ("m.s1.conv 48->96 @320", 48, 320, 96), ("m.s2.conv 96->192 @160", 96, 160, 192), ("m.s3.conv 192->384 @80", 192, 80, 384),
+          ("m.s4.conv 384->768 @40", 384, 40, 768), ("m.down0 192->192 @80", 192, 80, 192), ("m.down1 384->384 @40", 384, 40, 384)]
+if len(sys.argv) > 1:
+    LAYERS = [l for l in LAYERS if any(a in l[0] for a in sys.argv[1:])]
 B = 64
 for name, Cin, H, Cout in LAYERS:
     W = H
