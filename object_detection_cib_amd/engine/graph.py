@@ -19,14 +19,7 @@ P5_STAGES = ((64, 128, 3, True, False), (128, 256, 6, True, False),
              (256, 512, 9, True, False), (512, 1024, 3, False, True))
 
 
-def make_divisible(x: float, widen_factor: float = 1.0, divisor: int = 8) -> int:
-    """kod/nn/utils.py:7-13."""
-    return math.ceil(x * widen_factor / divisor) * divisor
-
-
-def make_round(x: float, deepen_factor: float = 1.0) -> int:
-    """kod/nn/utils.py:16-22."""
-    return int(max(round(x * deepen_factor), 1) if x > 1 else x)
+from ..nn.utils import make_divisible, make_round  # noqa: E402,F401  (channel / depth rounding; also re-exported from here)
 
 
 @dataclass
