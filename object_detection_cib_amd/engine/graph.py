@@ -10,7 +10,6 @@ seeded initial weights are identical.
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass, field
 from typing import List, Optional
 
