@@ -42,10 +42,11 @@ __device__ __forceinline__ float sigmoid_f(float z) { return 1.0f / (1.0f + __ex
 
 // ---- BatchNorm + SiLU elementwise arithmetic shared by the passes that form it (bn_act.hip, the data gradients' fused
 // reduction epilogue in conv_igemm.hip, the fused stem backward in conv_wgrad.hip).  These passes cost VALU issue slots
-// that the co-running weight gradients want (replacing the sigmoid by the identity in the two apply passes alone makes the
-// training step 6 % faster), so: explicit FMAs (the library is built with -ffp-contract=off; 21.8 -> 15 issue cycles per
-// element in the backward pass) and sigmoid = rcp(1 + exp2(-log2e * z)): v_exp_f32 + v_rcp_f32, 1 ulp each, no Newton step
-// (the results are rounded to bf16).  (Folding -log2e into per-channel constants would save the multiply but costs sixteen
+// that the co-running weight gradients want, so: explicit FMAs (the library is built with -ffp-contract=off; 21.8 -> 15 issue
+// cycles per element in the backward pass) and sigmoid = rcp(1 + exp2(-log2e * z)): v_exp_f32 + v_rcp_f32, 1 ulp each, no
+// Newton step (the results are rounded to bf16).  (How much is left in them: a backward apply with no sigmoid at all - dz taken
+// from the data gradient's epilogue - is 6 % shorter in isolation and moves the step by 0.3 %, LOG round 5; round 2's
+// "+ 6 % step with the sigmoid replaced by the identity" came from a diverged run on a chip that then clocks higher.)  (Folding -log2e into per-channel constants would save the multiply but costs sixteen
 // registers: an occupancy step in the apply pass, spills in the 128-register conv tiles.)
 #define KOD_NEG_LOG2E (-1.4426950408889634f)
 __device__ __forceinline__ float kod_sigmoid_l2(float zl) {
