@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, int
     for (int u = 0; u < U; ++u) {
       const long m = m0 + u * stride;
       if (m < M) {
-        v[u] = *reinterpret_cast<const bf16x8*>(y + m * ldy + cc * 8);
+        v[u] = kod_load_once<bf16x8>(y + m * ldy + cc * 8);
         if (res) r[u] = *reinterpret_cast<const bf16x8*>(res + m * ldr + rcoff + cc * 8);
       }
     }
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA
     for (int u = 0; u < U; ++u) {
       const long m = m0 + u * stride;
       if (m < M) {
-        g[u] = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
-        v[u] = *reinterpret_cast<const bf16x8*>(y + m * ldy + cc * 8);
+        g[u] = kod_load_once<bf16x8>(dA + m * lda + dacoff + cc * 8);
+        v[u] = kod_load_once<bf16x8>(y + m * ldy + cc * 8);
         if (acc) old[u] = *reinterpret_cast<const bf16x8*>(dI + m * ldi + dicoff + cc * 8);
       }
     }

@@ -817,13 +817,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_v4_kernel(const float* part,
     f32x4 s0 = s, s1 = s, s2 = s, s3 = s;
     int i = sl;
     for (; i + 3 * RED_L < splits; i += 4 * RED_L) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(p + (size_t)i * slab);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + (size_t)(i + RED_L) * slab);
-      const f32x4 a2 = *reinterpret_cast<const f32x4*>(p + (size_t)(i + 2 * RED_L) * slab);
-      const f32x4 a3 = *reinterpret_cast<const f32x4*>(p + (size_t)(i + 3 * RED_L) * slab);
+      const f32x4 a0 = kod_load_once<f32x4>(p + (size_t)i * slab);
+      const f32x4 a1 = kod_load_once<f32x4>(p + (size_t)(i + RED_L) * slab);
+      const f32x4 a2 = kod_load_once<f32x4>(p + (size_t)(i + 2 * RED_L) * slab);
+      const f32x4 a3 = kod_load_once<f32x4>(p + (size_t)(i + 3 * RED_L) * slab);
       s0 += a0; s1 += a1; s2 += a2; s3 += a3;
     }
-    for (; i < splits; i += RED_L) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)i * slab);
+    for (; i < splits; i += RED_L) s0 += kod_load_once<f32x4>(p + (size_t)i * slab);
     s = (s0 + s1) + (s2 + s3);
   }
   sm[sl][qx] = s;

@@ -34,6 +34,16 @@ extern "C" void kodhip_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+// A 16-byte load of data this launch reads exactly once and nothing reads again soon (the pre-BN tensor behind its apply
+// pass, dA behind the backward apply, weight-gradient slabs behind their reduction, gradients behind the optimizer, the
+// fp32 input image): non-temporal, so that it does not push the tensors the NEXT launches re-read out of L2 / Infinity Cache.
+// Measured on the replayed step: + 0.7 % for the two apply passes alone (LOG round 5); same bits.
+#ifndef KOD_NO_NT
+template <typename V> __device__ __forceinline__ V kod_load_once(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const V*>(p)); }
+#else
+template <typename V> __device__ __forceinline__ V kod_load_once(const void* p) { return *reinterpret_cast<const V*>(p); }
+#endif
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 

@@ -28,10 +28,10 @@ __global__ void nchw_to_nhwc4_x4_kernel(const float* x, bf16_t* y, int B, int C,
   const long HWq = HW >> 2;
   if (q >= (long)B * HWq) return;
   const long b = q / HWq, pq = q - b * HWq;
-  float4 pl[4];
+  f32x4 pl[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
-    pl[c] = c < C ? *reinterpret_cast<const float4*>(x + (b * C + c) * HW + pq * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    pl[c] = c < C ? kod_load_once<f32x4>(x + (b * C + c) * HW + pq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 o0, o1;
   const float* f0 = reinterpret_cast<const float*>(&pl[0]);
 #pragma unroll
@@ -507,7 +507,7 @@ __global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, const 
   const float lr = hyper[grp], mu = hyper[3 + grp], wd = hyper[6 + grp], gscale = hyper[9];
   const bool nesterov = hyper[10] != 0.f;
   f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
-  f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+  f32x4 gv = kod_load_once<f32x4>(g + i);
   f32x4 bv = *reinterpret_cast<const f32x4*>(buf + i);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
