@@ -846,9 +846,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             }
             if constexpr (MODE == MODE_PLAIN_BN) {
               if (sg_raw) {     // dz = dA * silu'(z), z = y*scale + shift, on the value as stored (bf16)
+#ifdef KOD_ABL_NOBNLOAD       // (tools/build_ablate.sh: what the pre-BN re-read / the arithmetic / the stores of this epilogue cost)
+                bf16x8 yv = v;
+#else
                 bf16x8 yv = *reinterpret_cast<const bf16x8*>(sg_raw + opix * sg_ldr);
+#endif
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
+#ifdef KOD_ABL_NOBNMATH
+                  ssum[e] += (float)v[e]; ssq[e] += (float)yv[e]; continue;
+#endif
                   // kodhip_common.h; the exponent's scale as one more multiply here: sixteen more per-channel constants
                   // would spill in the 128-register tiles
                   const float y = (float)yv[e];
@@ -868,6 +875,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
               ssq[e] += f * f;
             }
           }
+#ifdef KOD_ABL_NOSTORE
+          if (v[0] == (bf16_t)12345.f)
+#endif
           *reinterpret_cast<bf16x8*>(dst) = v;
         }
       }

@@ -19,6 +19,26 @@ from .graph import Graph, ConvUnit, HeadUnit, View, Buf, head_param
 from .ddp import plan_buckets, launch_bucket
 
 
+def _cu_masked_stream(device):
+    """Probe (LOG round 6): KODHIP_WG_CUMASK=<hex word>[:<words>] confines the weight-gradient stream
+    to a CU subset (hipExtStreamCreateWithCUMask; the 32-bit word is repeated over the chip's 256 CU bits).  None = unset."""
+    import os
+    spec = os.environ.get("KODHIP_WG_CUMASK")
+    if not spec:
+        return None
+    import ctypes
+    word, _, n = spec.partition(":")
+    words = int(n) if n else 8
+    mask = (ctypes.c_uint32 * words)(*([int(word, 16)] * words))
+    hip = ctypes.CDLL("libamdhip64.so")
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if rc != 0 or not st.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
 class BackwardMixin:
     # ------------------------------------------------------------------ backward
     def backward(self, head_grads: List[torch.Tensor], out_grads: Optional[List[torch.Tensor]] = None):
@@ -43,7 +63,7 @@ class BackwardMixin:
         wg = None
         if self.wgrad_overlap:
             if self.wg_stream is None:
-                self.wg_stream = torch.cuda.Stream(device=self.device)
+                self.wg_stream = _cu_masked_stream(self.device) or torch.cuda.Stream(device=self.device)
                 self.wg_more = [torch.cuda.Stream(device=self.device) for _ in range(self._wg_streams - 1)]
             wg = self.wg_stream
         # further weight-gradient streams (EngineOptions.wgrad_streams): the launches rotate over them, each stream with its

@@ -19,7 +19,9 @@ import torch
 from oracle import ref_import as R
 from oracle import synth
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+# `python -m oracle.gen_golden` rewrites tests/golden/ in place; KOD_GOLDEN_OUT=<dir> writes elsewhere (the CPU test
+# tests/test_oracle_golden.py::test_fixtures_regenerate_from_the_reference regenerates into a temp dir and diffs)
+OUT = os.environ.get("KOD_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def _np(t):

@@ -111,6 +111,18 @@ def _placeholder(name: str, **attrs):
     return m
 
 
+class ToTensorV2:
+    """albumentations.pytorch.ToTensorV2: torch.from_numpy(img.transpose(2, 0, 1)).  The reference binds this name at
+    import (`from albumentations.pytorch import ToTensorV2`, kod/data/augmentations/default.py), so the stand-in has to be
+    in place BEFORE the first reference import, whichever generator runs first - install() puts it there."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, **data):
+        return dict(data, image=torch.from_numpy(data["image"].transpose(2, 0, 1)))
+
+
 _installed = False
 
 
@@ -137,6 +149,7 @@ def install():
     for name in ("cv2", "albumentations", "albumentations.pytorch", "albumentations.core",
                  "albumentations.core.composition"):
         sys.modules[name] = _placeholder(name, TransformsSeqType=list)
+    sys.modules["albumentations.pytorch"].ToTensorV2 = ToTensorV2
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
 
@@ -227,13 +240,6 @@ def install_recording(rec: Recorder):
             rec("ToFloat", max_value=self.max_value)
             return dict(data, image=data["image"].astype("float32") / self.max_value)
 
-    class ToTensorV2:                    # albumentations.pytorch.ToTensorV2: torch.from_numpy(img.transpose(2, 0, 1))
-        def __init__(self, *a, **k):
-            pass
-
-        def __call__(self, **data):
-            return dict(data, image=torch.from_numpy(data["image"].transpose(2, 0, 1)))
-
     def _colour_op(name):
         class Op:
             def __init__(self, *a, **k):
@@ -247,4 +253,3 @@ def install_recording(rec: Recorder):
     A.Compose, A.ToFloat = Compose, ToFloat
     for n in ("Blur", "MedianBlur", "ToGray", "CLAHE"):
         setattr(A, n, _colour_op(n))
-    sys.modules["albumentations.pytorch"].ToTensorV2 = ToTensorV2

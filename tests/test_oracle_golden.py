@@ -288,3 +288,36 @@ def test_sppf_forms_vs_reference(golden, case):
     np.testing.assert_allclose(x.grad.numpy(), g[p + "dx"], rtol=1e-5, atol=1e-6)
     for k, v in m.named_parameters():
         np.testing.assert_allclose(v.grad.numpy(), g[p + "grad." + k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_fixtures_regenerate_from_the_reference(tmp_path):
+    """The pinning recipe is ONE command: `python -m oracle.gen_golden` from a clean process with an empty output
+    directory exits 0 and reproduces every committed fixture array for array (the generators used to
+    depend on their order - the reference binds albumentations' ToTensorV2 at import).  Needs the reference checkout
+    (build container only; skipped on the GPU box)."""
+    import os
+    import subprocess
+    import sys
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("reference checkout not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "KOD_GOLDEN_OUT": str(tmp_path), "PYTHONDONTWRITEBYTECODE": "1"}
+    r = subprocess.run([sys.executable, "-m", "oracle.gen_golden"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    made = sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
+    assert made == ["affine.npz", "assigner.npz", "decode_nms.npz", "iou.npz", "loss.npz", "mosaic.npz", "network.npz",
+                    "optim.npz", "protocol.npz", "samplers.npz", "sppf.npz"], made
+    n = 0
+    for f in made:
+        new, old = np.load(tmp_path / f, allow_pickle=False), np.load(os.path.join(root, "tests", "golden", f), allow_pickle=False)
+        assert sorted(new.files) == sorted(old.files), f
+        for k in new.files:
+            a, b = new[k], old[k]
+            assert a.dtype == b.dtype and a.shape == b.shape, (f, k)
+            if a.dtype.kind in "fc":
+                assert np.array_equal(a, b, equal_nan=True), (f, k)
+            else:
+                assert np.array_equal(a, b), (f, k)
+            n += 1
+    assert n > 500
