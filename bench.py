@@ -232,7 +232,7 @@ def loop_leg(net, loss_fn, B, S, nc, device, steps, mixup_prob=0.0, producer=Tru
         if prod is not None:
             prod.close()
     return {"value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
-            "workload": f"DeviceTrainPipeline (mosaic + affine + HSV + flip, mixup p={mixup_prob}, u8 pool of 256 images in HBM, "
+            "workload": f"DeviceTrainPipeline (mosaic + affine + colour transforms p=0.01 each + HSV + flip = the reference's default AugParams, mixup p={mixup_prob}, u8 pool of 256 images in HBM, "
                         + ("host RNG protocol in a producer process (descriptors through shared memory)" if producer else "host RNG protocol in-process")
                         + "; each batch composited as bf16 pixel pairs straight into the network's input buffer) -> hipGraph replay of the training step",
             "final_loss": float(total)}

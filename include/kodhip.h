@@ -233,6 +233,16 @@ int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int
 /* dx_f32 (NULL = none): fp32 shadow of dx holding the earlier producers' partial sum (see kodhip_conv_dgrad) */
 int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, void* dx, int ldx, int xcoff,
                         int B, int H, int W, int C, const float* dx_f32, kodStream_t stream);
+/* The three cascaded pools of an SPPF block (sppf.py:46-50,78-82: y1 = pool(x), y2 = pool(y1), y3 = pool(y2), all four
+ * tensors channel slices of one concat buffer) as ONE launch: stage j = 0..2 reads channels [coff0 + j mid, + mid) of
+ * buf [B][H][W][ld] and writes [coff0 + (j + 1) mid, + mid); idx0..2 as above.  Results are bit-identical to three
+ * kodhip_maxpool5_fwd / _bwd calls.  _ok: 1 if the geometry can take this form (one image's pixel groups in one block).
+ * _bwd: gbuf = the concat buffer's GRADIENT; stage j = 2, 1, 0 adds slice j + 1's scattered gradient to slice j. */
+int kodhip_maxpool5_cascade_ok(int H, int W, int mid);
+int kodhip_maxpool5_cascade_fwd(void* buf, int ld, int coff0, int mid, void* idx0, void* idx1, void* idx2,
+                                int B, int H, int W, kodStream_t stream);
+int kodhip_maxpool5_cascade_bwd(void* gbuf, int ld, int coff0, int mid, const void* idx0, const void* idx1, const void* idx2,
+                                int B, int H, int W, kodStream_t stream);
 int kodhip_upsample2x_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff,
                           int B, int H, int W, int C, kodStream_t stream);
 int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx, int xcoff, int accumulate,
@@ -298,6 +308,16 @@ int kodhip_iou_bwd(const float* boxes1, const float* boxes2, const float* grad_o
 int kodhip_compose_desc_bytes(void);
 int kodhip_compose_batch(const void* pool, const void* descs, const float* mix, const void* bilinear_tab,
                          float* out_f32, void* out_pairs, int B, int S, kodStream_t stream);
+/* image_color_transforms (kod/data/augmentations/default.py:420-432,460-461; the reference's shipped default,
+ * kod/configs/data/augmentations/aug_params.yaml:15): the albumentations stage between warp and HSV for ONE sample whose
+ * gate fired - descriptor `entry` (2 * sample + slot of descs [B][2]) is warped into out_u8 [S][S][3] and the fired
+ * transforms run on it in Compose order: ops bit 0 Blur(blur_k in 3/5/7), 1 MedianBlur(median_k), 2 ToGray, 3 CLAHE(clahe_clip
+ * in [1, 4], 8 x 8 tiles, on the L channel of an 8-bit Lab image).  tmp_u8: S*S*3 bytes, luts_u8: 64*256 bytes, color_tab: the
+ * Lab tables (data/device_pipeline.color_table()).  The descriptor's `pre` field must hold out_u8 when descs is uploaded:
+ * kodhip_compose_batch (same stream, afterwards) then takes that sample's warped pixels from there. */
+int kodhip_compose_color(const void* pool, const void* descs, const void* bilinear_tab, const void* color_tab, int entry,
+                         int ops, int blur_k, int median_k, double clahe_clip, void* out_u8, void* tmp_u8, void* luts_u8,
+                         int S, kodStream_t stream);
 
 /* ---- validation pre-processing: SampleReader (LongestMaxSize + PadIfNeeded(114), kod/data/sample_reader.py:16-40,
  *      102-136) + ValidationSampleAugmentor (ToFloat(255) + CHW, kod/data/augmentations/albu.py:91-119) ------------ */

@@ -498,6 +498,8 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA
 // ONE row in flight per thread and many blocks beat four rows per thread and 4 096 blocks on every size (the chip holds the
 // bytes in flight as resident waves instead of as registers: 6.5 M x 32 forward 191 -> 149 us, 1.6 M x 64 backward 134 ->
 // 111 us, 25 600 x 256 7.6 -> 6.2 us); tensors of >= 128 MB take 16 384 blocks, smaller ones 4 096 (more only adds ramp).
+static int bn_knob_u() { const char* e = getenv("KODHIP_BN_U"); const int u = e ? atoi(e) : 1; return (u == 2 || u == 4 || u == 8) ? u : 1; }
+static int bn_knob_grid() { const char* f = getenv("KODHIP_BN_GRID"); return f ? atoi(f) : 0; }
 static int apply_grid_cap(long M, int C) { return (M * C * 2 >= (128l << 20)) ? 16384 : 4096; }
 
 struct Geo { int threads, rpb, grid; };
@@ -641,13 +643,14 @@ int kodhip_bn_silu_apply(const void* y, int ldy, const float* scale, const float
   KOD_CHECK_ARG(y && scale && shift && out && M > 0, "bn_silu_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldo % 8 == 0 && ocoff % 8 == 0 && ocoff + C <= ldo, "bn_silu_apply: bad channel geometry");
   KOD_CHECK_ARG(!residual || (ldr % 8 == 0 && rcoff % 8 == 0 && rcoff + C <= ldr), "bn_silu_apply: bad residual slice");
-  static int tu = -1, tg = -1;            // A/B knobs: rows in flight per thread (KODHIP_BN_U = 2 | 4 | 8), grid cap (KODHIP_BN_GRID)
-  if (tu < 0) { const char* e = getenv("KODHIP_BN_U"); tu = e ? atoi(e) : 1; const char* f = getenv("KODHIP_BN_GRID"); tg = f ? atoi(f) : 0; }
+  // A/B knobs, read once (thread-safe: function-local static initialisers): rows in flight per thread (KODHIP_BN_U = 1 | 2 | 4 | 8;
+  // anything else means 1), grid cap (KODHIP_BN_GRID)
+  static const int tu = bn_knob_u(), tg = bn_knob_grid();
   Geo g = geo(M, C, tg ? tg : apply_grid_cap(M, C));
   KOD_CHECK_ARG(ldy % 8 == 0 && ldy >= C, "bn_silu_apply: bad row stride of y");
 #define KOD_APPLY(UU) hipLaunchKernelGGL(bn_silu_apply_kernel<UU>, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, ldy, scale, shift, \
                      (const bf16_t*)residual, ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb)
-  if (tu == 8) KOD_APPLY(8); else if (tu == 2) KOD_APPLY(2); else if (tu == 1) KOD_APPLY(1); else if (tu == 3) KOD_APPLY(3); else KOD_APPLY(4);
+  if (tu == 8) KOD_APPLY(8); else if (tu == 2) KOD_APPLY(2); else if (tu == 4) KOD_APPLY(4); else KOD_APPLY(1);
 #undef KOD_APPLY
   KOD_LAUNCH_CHECK("bn_silu_apply");
   return KOD_OK;
@@ -711,13 +714,12 @@ int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout,
   KOD_CHECK_ARG(dA && y_inout && scale && shift && coef && M > 0, "bn_silu_bwd_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda, "bn_silu_bwd_apply: bad geometry");
   KOD_CHECK_ARG(!dI || (ldi % 8 == 0 && dicoff % 8 == 0 && dicoff + C <= ldi), "bn_silu_bwd_apply: bad identity slice");
-  static int tu = -1, tg = -1;
-  if (tu < 0) { const char* e = getenv("KODHIP_BN_U"); tu = e ? atoi(e) : 1; const char* f = getenv("KODHIP_BN_GRID"); tg = f ? atoi(f) : 0; }
+  static const int tu = bn_knob_u(), tg = bn_knob_grid();
   Geo g = geo(M, C, tg ? tg : apply_grid_cap(M, C));
   KOD_CHECK_ARG(ldy % 8 == 0 && ldy >= C, "bn_silu_bwd_apply: bad row stride of y");
 #define KOD_BAPPLY(UU) hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<UU>, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)dA, lda, dacoff, \
                      (bf16_t*)y_inout, ldy, scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb)
-  if (tu == 8) KOD_BAPPLY(8); else if (tu == 2) KOD_BAPPLY(2); else if (tu == 1) KOD_BAPPLY(1); else if (tu == 3) KOD_BAPPLY(3); else KOD_BAPPLY(4);
+  if (tu == 8) KOD_BAPPLY(8); else if (tu == 2) KOD_BAPPLY(2); else if (tu == 4) KOD_BAPPLY(4); else KOD_BAPPLY(1);
 #undef KOD_BAPPLY
   KOD_LAUNCH_CHECK("bn_silu_bwd_apply");
   return KOD_OK;

@@ -1053,6 +1053,9 @@ __global__ __launch_bounds__(320, NT == 2 ? 3 : (TW == 160 ? 3 : 5)) void conv_s
         const long m = (long)row * a.Wo + ox0 + p;
         if (ox0 + p < a.Wo && c * 8 < a.N)
           vo = is_g ? (uint32_t)((m * a.lda + a.dacoff + c * 8) * 2) : (uint32_t)((m * a.ldy + c * 8) * 2);
+#ifdef KOD_ABL_STEMY      // (tools/build_ablate.sh: what the pre-BN tensor's read costs this kernel - y from one hot 4 KB instead)
+        if (!is_g) vo &= 0xFFFu;
+#endif
       }
 #if defined(__HIP_DEVICE_COMPILE__)
       if (i < NIX)

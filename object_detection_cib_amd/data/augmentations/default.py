@@ -9,7 +9,8 @@ the HSV round trip, the flip, /255 and HWC->CHW - are ONE launch of compose_kern
 comes back as a device tensor.  `sample.image` is either the DeviceCanvas MosaicAugmentor returned or a square u8
 HWC array (SampleReader output, kod/data/sample_reader.py:102-136), which is treated as a one-tile canvas.
 ``mixup(a, b)`` blends two such results in the same kernel.  The four p = 0.01 albumentations colour ops
-(image_color_transforms) are not on the HIP path: AugParams defaults to False and True raises.
+(image_color_transforms, on by default as in the reference) run on the device for the samples whose gate fires
+(kodhip_compose_color; the gate's own generator is seeded with rng_seed).
 """
 from __future__ import annotations
 
@@ -36,14 +37,10 @@ class _Composite(torch.Tensor):
 
 class TrainSampleAugmentor(object):
     def __init__(self, aug_params: AugParams, rng_seed: int = 51, device="cuda"):
-        if aug_params.image_color_transforms:
-            raise NotImplementedError(
-                "image_color_transforms=True (kod/configs/data/augmentations/aug_params.yaml:15: albumentations Blur / MedianBlur / "
-                "ToGray / CLAHE at p = 0.01 each, kod/data/augmentations/default.py:420-431) is not on the HIP path (SURVEY 2.1: out "
-                "of scope). Run the reference config with the Hydra override "
-                "`data.augmentations.aug_params.image_color_transforms=false` (or AugParams(image_color_transforms=False)).")
         self.aug_params = aug_params
         self.rng: np.random.Generator = np.random.default_rng(rng_seed)
+        import random
+        self.color_rng = random.Random(rng_seed)          # the colour Compose's own stream (host_protocol.color_gate)
         self.device = torch.device(device)
         self._tab = None
         self._stager = None
@@ -67,7 +64,7 @@ class TrainSampleAugmentor(object):
         descs = np.zeros((1, 2), dtype=SAMPLE_DESC)
         canvas.fill(descs[0, 0])
         bb, lb, out = augment_into(descs[0, 0], self.aug_params, self.rng, np.asarray(input_data.bboxes),
-                                   np.asarray(input_data.labels), canvas.size, border)
+                                   np.asarray(input_data.labels), canvas.size, border, color_rng=self.color_rng)
         mix = np.array([[-1.0, 0.0]], dtype=np.float32)
         img, _, _ = compose(canvas.pool, descs, mix, canvas.tab, out, canvas.stager)
         return AugmentedSample(image=_Composite.wrap(img[0], canvas, descs[0, 0].copy(), out), bboxes=bb, labels=lb)

@@ -9,8 +9,9 @@ Mirrors (same draw order, same arithmetic for boxes):
   TrainSampleAugmentor.__call__         kod/data/augmentations/default.py:440-488
   random_perspective / boxes / flip     kod/data/augmentations/default.py:111-351,386-397
   mixup                                 kod/data/augmentations/default.py:400-408
-The four p=0.01 albumentations colour ops (Blur / MedianBlur / ToGray / CLAHE, default.py:420-431) are not
-applied (out of scope; equals `image_color_transforms: false`).
+The four p=0.01 albumentations colour ops (Blur / MedianBlur / ToGray / CLAHE, default.py:420-432,460-461:
+`image_color_transforms`, on by default like in the reference) run on the device for the samples whose gate fired
+(csrc/compose.hip kodhip_compose_color; gate: host_protocol.color_gate).
 """
 from __future__ import annotations
 
@@ -26,7 +27,56 @@ from .detection import DetectionTarget
 
 
 from .host_protocol import (AffineParams, HSVParams, AugParams, SAMPLE_DESC, HostProtocol, PackedTargets, pack_targets,   # noqa: F401
-                            mosaic_layout, mosaic_boxes, affine_matrix, invert_affine, affine_boxes, augment_into, _box_candidates)
+                            mosaic_layout, mosaic_boxes, affine_matrix, invert_affine, affine_boxes, augment_into, _box_candidates,
+                            color_gate)
+
+
+def color_table() -> np.ndarray:
+    """Integer tables of the colour stage's 8-bit RGB <-> Lab round trip (CLAHE runs on L; csrc/compose.hip LabTab), as one
+    byte array: gamma u16[256] | cube root u16[3072] | forward matrix i32[9] | inverse matrix i32[9] | fy, dfx, dfz i32[256]
+    each | gamma encoding u8[4096].  Forward: OpenCV's RGB2Lab_b scheme (color_lab.cpp: sRGB gamma table x 8, Q12 matrix over
+    the D65 white point, Q15 cube-root table); inverse: f values per byte in Q15, the inverse of f in exact integer
+    arithmetic in the kernel, Q12 inverse matrix, gamma encoding by table (OpenCV 4's integer Lab2RGB is not restated;
+    parity unpinned).  Same numbers as oracle/datapath.lab_tables()."""
+    i = np.arange(256, dtype=np.float64) / 255.0
+    gamma = np.clip(np.rint(255.0 * 8 * np.where(i <= 0.04045, i / 12.92, ((i + 0.055) / 1.055) ** 2.4)), 0, 65535).astype(np.uint16)
+    x = np.arange(3072, dtype=np.float64) / (255.0 * 8)
+    cbrt = np.clip(np.rint(32768.0 * np.where(x < 0.008856, x * 7.787 + 16.0 / 116.0, np.cbrt(x))), 0, 65535).astype(np.uint16)
+    co = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    white = np.array([0.950456, 1.0, 1.088754])
+    C = np.rint(4096.0 * co / white[:, None]).astype(np.int32)
+    Cinv = np.rint(4096.0 * np.linalg.inv(co) * white[None, :]).astype(np.int32)
+    v = np.arange(256, dtype=np.float64)
+    fy = np.rint(32768.0 * (v * 100.0 / 255.0 + 16.0) / 116.0).astype(np.int32)
+    dfx = np.rint(32768.0 * (v - 128.0) / 500.0).astype(np.int32)
+    dfz = np.rint(32768.0 * (v - 128.0) / 200.0).astype(np.int32)
+    u = np.arange(4096, dtype=np.float64) / 4095.0
+    enc = np.clip(np.rint(255.0 * np.where(u <= 0.0031308, 12.92 * u, 1.055 * u ** (1 / 2.4) - 0.055)), 0, 255).astype(np.uint8)
+    parts = [gamma, cbrt, C.reshape(-1), Cinv.reshape(-1), fy, dfx, dfz, enc]
+    out = np.concatenate([np.ascontiguousarray(a).view(np.uint8).reshape(-1) for a in parts])
+    assert out.size == 9800 + 4096
+    return out
+
+
+_COLOR_TABS = {}
+
+
+def _color_stage(pool: torch.Tensor, descs: np.ndarray, mix: np.ndarray, S: int):
+    """Entries (2 * sample + slot) of descs [B][2] whose colour gate fired, and the u8 scratch images the stage leaves its
+    results in; sets every such descriptor's `pre` (so call BEFORE descs is uploaded).  Returns [] or
+    [(entry, ops, blur_k, median_k, clip, out, tmp, luts)]."""
+    hit = [(b, s) for b, s in zip(*np.nonzero(descs["color"])) if s == 0 or mix[b, 0] >= 0]
+    if not hit:
+        return []
+    scratch = torch.empty((len(hit), 2, S * S * 3 + 64 * 256), dtype=torch.uint8, device=pool.device)
+    jobs = []
+    for k, (b, s) in enumerate(hit):
+        d = descs[b, s]
+        out, tmp = scratch[k, 0], scratch[k, 1]
+        d["pre"] = out.data_ptr()
+        jobs.append((int(b) * 2 + int(s), int(d["color"]), int(d["blur_k"]), int(d["median_k"]), float(d["clahe_clip"]),
+                     out, tmp, tmp[S * S * 3:]))
+    return jobs
 
 
 def bilinear_table() -> np.ndarray:
@@ -85,8 +135,17 @@ def compose(pool: torch.Tensor, descs: np.ndarray, mix: np.ndarray, tab: torch.T
     """One launch of compose_kernel for descs [B][2] / mix [B][2]; returns (f32 [B,3,S,S] | None, pairs | None).
     pairs_out: write the pixel pairs into this tensor (the network's own input buffer, Engine.image_buffer) instead of a new one."""
     B = descs.shape[0]
+    jobs = _color_stage(pool, descs, mix, S)                 # image_color_transforms: the ~4 % of samples whose gate fired
     d_dev = stager.upload(descs)
     m_dev = stager.upload(mix).view(torch.float32)
+    if jobs:
+        ctab = _COLOR_TABS.get(pool.device)
+        if ctab is None:
+            ctab = _COLOR_TABS[pool.device] = torch.from_numpy(color_table()).to(pool.device)
+        for entry, ops, kb, km, clip, out, tmp, luts in jobs:
+            _lib.check(_lib.lib().kodhip_compose_color(pool.data_ptr(), d_dev.data_ptr(), tab.data_ptr(), ctab.data_ptr(), entry,
+                                                       ops, kb, km, clip, out.data_ptr(), tmp.data_ptr(), luts.data_ptr(), S,
+                                                       torch.cuda.current_stream().cuda_stream), "compose_color")
     img = torch.empty((B, 3, S, S), dtype=torch.float32, device=pool.device) if out_f32 else None
     pairs = None
     if out_pairs:
@@ -99,7 +158,7 @@ def compose(pool: torch.Tensor, descs: np.ndarray, mix: np.ndarray, tab: torch.T
                                                img.data_ptr() if out_f32 else None,
                                                pairs.data_ptr() if out_pairs else None, B, S,
                                                torch.cuda.current_stream().cuda_stream), "compose_batch")
-    return img, pairs, (d_dev, m_dev)
+    return img, pairs, (d_dev, m_dev, jobs)
 
 
 class ImagePool:

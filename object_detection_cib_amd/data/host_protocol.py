@@ -36,7 +36,7 @@ class AugParams(NamedTuple):               # default.py:80-108
     affine_params: AffineParams = AffineParams()
     hsv_params: HSVParams = HSVParams()
     flip_lr_prob: float = 0.5
-    image_color_transforms: bool = False
+    image_color_transforms: bool = True    # (the reference's default, default.py:85 / aug_params.yaml:15)
 
 
 # ----------------------------------------------------------------------------- host box / matrix math (numpy f64)
@@ -127,17 +127,46 @@ def affine_boxes(boxes, M, w_out, h_out, scale, perspective: bool = False):
 _TILE = np.dtype([("off", "<i8"), ("h", "<i4"), ("w", "<i4"), ("x1a", "<i4"), ("y1a", "<i4"), ("x2a", "<i4"),
                   ("y2a", "<i4"), ("x1b", "<i4"), ("y1b", "<i4")], align=True)
 SAMPLE_DESC = np.dtype([("tile", _TILE, (4,)), ("im", "<f8", (6,)), ("pw", "<f8", (3,)), ("lut_h", "u1", (256,)), ("lut_s", "u1", (256,)),
-                        ("lut_v", "u1", (256,)), ("hsv_on", "<i4"), ("flip", "<i4"), ("canvas", "<i4"), ("persp", "<i4")], align=True)
+                        ("lut_v", "u1", (256,)), ("hsv_on", "<i4"), ("flip", "<i4"), ("canvas", "<i4"), ("persp", "<i4"),
+                        ("color", "<i4"), ("blur_k", "<i4"), ("median_k", "<i4"), ("pad0", "<i4"), ("pre", "<u8"), ("clahe_clip", "<f8")], align=True)
+
+# ---- image_color_transforms (default.py:420-432,460-461): A.Compose([A.Blur(p=0.01), A.MedianBlur(p=0.01), A.ToGray(p=0.01),
+# A.CLAHE(p=0.01)]) on the warped u8 image, before the HSV jitter.  The gate below is the library's draw protocol (Compose: one
+# draw against its p = 1; every transform: one draw against its p; Blur / MedianBlur: a choice among the odd kernel sizes 3..7;
+# CLAHE: uniform(1, 4.0) clip limit, 8 x 8 tiles) on a generator of the stage's OWN (albumentations >= 1.4 keeps one per
+# Compose; 1.3.x drew from python's global `random`, interleaving with DetectionDataset's index draws - the reference does
+# not pin the version, requirements.txt:26).  albumentations is not installed here: protocol and pixel arithmetic are
+# restatements (parity unpinned); what tests/golden/protocol.npz pins is the stage's position.
+COLOR_BLUR, COLOR_MEDIAN, COLOR_GRAY, COLOR_CLAHE = 1, 2, 4, 8
 
 
-def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas: int, border, always_warp: bool = False):
+def color_gate(g: "_random.Random", p: float = 0.01):
+    """(ops bit mask, blur ksize, median ksize, CLAHE clip limit) of one call of the colour Compose"""
+    ops, kb, km, clip = 0, 0, 0, 0.0
+    g.random()
+    if g.random() < p:
+        ops |= COLOR_BLUR
+        kb = int(g.choice(list(range(3, 8, 2))))
+    if g.random() < p:
+        ops |= COLOR_MEDIAN
+        km = int(g.choice(list(range(3, 8, 2))))
+    if g.random() < p:
+        ops |= COLOR_GRAY
+    if g.random() < p:
+        ops |= COLOR_CLAHE
+        clip = float(g.uniform(1, 4.0))
+    return ops, kb, km, clip
+
+
+def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas: int, border, always_warp: bool = False,
+                 color_rng=None):
     """TrainSampleAugmentor.__call__ (default.py:440-488) for one sample: consumes the augmentor's generator in the
     reference's order (8 affine draws, 3 HSV draws, 1 flip draw), writes the pixel-side parameters (inverse affine
-    matrix, HSV LUTs, flip flag) into the compositing descriptor and returns the transformed boxes / labels and the
-    output image side."""
+    matrix, colour-stage draws, HSV LUTs, flip flag) into the compositing descriptor and returns the transformed boxes /
+    labels and the output image side.  color_rng: the colour stage's generator (needed when aug.image_color_transforms)."""
     ap = aug.affine_params
     desc["persp"] = 0
-    if not always_warp and ap.degrees == 0.0 and ap.translate == 0.0 and ap.scale == 0.0 and ap.shear == 0.0:
+    if not always_warp and ap.degrees == 0.0 and ap.translate == 0.0 and ap.scale == 0.0 and ap.shear == 0.0 and ap.perspective == 0.0:
         # AffineParams.should_aug() is False (default.py:38-48,445-457): no draws, no warp, the image keeps its size
         wo = ho = canvas
         desc["im"] = np.array([1.0, 0.0, 0.0, 0.0, 1.0, 0.0])
@@ -156,6 +185,10 @@ def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas:
         if len(lb):
             nb, keep = affine_boxes(bb, M, wo, ho, draws[3], perspective=persp)
             bb, lb = nb[keep], lb[keep]
+    desc["color"], desc["blur_k"], desc["median_k"], desc["clahe_clip"], desc["pre"] = 0, 0, 0, 0.0, 0
+    if aug.image_color_transforms:                       # default.py:460-461: between the warp and the HSV jitter
+        assert color_rng is not None, "image_color_transforms=True needs the colour stage's generator"
+        desc["color"], desc["blur_k"], desc["median_k"], desc["clahe_clip"] = color_gate(color_rng)
     hp = aug.hsv_params
     if hp.hue == 0.0 and hp.saturation == 0.0 and hp.value == 0.0:
         desc["hsv_on"] = 0
@@ -193,6 +226,7 @@ class HostProtocol:
         self.aug = aug_params
         self.mixup_prob = mixup_prob
         self.rng = np.random.default_rng(rng_seed)            # default.py:415
+        self.color_rng = _random.Random(rng_seed) if aug_params.image_color_transforms else None     # the colour Compose's own stream
         self.weights = image_repeat_factors
         self.sampler_indices = sampler_indices if sampler_indices is not None else range(len(self.shapes))
 
@@ -212,7 +246,7 @@ class HostProtocol:
             d["x1b"], d["y1b"] = b
         # always_warp: a batch is S x S, so the affine stage (which crops the 2S canvas to S) runs even when no jitter
         # is configured (the reference would hand 2S x 2S images to the collate function in that case)
-        bb, lb, _ = augment_into(desc, self.aug, self.rng, bb, lb, 2 * S, border, always_warp=True)
+        bb, lb, _ = augment_into(desc, self.aug, self.rng, bb, lb, 2 * S, border, always_warp=True, color_rng=self.color_rng)
         return bb, lb
 
     def batch(self, batch_indices: Sequence[int]):

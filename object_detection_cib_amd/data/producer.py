@@ -93,7 +93,10 @@ def _worker(shm_name: str, slots: int, B: int, cap: int, host_args: dict, rng_se
             v["boxes"][:n], v["labels"][:n], v["samples"][:n] = pt.boxes[:n], pt.labels[:n], pt.samples[:n]
             v["counts"][...] = pt.counts
             del v
-            ctrl[0] = seq + 1                                      # published after the slot's contents
+            # published after the slot's contents: the ring relies on x86-64's store ordering (TSO: stores of one thread
+            # become visible in program order; numpy's copies above are plain stores) and on the interpreter not reordering
+            # statements; the consumer reads ctrl[0] before the slot.  A weaker memory model would need a release fence here
+            ctrl[0] = seq + 1
     finally:
         del ctrl
         shm.close()
@@ -109,8 +112,11 @@ def _main():
     except Exception:      # noqa: BLE001
         pass
     job = pickle.load(sys.stdin.buffer)
-    if os.getppid() != job["parent"]:                  # the trainer died before the death signal was armed
-        return
+    if os.getppid() != job["parent"]:
+        # the trainer died before the death signal was armed - or this interpreter was not started by it directly (a
+        # `sys.executable` that is a forking shim): say so instead of leaving "producer died (exit code 0)" behind
+        print(f"descriptor producer: parent is {os.getppid()}, the job names {job['parent']}; leaving", file=sys.stderr)
+        sys.exit(3)
     _worker(job["shm"], job["slots"], job["B"], job["cap"], job["host_args"], job["rng_seed"], job["py_seed"], job["np_seed"],
             job["schedule"], job["parent"])
 
@@ -180,9 +186,13 @@ class DescriptorProducer:
             self.proc.kill()
             self.proc.wait(5.0)
         self.ctrl = None
-        self.shm.close()
-        self.shm.unlink()
-        self.shm = None
+        shm, self.shm = self.shm, None
+        try:
+            shm.close()               # (BufferError while a caller still holds views of a slot, e.g. after next() raised)
+        except BufferError:
+            pass
+        finally:
+            shm.unlink()              # the /dev/shm segment goes away whatever happened above
 
     def __del__(self):
         try:

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from ...engine.graph import build_csp_block_graph, build_csp_layer_graph
+from .activations import SiLUInplace
 from ..graph_module import GraphModule, check_norm_act
 
 
@@ -14,7 +15,7 @@ class CSPBlock(GraphModule):
     """conv2_3x3(conv1_1x1(x)) [+ x when add_identity and in == out]; hidden = int(out * expand_ratio) (csp.py:16-58)."""
 
     def __init__(self, in_channels: int, out_channels: int, expand_ratio: float = 0.5, add_identity: bool = True,
-                 norm_layer: Callable[..., nn.Module] = None, activation_layer: Callable[..., nn.Module] = None):
+                 norm_layer: Callable[..., nn.Module] = nn.BatchNorm2d, activation_layer: Callable[..., nn.Module] = SiLUInplace):
         super().__init__()
         check_norm_act(norm_layer, activation_layer)
         self.add_identity = add_identity and in_channels == out_channels
@@ -29,8 +30,8 @@ class CSPLayer(GraphModule):
     expand ratio 1 (csp.py:66-111); the concatenation is a channel-slice write, never a copy."""
 
     def __init__(self, in_channels: int, out_channels: int, expand_ratio: float = 0.5, add_identity: bool = True,
-                 num_blocks: int = 1, norm_layer: Callable[..., nn.Module] = None,
-                 activation_layer: Callable[..., nn.Module] = None):
+                 num_blocks: int = 1, norm_layer: Callable[..., nn.Module] = nn.BatchNorm2d,
+                 activation_layer: Callable[..., nn.Module] = SiLUInplace):
         super().__init__()
         check_norm_act(norm_layer, activation_layer)
         self._init_graph(build_csp_layer_graph(in_channels, out_channels, expand_ratio, add_identity, num_blocks), norm_layer)

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from ...engine.graph import build_sppf_graph
+from .activations import SiLUInplace
 from ..graph_module import GraphModule, check_norm_act
 
 
@@ -26,8 +27,8 @@ class SPPFBottleneck(GraphModule):
     is a 5 x 5 window, csrc/misc_ops.hip maxpool5_*)."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_sizes: int | Sequence[int] = 5, use_conv_first: bool = True,
-                 mid_channels_scale: float = 0.5, norm_layer: Callable[..., nn.Module] = None,
-                 activation_layer: Callable[..., nn.Module] = None):
+                 mid_channels_scale: float = 0.5, norm_layer: Callable[..., nn.Module] = nn.BatchNorm2d,
+                 activation_layer: Callable[..., nn.Module] = SiLUInplace):
         super().__init__()
         check_norm_act(norm_layer, activation_layer)
         if not _as_cascade(kernel_sizes):

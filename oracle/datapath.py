@@ -320,11 +320,14 @@ def augment_hsv_u8(img: np.ndarray, r3: np.ndarray) -> np.ndarray:
 
 # ----------------------------------------------------------------------------- whole-sample protocol
 def augment_sample(canvas, boxes, labels, border, S, rng: np.random.Generator, hsv=(0.015, 0.7, 0.4),
-                   flip_prob=0.5, translate=0.1, scale=0.5, degrees=0.0, shear=0.0, perspective=0.0, log=None):
-    """TrainSampleAugmentor.__call__ (default.py:440-488) without the four p=0.01 albumentations colour ops
-    (image_color_transforms=False, kod/configs/data/augmentations/no_aug_params.yaml:15).  Draw order of the augmentor's
-    generator: 8 affine uniforms, 3 HSV uniforms (one call), 1 flip draw - the flip draw only when flip_prob > 0
-    (AugParams.should_flip short-circuits, default.py:98-99).  log: dict that receives M / LUTs / flip."""
+                   flip_prob=0.5, translate=0.1, scale=0.5, degrees=0.0, shear=0.0, perspective=0.0, log=None,
+                   color=None):
+    """TrainSampleAugmentor.__call__ (default.py:440-488).  Draw order of the augmentor's generator: 8 affine uniforms,
+    3 HSV uniforms (one call), 1 flip draw - the flip draw only when flip_prob > 0 (AugParams.should_flip short-circuits,
+    default.py:98-99).  color: None, or the generator (`random.Random`) of the image_color_transforms stage
+    (default.py:420-432,460-461; the reference's default, configs/data/augmentations/aug_params.yaml:15) - the
+    albumentations Compose between warp and HSV draws from the LIBRARY's generator, see color_gate.  log: dict that
+    receives M / LUTs / flip / colour draws."""
     draws = affine_draws(rng, degrees=degrees, translate=translate, scale=scale, shear=shear, perspective=perspective)
     M, (wo, ho) = affine_matrix(draws, canvas.shape[1], canvas.shape[0], border)
     persp = draws[0] != 0 or draws[1] != 0                      # default.py:306-320: warpPerspective iff a perspective draw is non-zero
@@ -332,6 +335,10 @@ def augment_sample(canvas, boxes, labels, border, S, rng: np.random.Generator, h
     if len(labels):
         nb, keep = (perspective_boxes if persp else affine_boxes)(boxes, M, wo, ho, draws[3])
         boxes, labels = nb[keep], labels[keep]
+    cdraw = None
+    if color is not None:
+        cdraw = color_gate(color)
+        img = apply_color_ops(img, *cdraw)
     luts = None
     if not (hsv[0] == 0.0 and hsv[1] == 0.0 and hsv[2] == 0.0):
         r3 = rng.uniform(-1, 1, 3) * list(hsv) + 1
@@ -342,7 +349,7 @@ def augment_sample(canvas, boxes, labels, border, S, rng: np.random.Generator, h
         img = np.fliplr(img)
         boxes = flip_boxes(boxes, img.shape[1])
     if log is not None:
-        log.update(M=M, dsize=(wo, ho), luts=luts, flip=flip)
+        log.update(M=M, dsize=(wo, ho), luts=luts, flip=flip, color=cdraw)
     chw = np.ascontiguousarray(img.transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0)
     return chw, boxes, labels
 
@@ -454,3 +461,180 @@ def val_sample(img: np.ndarray, boxes: np.ndarray, S: int):
         b[:, [0, 2]] = b[:, [0, 2]] / w * nw + left
         b[:, [1, 3]] = b[:, [1, 3]] / h * nh + top
     return out, b
+
+
+# ----------------------------------------------------------------------------- image_color_transforms (default.py:420-432,460-461)
+# TrainSampleAugmentor's albumentations stage between the warp and the HSV jitter: A.Compose([A.Blur(p=0.01),
+# A.MedianBlur(p=0.01), A.ToGray(p=0.01), A.CLAHE(p=0.01)]).  albumentations is neither in the reference tree nor in this image
+# and the reference does not pin its version (requirements.txt:26): the GATE below restates the library's draw protocol
+# (core/composition.py Compose.__call__: one draw against the Compose's own p = 1; core/transforms_interface.py
+# BasicTransform.__call__: one draw per transform against its p; Blur / MedianBlur.get_params: a choice among the odd kernel
+# sizes 3..7; CLAHE.get_params: uniform(1, clip_limit = 4.0)) on a generator of the stage's OWN - albumentations >= 1.4 keeps
+# a generator per Compose; 1.3.x drew from python's global `random` instead, where these draws (and three more per call of
+# the ToFloat / ToTensorV2 Compose) would interleave with DetectionDataset's index draws: a library-version effect the
+# reference leaves open, modelled here as the separate stream - and the pixel operations restate OpenCV's published
+# algorithms (cv2.blur: box filter,
+# BORDER_REFLECT_101; cv2.medianBlur: BORDER_REPLICATE; RGB2GRAY: 15-bit fixed point; CLAHE: imgproc/src/clahe.cpp, on the L
+# channel of an 8-bit Lab image).  PARITY UNPINNED, like every other OpenCV restatement in this file - what the reference
+# pins is WHERE the stage sits (between random_perspective and augment_hsv) and that it runs at all.
+COLOR_BLUR, COLOR_MEDIAN, COLOR_GRAY, COLOR_CLAHE = 1, 2, 4, 8
+
+
+def color_gate(rnd=random, p: float = 0.01):
+    """The draws of one call of the colour Compose: (ops bit mask, blur ksize, median ksize, CLAHE clip limit)."""
+    ops, kb, km, clip = 0, 0, 0, 0.0
+    rnd.random()                                             # Compose.__call__: need_to_run = random.random() < self.p (p = 1)
+    if rnd.random() < p:                                     # Blur(blur_limit=7): ksize in {3, 5, 7}
+        ops |= COLOR_BLUR
+        kb = int(rnd.choice(list(range(3, 8, 2))))
+    if rnd.random() < p:                                     # MedianBlur(blur_limit=7)
+        ops |= COLOR_MEDIAN
+        km = int(rnd.choice(list(range(3, 8, 2))))
+    if rnd.random() < p:                                     # ToGray
+        ops |= COLOR_GRAY
+    if rnd.random() < p:                                     # CLAHE(clip_limit=4.0 -> (1, 4.0), tile_grid_size=(8, 8))
+        ops |= COLOR_CLAHE
+        clip = float(rnd.uniform(1, 4.0))
+    return ops, kb, km, clip
+
+
+def _reflect101(i, n):
+    i = np.abs(i)
+    return np.where(i >= n, 2 * (n - 1) - i, i)
+
+
+def blur_u8(img: np.ndarray, k: int) -> np.ndarray:
+    """cv2.blur(img, (k, k)): normalised box filter, BORDER_REFLECT_101, out = cvRound(sum * (1 / k^2)) (half to even)."""
+    h, w = img.shape[:2]
+    r = k // 2
+    yy = _reflect101(np.arange(-r, h + r), h)
+    xx = _reflect101(np.arange(-r, w + r), w)
+    p = img[yy][:, xx].astype(np.int64)
+    s = np.zeros(img.shape, np.int64)
+    for dy in range(k):
+        for dx in range(k):
+            s += p[dy:dy + h, dx:dx + w]
+    return np.clip(np.rint(s.astype(np.float64) * (1.0 / (k * k))), 0, 255).astype(np.uint8)
+
+
+def median_blur_u8(img: np.ndarray, k: int) -> np.ndarray:
+    """cv2.medianBlur(img, k): per-channel median of the k x k window, BORDER_REPLICATE."""
+    h, w = img.shape[:2]
+    r = k // 2
+    p = img[np.clip(np.arange(-r, h + r), 0, h - 1)][:, np.clip(np.arange(-r, w + r), 0, w - 1)]
+    win = np.lib.stride_tricks.sliding_window_view(p, (k, k), axis=(0, 1))          # [h][w][c][k][k]
+    return np.sort(win.reshape(h, w, img.shape[2], k * k), axis=-1)[..., (k * k) // 2].astype(np.uint8)
+
+
+def to_gray_u8(img: np.ndarray) -> np.ndarray:
+    """albumentations ToGray: cvtColor(RGB2GRAY) then GRAY2RGB - OpenCV's 15-bit weights on channels 0, 1, 2."""
+    v = img.astype(np.int64)
+    y = (v[..., 0] * 9798 + v[..., 1] * 19235 + v[..., 2] * 3735 + (1 << 14)) >> 15
+    return np.repeat(y[..., None], 3, -1).astype(np.uint8)
+
+
+def lab_tables():
+    """Integer tables of the 8-bit RGB <-> Lab round trip (sRGB, D65).  Forward: OpenCV's RGB2Lab_b scheme (color_lab.cpp:
+    gamma table x 8, 12-bit matrix, 15-bit cube-root table of 3072 entries).  Inverse: this file's own integer scheme (OpenCV
+    4's Lab2RGBinteger could not be restated from its description alone): Q15 f values from per-byte tables, the inverse of f
+    in exact integer arithmetic (cube in 64 bits -> Q16), a 12-bit inverse matrix, gamma encoding on a 4096-entry table.
+    Returns (gamma u16[256], cbrt u16[3072], C i32[3][3], fy i32[256], dfx i32[256], dfz i32[256], Cinv i32[3][3], enc u8[4096])."""
+    i = np.arange(256, dtype=np.float64) / 255.0
+    lin = np.where(i <= 0.04045, i / 12.92, ((i + 0.055) / 1.055) ** 2.4)
+    gamma = np.clip(np.rint(255.0 * 8 * lin), 0, 65535).astype(np.uint16)
+    x = np.arange(3072, dtype=np.float64) / (255.0 * 8)
+    cbrt = np.clip(np.rint(32768.0 * np.where(x < 0.008856, x * 7.787 + 16.0 / 116.0, np.cbrt(x))), 0, 65535).astype(np.uint16)
+    co = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    white = np.array([0.950456, 1.0, 1.088754])
+    C = np.rint(4096.0 * co / white[:, None]).astype(np.int32)
+    v = np.arange(256, dtype=np.float64)
+    fy = np.rint(32768.0 * (v * 100.0 / 255.0 + 16.0) / 116.0).astype(np.int32)
+    dfx = np.rint(32768.0 * (v - 128.0) / 500.0).astype(np.int32)
+    dfz = np.rint(32768.0 * (v - 128.0) / 200.0).astype(np.int32)
+    Cinv = np.rint(4096.0 * np.linalg.inv(co) * white[None, :]).astype(np.int32)
+    u = np.arange(4096, dtype=np.float64) / 4095.0
+    enc = np.clip(np.rint(255.0 * np.where(u <= 0.0031308, 12.92 * u, 1.055 * u ** (1 / 2.4) - 0.055)), 0, 255).astype(np.uint8)
+    return gamma, cbrt, C, fy, dfx, dfz, Cinv, enc
+
+
+LAB_T0, LAB_T1, LAB_K = 6780, 4520, 16832        # Q15 6/29 and 4/29; 3 (6/29)^2 / 8 in Q20 (Q15 f -> Q16 value below the knee)
+
+
+def rgb2lab_u8(img: np.ndarray, T=None) -> np.ndarray:
+    gamma, cbrt, C = (T or lab_tables())[:3]
+    lin = gamma[img].astype(np.int64)                                                   # [h][w][3]
+    f = [cbrt[(lin @ C[r].astype(np.int64) + (1 << 11)) >> 12].astype(np.int64) for r in range(3)]
+    Lscale, Lshift = (116 * 255 + 50) // 100, -((16 * 255 * (1 << 15) + 50) // 100)
+    L = (Lscale * f[1] + Lshift + (1 << 14)) >> 15
+    a = (500 * (f[0] - f[1]) + 128 * (1 << 15) + (1 << 14)) >> 15
+    b = (200 * (f[1] - f[2]) + 128 * (1 << 15) + (1 << 14)) >> 15
+    return np.clip(np.stack((L, a, b), -1), 0, 255).astype(np.uint8)
+
+
+def lab2rgb_u8(lab: np.ndarray, T=None) -> np.ndarray:
+    _, _, _, fy, dfx, dfz, Cinv, enc = T or lab_tables()
+    y = fy[lab[..., 0]].astype(np.int64)
+    f = np.clip(np.stack((y + dfx[lab[..., 1]], y, y - dfz[lab[..., 2]]), -1), 0, 65535)
+    xyz = np.where(f > LAB_T0, (f * f * f + (1 << 28)) >> 29, np.maximum((LAB_K * (f - LAB_T1) * 16 + (1 << 19)) >> 20, 0))      # Q16
+    lin = np.stack([(xyz @ Cinv[r].astype(np.int64) + (1 << 15)) >> 16 for r in range(3)], -1)                             # Q12
+    return enc[np.clip(lin, 0, 4095)]
+
+
+def clahe_plane_u8(src: np.ndarray, clip: float, grid: int = 8) -> np.ndarray:
+    """cv::CLAHE::apply on one 8-bit plane (imgproc/src/clahe.cpp): per-tile histogram, clip + redistribute, cumulative LUT,
+    bilinear interpolation of the four neighbouring tiles' LUTs (float32, cvRound)."""
+    h, w = src.shape
+    ph, pw = (grid - h % grid) % grid, (grid - w % grid) % grid
+    pad = src[_reflect101(np.arange(h + ph), h)][:, _reflect101(np.arange(w + pw), w)] if (ph or pw) else src
+    th, tw = pad.shape[0] // grid, pad.shape[1] // grid
+    area = th * tw
+    cl = max(int(clip * area / 256), 1)
+    scale = np.float32(255.0) / np.float32(area)
+    luts = np.zeros((grid, grid, 256), np.uint8)
+    for ty in range(grid):
+        for tx in range(grid):
+            hist = np.bincount(pad[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].reshape(-1), minlength=256).astype(np.int64)
+            clipped = int(np.maximum(hist - cl, 0).sum())
+            hist = np.minimum(hist, cl)
+            batch, residual = clipped // 256, clipped % 256
+            hist += batch
+            if residual:
+                step = max(256 // residual, 1)
+                idx = np.arange(0, 256, step)[:residual]
+                hist[idx] += 1
+            cum = np.cumsum(hist).astype(np.float32)
+            luts[ty, tx] = np.clip(np.rint(cum * scale), 0, 255).astype(np.uint8)
+
+    def axis(n, t):
+        f = np.arange(n, dtype=np.float32) * (np.float32(1.0) / np.float32(t)) - np.float32(0.5)
+        t1 = np.floor(f).astype(np.int64)
+        a = f - t1.astype(np.float32)
+        return np.maximum(t1, 0), np.minimum(t1 + 1, grid - 1), a, np.float32(1.0) - a
+    ty1, ty2, ya, ya1 = axis(h, th)
+    tx1, tx2, xa, xa1 = axis(w, tw)
+    v = src.astype(np.int64)
+    g = lambda ty, tx: luts[ty[:, None], tx[None, :], v].astype(np.float32)
+    res = (g(ty1, tx1) * xa1[None, :] + g(ty1, tx2) * xa[None, :]) * ya1[:, None] + \
+          (g(ty2, tx1) * xa1[None, :] + g(ty2, tx2) * xa[None, :]) * ya[:, None]
+    return np.clip(np.rint(res), 0, 255).astype(np.uint8)
+
+
+def clahe_u8(img: np.ndarray, clip: float) -> np.ndarray:
+    """albumentations F.clahe on an RGB image: RGB2LAB, CLAHE(clip, 8 x 8) on L, LAB2RGB."""
+    T = lab_tables()
+    lab = rgb2lab_u8(img, T)
+    lab[..., 0] = clahe_plane_u8(lab[..., 0], clip)
+    return lab2rgb_u8(lab, T)
+
+
+def apply_color_ops(img: np.ndarray, ops: int, kb: int, km: int, clip: float) -> np.ndarray:
+    """the fired transforms in Compose order"""
+    if ops & COLOR_BLUR:
+        img = blur_u8(img, kb)
+    if ops & COLOR_MEDIAN:
+        img = median_blur_u8(img, km)
+    if ops & COLOR_GRAY:
+        img = to_gray_u8(img)
+    if ops & COLOR_CLAHE:
+        img = clahe_u8(img, clip)
+    return img

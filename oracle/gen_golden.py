@@ -369,7 +369,9 @@ def gen_protocol():
             hsv = over.get("hsv", (0.015, 0.7, 0.4))
             params = D.AugParams(affine_params=D.AffineParams(degrees=over.get("degrees", 0.0), shear=over.get("shear", 0.0),
                                                               perspective=over.get("perspective", 0.0)),
-                                 hsv_params=D.HSVParams(*hsv), flip_lr_prob=over.get("flip", 0.5), image_color_transforms=False)
+                                 hsv_params=D.HSVParams(*hsv), flip_lr_prob=over.get("flip", 0.5),
+                                 image_color_transforms=bool(over.get("color", False)))
+            rec.color_rng = random.Random(synth.PROTOCOL_COLOR_SEED) if over.get("color") else None
             aug = D.TrainSampleAugmentor(params, rng_seed=51)
 
             def augmentor(sample, border=(0, 0), _aug=aug):
@@ -395,6 +397,9 @@ def gen_protocol():
             ccrc = np.zeros((N, 2), np.int64)
             icrc = np.zeros(N, np.int64)
             mb, mbn, fb, fl, fn = [], np.zeros((N, 2), np.int64), [], [], np.zeros(N, np.int64)
+            col = np.zeros((N, 2, 3), np.int64)                       # colour stage per augmentor call: ops bit mask, blur ksize, median ksize
+            col_clip = np.zeros((N, 2))                               # ... CLAHE clip limit
+            col_pos = np.full((N, 2), -1, np.int64)                   # ... 1 = the stage ran AFTER the warp and BEFORE the first LUT
             for k in range(N):
                 rec.take()
                 smp = ds[k % n]
@@ -418,6 +423,17 @@ def gen_protocol():
                         Ms[k, stage] = p["M"]; dsize[k, stage] = p["dsize"]
                     elif e == "LUT":
                         luts[k, stage, n_lut[k, stage]] = p["lut"]; n_lut[k, stage] += 1
+                    elif e == "color_stage":
+                        assert p["n"] == 4
+                        col_pos[k, stage] = int(not np.isnan(Ms[k, stage]).all() and n_lut[k, stage] == 0 and flips[k, stage] == 0)
+                    elif e == "color":
+                        col[k, stage, 0] |= p["bit"]
+                        if p["op"] == "Blur":
+                            col[k, stage, 1] = p["ksize"]
+                        elif p["op"] == "MedianBlur":
+                            col[k, stage, 2] = p["ksize"]
+                        elif p["op"] == "CLAHE":
+                            col_clip[k, stage] = p["clip_limit"]
                     elif e == "flip":
                         flips[k, stage] = 1
                     elif e == "beta":
@@ -432,6 +448,8 @@ def gen_protocol():
                         p + "mosaic_boxes": np.concatenate(mb, 0), p + "mosaic_counts": mbn,
                         p + "boxes": np.concatenate(fb, 0).astype(np.float64), p + "labels": np.concatenate(fl, 0).astype(np.int64),
                         p + "counts": fn})
+            if over.get("color"):
+                out.update({p + "color": col, p + "color_clip": col_clip, p + "color_pos": col_pos})
     finally:
         D.horizontal_flip, np.random.beta = flip_fn, beta_fn
     np.savez_compressed(os.path.join(OUT, "protocol.npz"), **out)

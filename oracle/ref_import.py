@@ -240,16 +240,43 @@ def install_recording(rec: Recorder):
             rec("ToFloat", max_value=self.max_value)
             return dict(data, image=data["image"].astype("float32") / self.max_value)
 
-    def _colour_op(name):
+    # The colour stage (default.py:420-432: A.Compose([A.Blur(p=0.01), A.MedianBlur(p=0.01), A.ToGray(p=0.01),
+    # A.CLAHE(p=0.01)])): each stand-in takes the p the REFERENCE passes, draws against it on the stage's own generator
+    # (rec.color_rng, see oracle/datapath.color_gate for the protocol and why it is a separate stream), logs what fired
+    # and hands the pixels to the oracle's restatement.  A Compose that holds such transforms makes the Compose-level draw.
+    import random as _pyrandom
+
+    def _colour_op(name, bit, draw_params, apply):
         class Op:
-            def __init__(self, *a, **k):
-                pass
+            colour_stage = True
+
+            def __init__(self, *a, p=0.5, **k):
+                self.p = p
 
             def __call__(self, **data):
-                raise NotImplementedError(f"albumentations.{name} is not part of the recorded protocol "
-                                          "(image_color_transforms=False)")
+                g = getattr(rec, "color_rng", None)
+                assert g is not None, "set Recorder.color_rng before running a configuration with image_color_transforms=True"
+                if g.random() < self.p:
+                    params = draw_params(g)
+                    rec("color", op=name, bit=bit, **params)
+                    return dict(data, image=apply(data["image"], **params))
+                return data
+        Op.__name__ = name
         return Op
 
-    A.Compose, A.ToFloat = Compose, ToFloat
-    for n in ("Blur", "MedianBlur", "ToGray", "CLAHE"):
-        setattr(A, n, _colour_op(n))
+    class ColourAwareCompose(Compose):
+        def __call__(self, **data):
+            if any(getattr(t, "colour_stage", False) for t in self.transforms):
+                rec("color_stage", n=len(self.transforms))
+                rec.color_rng.random()                    # Compose.__call__: need_to_run = random() < self.p (p = 1)
+            return super().__call__(**data)
+
+    A.Compose, A.ToFloat = ColourAwareCompose, ToFloat
+    odd = list(range(3, 8, 2))
+    A.Blur = _colour_op("Blur", DP.COLOR_BLUR, lambda g: dict(ksize=int(g.choice(odd))), lambda im, ksize: DP.blur_u8(im, ksize))
+    A.MedianBlur = _colour_op("MedianBlur", DP.COLOR_MEDIAN, lambda g: dict(ksize=int(g.choice(odd))),
+                              lambda im, ksize: DP.median_blur_u8(im, ksize))
+    A.ToGray = _colour_op("ToGray", DP.COLOR_GRAY, lambda g: {}, lambda im: DP.to_gray_u8(im))
+    A.CLAHE = _colour_op("CLAHE", DP.COLOR_CLAHE, lambda g: dict(clip_limit=float(g.uniform(1, 4.0))),
+                         lambda im, clip_limit: DP.clahe_u8(im, clip_limit))
+    del _pyrandom

@@ -199,8 +199,13 @@ PROTOCOL_CASES = {
     "rot": (0.0, False, dict(degrees=10.0, shear=5.0, flip=0.0)),    # all matrix factors live; flip_lr_prob = 0: no flip draw
     "nohsv": (0.0, False, dict(hsv=(0.0, 0.0, 0.0))),                # HSVParams.should_aug() False: no HSV draws (default.py:359-364)
     "persp": (0.3, False, dict(degrees=5.0, shear=2.0, perspective=0.0008)),   # cv2.warpPerspective + the boxes' perspective divide (default.py:306-313,257-260)
+    # image_color_transforms=True (the reference's default, aug_params.yaml:15): the albumentations colour stage between warp and HSV
+    "color": (0.3, False, dict(color=True)),
 }
 PROTOCOL_S, PROTOCOL_POOL, PROTOCOL_N = 64, 12, 64
+# generator seed of the colour stage's gate in the 'color' case (the library's own stream; chosen so that each of the four
+# p = 0.01 transforms fires at least once within the case's ~85 augmentor calls)
+PROTOCOL_COLOR_SEED = 127
 
 
 def protocol_pool():

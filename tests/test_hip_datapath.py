@@ -24,9 +24,11 @@ def test_batch_matches_oracle_protocol(S, mixup, seed):
     idxs = [3, 0, 7, 11, 5, 2] if S < 640 else [3, 0, 7, 11]
     a = AugParams()
     assert a.flip_lr_prob > 0 and a.hsv_params.hue > 0 and a.affine_params.scale > 0     # augmentation really is on
+    assert a.image_color_transforms                     # ... the albumentations colour stage too (the reference's default)
     random.seed(seed); np.random.seed(seed)
     rng = np.random.default_rng(51)
-    ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup) for i in idxs]
+    cgen = random.Random(51)                            # the colour stage's own generator: the product seeds it with rng_seed
+    ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup, aug=dict(color=cgen)) for i in idxs]
     random.seed(seed); np.random.seed(seed)
     pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda",
                                AugParams(), mixup_prob=mixup, rng_seed=51)
@@ -60,7 +62,9 @@ def test_rotated_and_sheared_batches_match_oracle(S, degrees, shear, persp, mixu
     aug = AugParams(affine_params=AffineParams(degrees=degrees, translate=0.1, scale=0.5, shear=shear, perspective=persp))
     random.seed(seed); np.random.seed(seed)
     rng = np.random.default_rng(51)
-    ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup, aug=dict(degrees=degrees, shear=shear, perspective=persp)) for i in idxs]
+    cgen = random.Random(51)
+    ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup, aug=dict(degrees=degrees, shear=shear, perspective=persp,
+                                                                              color=cgen)) for i in idxs]
     random.seed(seed); np.random.seed(seed)
     pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda", aug,
                                mixup_prob=mixup, rng_seed=51)
@@ -76,13 +80,84 @@ def test_rotated_and_sheared_batches_match_oracle(S, degrees, shear, persp, mixu
     assert moved == len(idxs)           # (every image shows pool pixels, not only the border value)
 
 
+class _ScriptedGate:
+    """A stand-in for the colour stage's generator that makes the gate (datapath.color_gate / host_protocol.color_gate) fire a
+    scripted plan [(ops, blur_k, median_k, clip), ...], one entry per augmentor call, cycling."""
+
+    def __init__(self, plan):
+        self.plan, self.i, self.ph, self.cur = plan, 0, 0, None
+
+    def random(self):
+        if self.ph == 0:
+            self.cur = self.plan[self.i % len(self.plan)]
+            self.i += 1
+            self.ph = 1
+            return 0.5                                    # the Compose's own draw
+        bit = 1 << (self.ph - 1)
+        self.ph = (self.ph + 1) % 5
+        return 0.0 if self.cur[0] & bit else 0.5
+
+    def choice(self, seq):
+        k = self.cur[1] if self.ph == 2 else self.cur[2]  # (the phase counter already points at the next transform)
+        assert k in seq
+        return k
+
+    def uniform(self, a, b):
+        assert a <= self.cur[3] <= b
+        return self.cur[3]
+
+
+@pytest.mark.parametrize("S,mixup,seed", [(64, 0.5, 21), (52, 0.0, 22), (128, 1.0, 23), (640, 0.5, 24)])
+def test_color_transforms_match_oracle(S, mixup, seed):
+    """image_color_transforms (kod/data/augmentations/default.py:420-432,460-461: albumentations Blur / MedianBlur / ToGray /
+    CLAHE at p = 0.01 each between the warp and the HSV jitter - the reference's shipped default) with the gate SCRIPTED so
+    that every transform, every kernel size and several combinations fire: csrc/compose.hip's colour kernels against
+    oracle/datapath.py's restatements (cv2.blur, cv2.medianBlur, RGB2GRAY, CLAHE on the L channel of an 8-bit Lab image),
+    final f32 images bit for bit - also at 640 px, with mixup partners, and at a size that is not a multiple of CLAHE's 8
+    tiles (52: reflect-padded tiles).  Where the stage sits and that the reference runs it is pinned by protocol.npz ('color');
+    albumentations' / OpenCV's own arithmetic cannot be (not installed): both sides are this repository's restatement."""
+    plan = [(1, 3, 0, 0.0), (2, 0, 5, 0.0), (4, 0, 0, 0.0), (8, 0, 0, 2.5), (0, 0, 0, 0.0), (15, 7, 7, 3.9), (1, 5, 0, 0.0),
+            (2, 0, 7, 0.0), (3, 7, 3, 0.0), (12, 0, 0, 1.0), (2, 0, 3, 0.0), (9, 3, 0, 4.0)]
+    if S == 640:
+        plan = [(15, 7, 7, 3.3), (0, 0, 0, 0.0), (10, 0, 5, 1.7), (5, 5, 0, 0.0)]
+    cache = _cache(10, S, seed)
+    idxs = [3, 0, 7, 9, 5, 2, 1, 8] if S < 640 else [3, 0, 7]
+    random.seed(seed); np.random.seed(seed)
+    rng = np.random.default_rng(51)
+    gate = _ScriptedGate(plan)
+    logs = [{} for _ in idxs]
+    ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup, aug=dict(color=gate), log=lg) for i, lg in zip(idxs, logs)]
+    random.seed(seed); np.random.seed(seed)
+    pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda", AugParams(),
+                               mixup_prob=mixup, rng_seed=51)
+    pipe.host.color_rng = _ScriptedGate(plan)
+    img, _, targets = pipe.make_batch(idxs, out_f32=True)
+    img = img.cpu().numpy()
+    fired = 0
+    for k, (rimg, rbb, rlb) in enumerate(ref):
+        np.testing.assert_array_equal(targets[k].boxes.numpy(), rbb)
+        np.testing.assert_array_equal(targets[k].labels.numpy(), rlb)
+        diff = np.abs(img[k] - rimg)
+        assert diff.max() == 0.0, (k, [st["color"] for st in logs[k]["stages"]], diff.max(), (diff > 0).mean())
+        fired += sum(bin(st["color"][0]).count("1") for st in logs[k]["stages"])
+    assert fired >= (8 if S < 640 else 4)
+    # the stage changes pixels: the same batch without it differs exactly on the samples whose gate fired
+    random.seed(seed); np.random.seed(seed)
+    off = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda",
+                              AugParams(image_color_transforms=False), mixup_prob=mixup, rng_seed=51)
+    plain = off.make_batch(idxs, out_f32=True)[0].cpu().numpy()
+    for k in range(len(idxs)):
+        any_fired = any(st["color"][0] for st in logs[k]["stages"])
+        assert (np.abs(plain[k] - img[k]).max() > 0) == any_fired, k
+
+
 def test_full_size_properties():
     """640 px, batch 16: finite, in [0,1], deterministic, no-augmentation identity composite."""
     S = 640
     cache = _cache(8, S, 9)
     pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda",
                                AugParams(affine_params=AffineParams(0, 0, 0, 0, 0), hsv_params=HSVParams(0, 0, 0),
-                                         flip_lr_prob=0.0))
+                                         flip_lr_prob=0.0, image_color_transforms=False))
     random.seed(1)
     a, _, ta = pipe.make_batch(list(range(8)) * 2)
     random.seed(1)

@@ -96,7 +96,7 @@ def _compare(hip, ref, xs, ftol=1e-2, gtol=4e-2, in_gtol=None, vs_emulation=Fals
 def test_csp_block_and_layer():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(4, 64, 24, 40, generator=g)
-    torch.manual_seed(3); hip = CSPBlock(64, 64, 1.0, True)
+    torch.manual_seed(3); hip = CSPBlock(64, 64, 1.0, True, Yolov5BatchNorm2d)
     torch.manual_seed(3); ref = N.Bottleneck(64, True)
     _compare(hip, ref, [x])
     torch.manual_seed(4); hip = CSPLayer(64, 128, 0.5, True, 2, Yolov5BatchNorm2d, torch.nn.SiLU)
@@ -120,7 +120,7 @@ def test_csp_block_and_layer():
 
 def test_sppf_bottleneck():
     x = torch.randn(3, 128, 16, 16, generator=torch.Generator().manual_seed(2))
-    torch.manual_seed(5); hip = SPPFBottleneck(128, 128)
+    torch.manual_seed(5); hip = SPPFBottleneck(128, 128, norm_layer=Yolov5BatchNorm2d)
     torch.manual_seed(5); ref = N.SPPF(128, 128)
     # bf16 input + two conv layers with K = 128 / 256 (forward measured 1.2e-2).  Gradients: activations rounded to bf16 tie far
     # more often than fp32 ones, so a 5x5 max-pool routes some gradients to another pixel than the fp32 oracle does (the pool
@@ -139,7 +139,7 @@ def test_sppf_parallel_pools_and_no_leading_conv(first):
     (pinned to the reference by tests/golden/sppf.npz)."""
     cin = 128 if first else 64
     x = torch.randn(3, cin, 16, 16, generator=torch.Generator().manual_seed(12))
-    torch.manual_seed(15); hip = SPPFBottleneck(cin, 128, kernel_sizes=(5, 9, 13), use_conv_first=first)
+    torch.manual_seed(15); hip = SPPFBottleneck(cin, 128, kernel_sizes=(5, 9, 13), use_conv_first=first, norm_layer=Yolov5BatchNorm2d)
     torch.manual_seed(15); ref = N.SPPF(cin, 128, (5, 9, 13), first)
     assert (hip.conv1 is None) == (not first)
     _compare(hip, ref, [x], ftol=2e-2, gtol=1.5e-1, in_gtol=2e-1)

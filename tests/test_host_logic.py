@@ -428,7 +428,7 @@ def test_bench_ranks_under_an_external_launcher_supervise_and_walk_the_ladder():
     assert not [ln for o in outs for ln in o[0].splitlines() if ln.startswith("{")]
 
 
-@pytest.mark.parametrize("case", ["plain", "mix03", "mix10", "rfs03", "rot", "nohsv", "persp"])
+@pytest.mark.parametrize("case", ["plain", "mix03", "mix10", "rfs03", "rot", "nohsv", "persp", "color"])
 def test_host_protocol_vs_reference_recording(case):
     """The PRODUCT's host side of the data protocol (data/host_protocol.HostProtocol: numpy only) against the recording of
     the reference's real DetectionDataset.__getitem__ + TrainSampleAugmentor (tests/golden/protocol.npz, made by
@@ -449,11 +449,17 @@ def test_host_protocol_vs_reference_recording(case):
     offsets = np.concatenate(([0], np.cumsum([h * w_ * 3 for h, w_ in shapes])[:-1]))
     aug = AugParams(affine_params=AffineParams(degrees=over.get("degrees", 0.0), shear=over.get("shear", 0.0),
                                                perspective=over.get("perspective", 0.0)),
-                    hsv_params=HSVParams(*over.get("hsv", (0.015, 0.7, 0.4))), flip_lr_prob=over.get("flip", 0.5))
+                    hsv_params=HSVParams(*over.get("hsv", (0.015, 0.7, 0.4))), flip_lr_prob=over.get("flip", 0.5),
+                    image_color_transforms=bool(over.get("color", False)))
     random.seed(2023)
     np.random.seed(2023)
     host = HostProtocol(shapes, offsets, [b for _, b, _ in pool], [l for _, _, l in pool], S, aug_params=aug,
                         mixup_prob=mixup_prob, rng_seed=51, image_repeat_factors=w, sampler_indices=si)
+    if over.get("color"):           # the recording's colour-stage generator (the product seeds its own with rng_seed)
+        assert host.color_rng is not None
+        host.color_rng = random.Random(synth.PROTOCOL_COLOR_SEED)
+    else:
+        assert host.color_rng is None
     descs, mix, per = host.batch([k % n for k in range(N)])
     ob = 0
     for k in range(N):
@@ -472,6 +478,11 @@ def test_host_protocol_vs_reference_recording(case):
             else:
                 assert d["hsv_on"] == 0
             assert d["flip"] == g["flip"][k, st] and d["canvas"] == 2 * S
+            if over.get("color"):   # image_color_transforms: which transforms fired for this augmentor call, with what parameters
+                assert (int(d["color"]), int(d["blur_k"]), int(d["median_k"])) == tuple(int(v) for v in g["color"][k, st]), (case, k, st)
+                assert d["clahe_clip"] == g["color_clip"][k, st] and d["pre"] == 0
+            else:
+                assert d["color"] == 0 and d["pre"] == 0
         if stages == 2:
             r = g["mixup_r"][k]
             assert mix[k, 0] == np.float32(r) and mix[k, 1] == np.float32(1 - r)

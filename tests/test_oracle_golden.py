@@ -232,10 +232,12 @@ def test_per_sample_protocol_vs_reference(golden, case):
         aug["flip_prob"] = over["flip"]
     if "hsv" in over:
         aug["hsv"] = over["hsv"]
+    if over.get("color"):                 # image_color_transforms=True: the colour stage's own generator (see datapath.color_gate)
+        aug["color"] = random.Random(synth.PROTOCOL_COLOR_SEED)
     random.seed(2023)
     np.random.seed(2023)
     rng = np.random.default_rng(51)
-    ob = om = 0
+    ob = om = fired = 0
     for k in range(N):
         log = {}
         img, bb, lb = datapath.train_sample(pool, k % n, S, rng, mixup_prob=mixup_prob, weights=w, sampler_indices=si,
@@ -253,6 +255,15 @@ def test_per_sample_protocol_vs_reference(golden, case):
             else:
                 assert g["n_lut"][k, st] == 3 and all(np.array_equal(stage["luts"][c], g["luts"][k, st, c]) for c in range(3))
             assert int(stage["flip"]) == g["flip"][k, st]
+            if over.get("color"):
+                # the reference ran its albumentations stage AFTER the warp and BEFORE the first HSV look-up (color_pos = 1), and
+                # the recording's draws (which transform fired, with what parameter) are the oracle's
+                assert g["color_pos"][k, st] == 1
+                ops, kb, km, clip = stage["color"]
+                assert (ops, kb, km) == tuple(int(v) for v in g["color"][k, st]) and clip == g["color_clip"][k, st], (case, k, st)
+                fired += bin(ops).count("1")
+            else:
+                assert stage["color"] is None
         assert (len(log["stages"]) == 2) == bool(g["flip"][k, 1] >= 0)
         if log["mixup_r"] is None:
             assert np.isnan(g["mixup_r"][k])
@@ -263,6 +274,8 @@ def test_per_sample_protocol_vs_reference(golden, case):
         ob += cnt
         assert img.dtype == np.float32 and zlib.crc32(np.ascontiguousarray(img).tobytes()) == g["image_crc"][k], (case, k)
     assert ob == len(g["boxes"]) and om == len(g["mosaic_boxes"])
+    if over.get("color"):
+        assert fired >= 4 and set(np.unique(g["color"][..., 0])) >= {0, 1, 2, 8, 12}     # every transform fired in the recording
 
 
 @pytest.mark.parametrize("case", list(synth.sppf_cases()))

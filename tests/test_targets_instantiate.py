@@ -75,7 +75,8 @@ def test_every_hot_path_target_constructs_with_reference_kwargs():
     # data/augmentations/{aug_params,no_aug_params,default}.yaml, data/default.yaml:14-16
     AP, HP, AUG = (_get(f"kod.data.augmentations.default.{n}") for n in ("AffineParams", "HSVParams", "AugParams"))
     aug = AUG(affine_params=AP(degrees=0.0, translate=0.1, scale=0.5, shear=0.0, perspective=0.0),
-              hsv_params=HP(hue=0.015, saturation=0.7, value=0.4), flip_lr_prob=0.5, image_color_transforms=False)
+              hsv_params=HP(hue=0.015, saturation=0.7, value=0.4), flip_lr_prob=0.5,
+              image_color_transforms=True)           # aug_params.yaml:15 as shipped: no Hydra override needed (round 6)
     none = AUG(affine_params=AP(0.0, 0.0, 0.0, 0.0, 0.0), hsv_params=HP(0.0, 0.0, 0.0), flip_lr_prob=0.0,
                image_color_transforms=False)
     for a in (aug, none):
