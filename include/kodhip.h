@@ -251,10 +251,11 @@ int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx,
 int kodhip_head_bwd_prep(const float* g, void* dy, float* workspace, float* db_box, float* db_obj, float* db_cls,
                          int B, int HW, int A, int nc, int Npad, kodStream_t stream);
 
-/* ---- optimizer (torch.optim.SGD, dampening 0, as grouped by kod/nn/optim/smart.py:36-58) ---------- */
+/* ---- optimizer (torch.optim.SGD as grouped by kod/nn/optim/smart.py:36-58) ---------------------- */
 int kodhip_sgd_nesterov(float* params, const float* grads, float* momentum_buf, const void* group_ids,
                         long n, const float* hyper /* device, 12 floats: lr[3] momentum[3] wd[3] grad_scale,
-                                                      nesterov (smart_sgd.yaml: 1; 0 = plain momentum), reserved */,
+                                                      flags = nesterov (smart_sgd.yaml: 1) + 2 maximize + 4 first step
+                                                      (only read when dampening != 0), dampening */,
                         kodStream_t stream);
 int kodhip_fill_u32(void* p, uint32_t value, long n, kodStream_t stream);
 /* dst (device) <- src (PINNED host memory), bytes % 16 == 0, both 16-byte aligned: a kernel pulling the bytes through the

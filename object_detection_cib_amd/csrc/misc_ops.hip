@@ -563,8 +563,11 @@ __global__ void head_bias_reduce_kernel(const float* bpart, int nblk, int Npad, 
 
 // ------------------------------------------------------------------ SGD
 // group id per 64-element granule: 0 bias, 1 decay, 2 norm, 255 padding
-// hyper (device memory, so a captured hipGraph sees per-step schedules): lr[3] | momentum[3] | wd[3] | grad_scale | nesterov
-// (12 floats; torch.optim.SGD with dampening = 0: buf = mu * buf + g; p -= lr * (nesterov ? g + mu * buf : buf))
+// hyper (device memory, so a captured hipGraph sees per-step schedules): lr[3] | momentum[3] | wd[3] | grad_scale | flags |
+// dampening (12 floats; flags = nesterov + 2 maximize + 4 first step, small integers held in a float).  torch.optim.SGD
+// (torch/optim/sgd.py _single_tensor_sgd): g = maximize ? -g : g; g += wd * p; momentum != 0: buf = first step ? g :
+// mu * buf + (1 - dampening) * g; g = nesterov ? g + mu * buf : buf; p -= lr * g.  With dampening = 0 the first step needs no
+// flag (buf starts at zero: mu * 0 + g = g), which is the reference's configuration (smart_sgd.yaml).
 __global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, const unsigned char* gid, long n,
                                     const float* hyper) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -572,15 +575,18 @@ __global__ void sgd_nesterov_kernel(float* p, const float* g, float* buf, const 
   unsigned char grp = gid[i >> 6];
   if (grp > 2) return;
   const float lr = hyper[grp], mu = hyper[3 + grp], wd = hyper[6 + grp], gscale = hyper[9];
-  const bool nesterov = hyper[10] != 0.f;
+  const int flags = (int)hyper[10];
+  const bool nesterov = (flags & 1) != 0, maximize = (flags & 2) != 0, first = (flags & 4) != 0;
+  const float undamped = 1.0f - hyper[11];
   f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
   f32x4 gv = kod_load_once<f32x4>(g + i);
   f32x4 bv = *reinterpret_cast<const f32x4*>(buf + i);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float gg = gv[e] * gscale;
+    if (maximize) gg = -gg;
     if (wd != 0.f) gg = gg + wd * pv[e];
-    float b = mu * bv[e] + gg;
+    float b = (first || mu == 0.f) ? gg : mu * bv[e] + undamped * gg;      // (undamped = 1: mu * buf + g, bit for bit)
     bv[e] = b;
     pv[e] = pv[e] - lr * (nesterov ? gg + mu * b : b);
   }

@@ -156,8 +156,11 @@ class ArenaMixin:
         self.pack_blocks = blk
         self.exec_units = exec_units
         self.device = device
-        self.hyper = torch.zeros(12, dtype=torch.float32, device=device)      # lr[3] | momentum[3] | wd[3] | grad scale | nesterov | -
+        self.hyper = torch.zeros(12, dtype=torch.float32, device=device)      # lr[3] | momentum[3] | wd[3] | grad scale | flags | dampening
         self.sgd_nesterov = True          # FusedSGD(nesterov=...): smart_sgd.yaml's default, kod/configs/nn/optimizers/smart_sgd.yaml
+        self.sgd_dampening, self.sgd_maximize = 0.0, False      # torch.optim.SGD(dampening=, maximize=) through FusedSGD
+        self.sgd_steps = 0                # optimizer steps taken (torch's first step copies the gradient into the momentum buffer)
+        self._hyper_args = None
         # pinned staging ring: the H2D copy is asynchronous, so a slot is not rewritten for the next 15 uploads
         self._hyper_host = [torch.zeros(12, dtype=torch.float32).pin_memory() for _ in range(16)]
         self._hyper_events = [None] * len(self._hyper_host)
@@ -201,7 +204,10 @@ class ArenaMixin:
     def set_hyper(self, lr, momentum, weight_decay, grad_scale: float = 1.0):
         """Upload the optimizer hyper-parameters (3-tuples for bias_params, decay_params, norm_params) to the device
         buffer the fused SGD kernel reads - outside any captured graph, so schedules keep working under replay."""
-        vals = (*lr, *momentum, *weight_decay, grad_scale, 1.0 if self.sgd_nesterov else 0.0, 0.0)
+        self._hyper_args = (tuple(lr), tuple(momentum), tuple(weight_decay), grad_scale)
+        first = self.sgd_dampening != 0.0 and self.sgd_steps == 0
+        flags = (1.0 if self.sgd_nesterov else 0.0) + (2.0 if self.sgd_maximize else 0.0) + (4.0 if first else 0.0)
+        vals = (*lr, *momentum, *weight_decay, grad_scale, flags, float(self.sgd_dampening))
         if vals != self._hyper_vals:                       # only touch the device copy when the schedule moved
             k = self._hyper_slot
             self._hyper_slot = (k + 1) % len(self._hyper_host)
@@ -227,6 +233,14 @@ class ArenaMixin:
                                                 self.m_arena.data_ptr(), self.gid.data_ptr(), self.n_arena,
                                                 self.hyper.data_ptr(), self._stream()), "sgd")
         self.param_version += 1
+        self.note_sgd_step()
+
+    def note_sgd_step(self):
+        """one optimizer step has run (eagerly, or inside a replayed graph): with dampening the first step's flag must leave
+        the device block before the next one"""
+        self.sgd_steps += 1
+        if self.sgd_dampening != 0.0 and self.sgd_steps == 1 and self._hyper_args is not None:
+            self.set_hyper(*self._hyper_args)
 
     def mark_params_changed(self):
         self.param_version += 1

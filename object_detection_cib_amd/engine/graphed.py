@@ -166,6 +166,7 @@ class GraphedTrainStep:
         self._load(images, targets)
         self.graph.replay()
         self.eng.param_version += 1           # the replayed SGD changed the parameters
+        self.eng.note_sgd_step()
         return self.total, self.parts
 
 

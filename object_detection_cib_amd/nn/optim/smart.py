@@ -33,22 +33,25 @@ def split_param_groups(net: nn.Module):
 
 
 class FusedSGD(torch.optim.Optimizer):
-    """torch.optim.SGD(dampening=0; nesterov or plain momentum) over a HIP Yolov5Network: same param_groups / state_dict
-    layout, the update itself is the engine's fused multi-tensor kernel.  Hyper-parameters are read from ``param_groups``
-    at every ``step()`` (so warm-up and LR schedulers work unchanged)."""
+    """torch.optim.SGD (momentum with or without Nesterov, dampening, maximize) over a HIP Yolov5Network: same
+    param_groups / state_dict layout, the update itself is the engine's fused multi-tensor kernel.  lr / momentum /
+    weight_decay are read from ``param_groups`` at every ``step()`` (so warm-up and LR schedulers work unchanged);
+    dampening, nesterov and maximize are the constructor's (one value for all groups, as SmartOptimizer builds them)."""
 
     def __init__(self, params, lr: float = 1e-3, momentum: float = 0.0, dampening: float = 0.0,
                  weight_decay: float = 0.0, nesterov: bool = False, *, net: nn.Module, world_size: int = 1,
                  maximize: bool = False, foreach=None, differentiable: bool = False):
-        if dampening != 0.0 or maximize:
-            raise NotImplementedError("the fused kernel implements SGD(dampening=0, maximize=False), with or without Nesterov "
-                                      "momentum (kod/configs/nn/optimizers/smart_sgd.yaml: nesterov=True)")
+        if nesterov and (momentum <= 0 or dampening != 0):            # torch.optim.SGD.__init__
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        if foreach is False or differentiable:
+            raise NotImplementedError("FusedSGD is the fused multi-tensor update (foreach=False / differentiable=True have no HIP form)")
         defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov,
                         maximize=maximize, foreach=foreach, differentiable=differentiable)
         super().__init__(params, defaults)
         self.net = net
         self.world_size = world_size
         self._nesterov = bool(nesterov)
+        self._dampening, self._maximize = float(dampening), bool(maximize)
         self.steps_taken = 0          # torch keeps no momentum_buffer before the first step (checkpoint layout)
 
     def _by_name(self):
@@ -59,7 +62,9 @@ class FusedSGD(torch.optim.Optimizer):
             raise RuntimeError("FusedSGD expects SmartOptimizer's groups bias_params / decay_params / norm_params")
 
     def hyper(self):
-        self.net.engine().sgd_nesterov = self._nesterov        # (the engine's device-side hyper block carries the flag)
+        eng = self.net.engine()                                # (the engine's device-side hyper block carries the flags)
+        eng.sgd_nesterov, eng.sgd_dampening, eng.sgd_maximize = self._nesterov, self._dampening, self._maximize
+        eng.sgd_steps = self.steps_taken
         g = self._by_name()
         return ([float(x["lr"]) for x in g], [float(x["momentum"]) for x in g], [float(x["weight_decay"]) for x in g])
 

@@ -472,10 +472,12 @@ def test_maxpool_cascade_equals_three_launches(case):
     assert lib.kodhip_maxpool5_cascade_fwd(bufs[0].data_ptr(), 4 * 64, 0, 64, 1, 1, 1, 1, 80, 80, stream()) != 0
 
 
-@pytest.mark.parametrize("nesterov", [True, False])
-def test_sgd_nesterov(nesterov):
-    """kodhip_sgd_nesterov against torch.optim.SGD itself (dampening = 0), Nesterov momentum (smart_sgd.yaml) and plain
-    momentum (hyper[10] = 0), three groups with their own lr / momentum / weight decay, three steps."""
+@pytest.mark.parametrize("nesterov,dampening,maximize", [(True, 0.0, False), (False, 0.0, False), (False, 0.3, False),
+                                                         (False, 0.0, True), (False, 0.25, True)])
+def test_sgd_nesterov(nesterov, dampening, maximize):
+    """kodhip_sgd_nesterov against torch.optim.SGD itself: Nesterov momentum (smart_sgd.yaml), plain momentum, dampening
+    (the first step copies the gradient into the momentum buffer: flag 4 of hyper[10]) and maximize; three groups with
+    their own lr / momentum / weight decay, three steps."""
     g = torch.Generator().manual_seed(2)
     n = 64 * 7
     p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g)
@@ -486,9 +488,11 @@ def test_sgd_nesterov(nesterov):
     grc, gidc = gr.cuda(), gid.cuda()
     refs = [torch.nn.Parameter(p[64 * k:64 * k + 64].clone()) for k in range(7)]
     opt = torch.optim.SGD([dict(params=[refs[k] for k in range(7) if int(gid[k]) == gi], lr=lr[gi], momentum=mom[gi],
-                                weight_decay=wd[gi]) for gi in range(3)], lr=0.1, nesterov=nesterov, momentum=0.5)
+                                weight_decay=wd[gi]) for gi in range(3)], lr=0.1, nesterov=nesterov, momentum=0.5,
+                          dampening=dampening, maximize=maximize)
     for step in range(3):
-        hyper = torch.tensor([*lr, *mom, *wd, 0.5, 1.0 if nesterov else 0.0, 0.0], dtype=torch.float32, device="cuda")
+        flags = (1.0 if nesterov else 0.0) + (2.0 if maximize else 0.0) + (4.0 if (dampening and step == 0) else 0.0)
+        hyper = torch.tensor([*lr, *mom, *wd, 0.5, flags, dampening], dtype=torch.float32, device="cuda")
         _lib.check(lib.kodhip_sgd_nesterov(pc.data_ptr(), grc.data_ptr(), buf.data_ptr(), gidc.data_ptr(), n,
                                            hyper.data_ptr(), stream()), "sgd")
         for k in range(7):
