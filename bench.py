@@ -568,7 +568,7 @@ def supervise_rank(args) -> int:
     return last
 
 
-PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
 
 
 def stamp_report(eng, graph, step, file=sys.stderr):

@@ -70,13 +70,13 @@ def test_product_fails_loudly_without_gpu():
 
 
 def test_pmc_evidence_matches_kernel_sources():
-    """profiles/r05_pmc_traffic.json (what bench.py quotes as roofline.traffic) must have been collected on the kernel
+    """profiles/r06_pmc_traffic.json (what bench.py quotes as roofline.traffic) must have been collected on the kernel
     sources in the tree: a stale file fails HERE, loudly, instead of being quoted (bench.py itself then reports
     traffic null).  Fix: tools/collect_evidence.sh on the GPU box + tools/refresh_profiles.py, or delete the file."""
     import json
     import os
     from object_detection_cib_amd import build as kb
-    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_pmc_traffic.json")
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_pmc_traffic.json")
     if not os.path.exists(p):
         pytest.skip("no PMC evidence committed")
     assert json.load(open(p))["csrc_digest"] == kb.source_digest(), "PMC evidence is older than csrc/: re-collect it"

@@ -3,7 +3,7 @@
 # Collects, under gpurun_out/ev_<tag>/: the bench line, a kernel trace with stats, the FETCH_SIZE / WRITE_SIZE PMC
 # passes (separate runs, kernel trace only - MI355X_MICROARCH.md, HBM) and an MFMA counter pass.  rocprofv3 gets the
 # interpreter directly after `--` (no wrapper).  tools/refresh_profiles.py turns the directory into profiles/<tag>_*.
-tag=${1:-r05}
+tag=${1:-r06}
 variant=${2:-yv5s}
 V="--variant $variant"
 R="$GRAFT_REPO_ROOT"; test -n "$R" || R="$(cd "$(dirname "$0")/.." && pwd)"

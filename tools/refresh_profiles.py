@@ -8,7 +8,7 @@ stores.  Per launch = summed counter / number of dispatches of the family in the
 import csv, glob, json, os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 EV = os.path.join(ROOT, "gpurun_out", f"ev_{tag}")
 PR = os.path.join(ROOT, "profiles")
 
