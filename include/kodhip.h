@@ -233,16 +233,6 @@ int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int
 /* dx_f32 (NULL = none): fp32 shadow of dx holding the earlier producers' partial sum (see kodhip_conv_dgrad) */
 int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, void* dx, int ldx, int xcoff,
                         int B, int H, int W, int C, const float* dx_f32, kodStream_t stream);
-/* The three cascaded pools of an SPPF block (sppf.py:46-50,78-82: y1 = pool(x), y2 = pool(y1), y3 = pool(y2), all four
- * tensors channel slices of one concat buffer) as ONE launch: stage j = 0..2 reads channels [coff0 + j mid, + mid) of
- * buf [B][H][W][ld] and writes [coff0 + (j + 1) mid, + mid); idx0..2 as above.  Results are bit-identical to three
- * kodhip_maxpool5_fwd / _bwd calls.  _ok: 1 if the geometry can take this form (one image's pixel groups in one block).
- * _bwd: gbuf = the concat buffer's GRADIENT; stage j = 2, 1, 0 adds slice j + 1's scattered gradient to slice j. */
-int kodhip_maxpool5_cascade_ok(int H, int W, int mid);
-int kodhip_maxpool5_cascade_fwd(void* buf, int ld, int coff0, int mid, void* idx0, void* idx1, void* idx2,
-                                int B, int H, int W, kodStream_t stream);
-int kodhip_maxpool5_cascade_bwd(void* gbuf, int ld, int coff0, int mid, const void* idx0, const void* idx1, const void* idx2,
-                                int B, int H, int W, kodStream_t stream);
 int kodhip_upsample2x_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff,
                           int B, int H, int W, int C, kodStream_t stream);
 int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx, int xcoff, int accumulate,

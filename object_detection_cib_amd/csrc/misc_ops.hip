@@ -248,34 +248,6 @@ __global__ __launch_bounds__(256) void maxpool5_fwd_kernel(const bf16_t* x, int 
   maxpool5_fwd_body(x, ldx, xcoff, y, ldy, ycoff, idx, H, W, C, b, gy, gx, c4);
 }
 
-// The SPPF cascade (kod/nn/layers/sppf.py:46-50,78-82: y1 = pool(x), y2 = pool(y1), y3 = pool(y2), all slices of one concat
-// buffer) as ONE launch: a block owns one image x CQ channel quads - every pixel group of the image - so a stage's 5 x 5
-// neighbourhoods never leave the block and the stages are separated by a block barrier instead of a kernel boundary (three
-// 20-us launches of a 6.5 MB tensor on the forward chain's critical path are mostly launch ramp and tail).  The arithmetic
-// of a stage is maxpool5_fwd_body's: values and argmax bytes are bit-identical to three separate launches.
-struct PoolCascade {
-  bf16_t* buf; int ld, coff0, mid;            // stage j reads channels [coff0 + j mid, + mid), writes the next slice
-  unsigned char* idx[3];
-  int B, H, W, CQ, groups;                    // CQ channel quads per block, groups = HG * WG (CQ * groups <= blockDim)
-};
-
-__global__ __launch_bounds__(256) void maxpool5_cascade_fwd_kernel(PoolCascade a) {
-  const int WG = (a.W + 3) >> 2;
-  const int qpb = (a.mid >> 2) / a.CQ;                 // blocks per image
-  const int b = blockIdx.x / qpb, q0 = (blockIdx.x - b * qpb) * a.CQ;
-  const int t = threadIdx.x;
-  const bool active = t < a.CQ * a.groups;
-  const int c4 = q0 + (active ? t % a.CQ : 0), g = active ? t / a.CQ : 0;
-  const int gy = g / WG, gx = g - gy * WG;
-#pragma unroll 1
-  for (int j = 0; j < 3; ++j) {
-    if (active)
-      maxpool5_fwd_body(a.buf, a.ld, a.coff0 + j * a.mid, a.buf, a.ld, a.coff0 + (j + 1) * a.mid, a.idx[j], a.H, a.W, a.mid, b, gy, gx, c4);
-    __threadfence_block();
-    __syncthreads();
-  }
-}
-
 // dx[p] += sum over outputs q whose argmax is p of dy[q]   (gather form, deterministic).  Issue-bound like the forward
 // kernel: comparing every (input, output) pair in registers costs ~6 instructions per pair, 25 pairs per input element
 // (34 us).  Here a thread owns a 4 x 4 block of input pixels x 4 channels and keeps their 64 sums in PRIVATE LDS words
@@ -396,28 +368,6 @@ __global__ __launch_bounds__(POOL_BWD_THREADS) void maxpool5_bwd_kernel(const bf
   const int b = (int)(p / HG);
   maxpool5_bwd_body<POOL_BWD_THREADS>(words0 + threadIdx.x, words1 + threadIdx.x, words2 + threadIdx.x, words3 + threadIdx.x,
                                       dy, ldy, ycoff, idx, dx, ldx, xcoff, H, W, C, dx32, b, gy, gx, c4);
-}
-
-// backward of the SPPF cascade as one launch (see maxpool5_cascade_fwd_kernel; here a.buf is the concat GRADIENT buffer):
-// stage j = 2, 1, 0 scatters slice j + 1 into slice j, which the next stage then reads whole - block barriers in between.
-constexpr int POOL_CASCADE_THREADS = 256;   // 70 KB of private words per block: two blocks per CU
-__global__ __launch_bounds__(POOL_CASCADE_THREADS) void maxpool5_cascade_bwd_kernel(PoolCascade a) {
-  __shared__ float words0[17 * POOL_CASCADE_THREADS], words1[17 * POOL_CASCADE_THREADS], words2[17 * POOL_CASCADE_THREADS], words3[17 * POOL_CASCADE_THREADS];
-  const int WG = (a.W + 3) >> 2;
-  const int qpb = (a.mid >> 2) / a.CQ;
-  const int b = blockIdx.x / qpb, q0 = (blockIdx.x - b * qpb) * a.CQ;
-  const int t = threadIdx.x;
-  const bool active = t < a.CQ * a.groups;
-  const int c4 = q0 + (active ? t % a.CQ : 0), g = active ? t / a.CQ : 0;
-  const int gy = g / WG, gx = g - gy * WG;
-#pragma unroll 1
-  for (int j = 2; j >= 0; --j) {
-    if (active)
-      maxpool5_bwd_body<POOL_CASCADE_THREADS>(words0 + t, words1 + t, words2 + t, words3 + t, a.buf, a.ld, a.coff0 + (j + 1) * a.mid,
-                                              a.idx[j], a.buf, a.ld, a.coff0 + j * a.mid, a.H, a.W, a.mid, nullptr, b, gy, gx, c4);
-    __threadfence_block();
-    __syncthreads();
-  }
 }
 
 // ------------------------------------------------------------------ nearest x2 upsample
@@ -656,49 +606,6 @@ int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, voi
   hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(cdiv(n, POOL_BWD_THREADS)), dim3(POOL_BWD_THREADS), 0, stream, (const bf16_t*)dy, ldy, ycoff,
                      (const unsigned char*)idx, (bf16_t*)dx, ldx, xcoff, B, H, W, C, dx_f32);
   KOD_LAUNCH_CHECK("maxpool5_bwd");
-  return KOD_OK;
-}
-
-// The three cascaded 5 x 5 / stride 1 / pad 2 pools of an SPPF block in one launch: buf [B][H][W][ld] (bf16), stage j
-// (0..2) reads channels [coff0 + j * mid, + mid) and writes [coff0 + (j + 1) * mid, + mid); idx0..2: the stages' argmax bytes
-// [B][H][W][mid].  Bit-identical to three kodhip_maxpool5_fwd calls.  kodhip_maxpool5_cascade_ok: whether a geometry can
-// take this form (an image's pixel groups x at least 4 channel quads must fit one 256-thread block).
-static int pool_cascade_cq(int H, int W, int mid) {
-  const int groups = ((H + 3) / 4) * ((W + 3) / 4);
-  for (int cq = 8; cq >= 4; cq >>= 1)
-    if (groups * cq <= 256 && (mid / 4) % cq == 0) return cq;
-  return 0;
-}
-int kodhip_maxpool5_cascade_ok(int H, int W, int mid) { return (mid % 8 == 0 && pool_cascade_cq(H, W, mid) > 0) ? 1 : 0; }
-
-static int pool_cascade_args(PoolCascade& a, void* buf, int ld, int coff0, int mid, void* idx0, void* idx1, void* idx2, int B, int H, int W) {
-  KOD_CHECK_ARG(buf && idx0 && idx1 && idx2 && B > 0 && H > 0 && W > 0, "maxpool5_cascade: bad args");
-  KOD_CHECK_ARG(mid % 8 == 0 && ld % 8 == 0 && coff0 % 8 == 0 && coff0 + 4 * mid <= ld, "maxpool5_cascade: bad channel geometry");
-  const int cq = pool_cascade_cq(H, W, mid);
-  KOD_CHECK_ARG(cq > 0, "maxpool5_cascade: %d x %d images do not fit one block (query kodhip_maxpool5_cascade_ok)", H, W);
-  a.buf = (bf16_t*)buf; a.ld = ld; a.coff0 = coff0; a.mid = mid;
-  a.idx[0] = (unsigned char*)idx0; a.idx[1] = (unsigned char*)idx1; a.idx[2] = (unsigned char*)idx2;
-  a.B = B; a.H = H; a.W = W; a.CQ = cq; a.groups = ((H + 3) / 4) * ((W + 3) / 4);
-  return KOD_OK;
-}
-
-int kodhip_maxpool5_cascade_fwd(void* buf, int ld, int coff0, int mid, void* idx0, void* idx1, void* idx2,
-                                int B, int H, int W, hipStream_t stream) {
-  PoolCascade a;
-  if (int rc = pool_cascade_args(a, buf, ld, coff0, mid, idx0, idx1, idx2, B, H, W)) return rc;
-  hipLaunchKernelGGL(maxpool5_cascade_fwd_kernel, dim3(B * ((mid / 4) / a.CQ)), dim3(256), 0, stream, a);
-  KOD_LAUNCH_CHECK("maxpool5_cascade_fwd");
-  return KOD_OK;
-}
-
-// gbuf: the concat buffer's gradient; stage j = 2, 1, 0 adds the scattered gradient of slice j + 1 to slice j (bf16
-// read-modify-write like kodhip_maxpool5_bwd without an fp32 shadow).  Bit-identical to three kodhip_maxpool5_bwd calls.
-int kodhip_maxpool5_cascade_bwd(void* gbuf, int ld, int coff0, int mid, const void* idx0, const void* idx1, const void* idx2,
-                                int B, int H, int W, hipStream_t stream) {
-  PoolCascade a;
-  if (int rc = pool_cascade_args(a, gbuf, ld, coff0, mid, (void*)idx0, (void*)idx1, (void*)idx2, B, H, W)) return rc;
-  hipLaunchKernelGGL(maxpool5_cascade_bwd_kernel, dim3(B * ((mid / 4) / a.CQ)), dim3(POOL_CASCADE_THREADS), 0, stream, a);
-  KOD_LAUNCH_CHECK("maxpool5_cascade_bwd");
   return KOD_OK;
 }
 

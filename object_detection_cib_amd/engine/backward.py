@@ -367,16 +367,6 @@ class BackwardMixin:
                 chk(lib.kodhip_upsample2x_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
                                               self._ptr(op.src, True), op.src.buf.C, op.src.coff,
                                               acc_flag(op.src), B, h, w, op.src.C, f32("up", op, op.src)[1], s), "upsample_bwd")
-            elif op.kind == "pool" and ri + 1 < len(rops) and self._pool_cascade(self.g.ops, op_index[id(op)] - 2, H, W) and \
-                    all(o.src.buf.name in touched for o in (op, rops[ri], rops[ri + 1])):
-                # SPPF's three pools (reached last one first): one launch scatters slice 3 -> 2 -> 1 -> 0 of the concat gradient
-                first = rops[ri + 1]
-                ri += 2
-                pool_i -= 3
-                h, w = H // first.src.stride, W // first.src.stride
-                sync_grad(first.src.buf.name)
-                chk(lib.kodhip_maxpool5_cascade_bwd(self.gact[first.src.buf.name].data_ptr(), first.src.buf.C, first.src.coff, first.src.C,
-                                                    *[self.pool_idx[pool_i + j].data_ptr() for j in range(3)], B, h, w, s), "maxpool_cascade_bwd")
             elif op.kind == "pool":
                 pool_i -= 1
                 h, w = H // op.src.stride, W // op.src.stride

@@ -28,20 +28,6 @@ class ForwardMixin:
     def _stream(self):
         return torch.cuda.current_stream().cuda_stream
 
-    def _pool_cascade(self, ops, k, H, W) -> bool:
-        """ops[k .. k + 2] are SPPF's three cascaded pools over consecutive slices of one concat buffer, in a geometry
-        the one-launch form takes (KODHIP_POOL_CASCADE=0: three launches, for A/B); not with fp32 gradient shadows."""
-        if self.opt.native.get("KODHIP_POOL_CASCADE", "1") == "0" or self.opt.dx_accum_fp32:
-            return False
-        if k + 2 >= len(ops) or any(o.kind != "pool" for o in ops[k:k + 3]):
-            return False
-        a = ops[k]
-        for j, o in enumerate(ops[k:k + 3]):
-            if o.src.buf is not a.src.buf or o.dst.buf is not a.src.buf or o.src.C != a.src.C or o.dst.C != a.src.C or \
-                    o.src.coff != a.src.coff + j * a.src.C or o.dst.coff != a.src.coff + (j + 1) * a.src.C:
-                return False
-        return bool(self.lib.kodhip_maxpool5_cascade_ok(H // a.src.stride, W // a.src.stride, a.src.C))
-
     # -- per-family kernel timing (bench.py's roofline table): HIP events around every launch of an eager step, recorded
     #    on the stream the launch goes to.  self.profile = [] switches it on; entries (family, e0, e1, algorithmic bytes).
     def _t0(self, stream=None):
@@ -325,13 +311,6 @@ class ForwardMixin:
                     stats_stage(group)
                 for u in group:
                     apply_stage(u)
-            elif op.kind == "pool" and self._pool_cascade(ops, i - 1, H, W):
-                # SPPF's three cascaded pools as one launch (csrc/misc_ops.hip maxpool5_cascade_fwd_kernel)
-                h, w = H // op.src.stride, W // op.src.stride
-                chk(lib.kodhip_maxpool5_cascade_fwd(self.act[op.src.buf.name].data_ptr(), op.src.buf.C, op.src.coff, op.src.C,
-                                                    *[self.pool_idx[pool_i + j].data_ptr() for j in range(3)], B, h, w, s), "maxpool_cascade")
-                pool_i += 3
-                i += 2
             elif op.kind == "pool":
                 h, w = H // op.src.stride, W // op.src.stride
                 chk(lib.kodhip_maxpool5_fwd(self._ptr(op.src), op.src.buf.C, op.src.coff, self._ptr(op.dst),
