@@ -233,6 +233,11 @@ int kodhip_maxpool5_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int
 /* dx_f32 (NULL = none): fp32 shadow of dx holding the earlier producers' partial sum (see kodhip_conv_dgrad) */
 int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, void* dx, int ldx, int xcoff,
                         int B, int H, int W, int C, const float* dx_f32, kodStream_t stream);
+/* any odd window K <= 15 (SPPFBottleneck's kernel_sizes, sppf.py:27-67): K = 5 dispatches to the kernels above */
+int kodhip_maxpool_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff, void* idx,
+                       int B, int H, int W, int C, int K, kodStream_t stream);
+int kodhip_maxpool_bwd(const void* dy, int ldy, int ycoff, const void* idx, void* dx, int ldx, int xcoff,
+                       int B, int H, int W, int C, int K, const float* dx_f32, kodStream_t stream);
 int kodhip_upsample2x_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff,
                           int B, int H, int W, int C, kodStream_t stream);
 int kodhip_upsample2x_bwd(const void* dy, int ldy, int ycoff, void* dx, int ldx, int xcoff, int accumulate,

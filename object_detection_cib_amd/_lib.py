@@ -80,6 +80,8 @@ SIGNATURES = {
     "kodhip_bn_silu_bwd_apply": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i64, i32, vp]),
     "kodhip_maxpool5_fwd": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "kodhip_maxpool5_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "kodhip_maxpool_fwd": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "kodhip_maxpool_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "kodhip_upsample2x_fwd": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "kodhip_upsample2x_bwd": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "kodhip_head_bwd_prep": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -370,6 +370,84 @@ __global__ __launch_bounds__(POOL_BWD_THREADS) void maxpool5_bwd_kernel(const bf
                                       dy, ldy, ycoff, idx, dx, ldx, xcoff, H, W, C, dx32, b, gy, gx, c4);
 }
 
+// ------------------------------------------------------------------ max-pool of any odd window (SPPF kernel_sizes != 5)
+// SPPFBottleneck takes any kernel size or sequence of sizes (kod/nn/layers/sppf.py:27-67); the network's 5 (and the SPP
+// sequence 5 / 9 / 13 as its cascade) runs through maxpool5_* above, every other window through these two plain kernels -
+// one thread per (pixel, 8 channels), torch's scan: row-major over the window, `val > max || isnan(val)` replaces (so the
+// FIRST maximum and the LAST NaN win, aten/native/cpu/MaxPoolKernel.cpp), -inf padding.  idx byte = dy * 16 + dx (K <= 15).
+__global__ __launch_bounds__(256) void maxpool_k_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_t* y, int ldy, int ycoff,
+                                                            unsigned char* idx, int B, int H, int W, int C, int K) {
+  const int C8 = C >> 3;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * H * W * C8) return;
+  const int c8 = (int)(i % C8);
+  const long p = i / C8;
+  const int ox = (int)(p % W), oy = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+  const int r = K >> 1;
+  float best[8];
+  int tap[8];
+  bool first = true;
+  for (int dy = 0; dy < K; ++dy) {
+    const int iy = oy + dy - r;
+    if (iy < 0 || iy >= H) continue;
+    for (int dx = 0; dx < K; ++dx) {
+      const int ix = ox + dx - r;
+      if (ix < 0 || ix >= W) continue;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)(b * H + iy) * W + ix) * ldx + xcoff + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[e];
+        if (first) { best[e] = -INFINITY; tap[e] = dy * 16 + dx; }
+        if (f > best[e] || f != f) { best[e] = f; tap[e] = dy * 16 + dx; }
+      }
+      first = false;
+    }
+  }
+  bf16x8 o;
+  unsigned long long ib = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { o[e] = (bf16_t)best[e]; ib |= (unsigned long long)(tap[e] & 0xff) << (8 * e); }
+  *reinterpret_cast<bf16x8*>(y + p * ldy + ycoff + c8 * 8) = o;
+  *reinterpret_cast<unsigned long long*>(idx + p * C + c8 * 8) = ib;
+}
+
+// dx[p] += sum over the outputs whose argmax is p (gather form: fixed order, deterministic); dx32 as in maxpool5_bwd_kernel
+__global__ __launch_bounds__(256) void maxpool_k_bwd_kernel(const bf16_t* dy, int ldy, int ycoff, const unsigned char* idx,
+                                                            bf16_t* dx, int ldx, int xcoff, int B, int H, int W, int C, int K,
+                                                            const float* dx32) {
+  const int C8 = C >> 3;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * H * W * C8) return;
+  const int c8 = (int)(i % C8);
+  const long p = i / C8;
+  const int ix = (int)(p % W), iy = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+  const int r = K >> 1;
+  float acc[8];
+  bf16_t* d = dx + p * ldx + xcoff + c8 * 8;
+  if (dx32) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = dx32[p * ldx + xcoff + c8 * 8 + e];
+  } else {
+    const bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (float)old[e];
+  }
+  for (int oy = max(iy - r, 0); oy <= min(iy + r, H - 1); ++oy)
+    for (int ox = max(ix - r, 0); ox <= min(ix + r, W - 1); ++ox) {
+      const long q = (long)(b * H + oy) * W + ox;
+      const unsigned long long ib = *reinterpret_cast<const unsigned long long*>(idx + q * C + c8 * 8);
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + q * ldy + ycoff + c8 * 8);
+      const unsigned me = (unsigned)((iy - oy + r) * 16 + (ix - ox + r));
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (((ib >> (8 * e)) & 0xffu) == me) acc[e] += (float)g[e];
+    }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)acc[e];
+  *reinterpret_cast<bf16x8*>(d) = o;
+}
+
 // ------------------------------------------------------------------ nearest x2 upsample
 __global__ void upsample2x_fwd_kernel(const bf16_t* x, int ldx, int xcoff, bf16_t* y, int ldy, int ycoff,
                                       int B, int H, int W, int C) {   // H,W = input dims
@@ -606,6 +684,32 @@ int kodhip_maxpool5_bwd(const void* dy, int ldy, int ycoff, const void* idx, voi
   hipLaunchKernelGGL(maxpool5_bwd_kernel, dim3(cdiv(n, POOL_BWD_THREADS)), dim3(POOL_BWD_THREADS), 0, stream, (const bf16_t*)dy, ldy, ycoff,
                      (const unsigned char*)idx, (bf16_t*)dx, ldx, xcoff, B, H, W, C, dx_f32);
   KOD_LAUNCH_CHECK("maxpool5_bwd");
+  return KOD_OK;
+}
+
+// Max-pool K x K / stride 1 / pad K / 2 for any odd K <= 15 (SPPFBottleneck's kernel_sizes, kod/nn/layers/sppf.py:27-67):
+// K = 5 takes the tuned kernels (kodhip_maxpool5_*), every other window the plain ones.  Same idx / dx_f32 conventions.
+int kodhip_maxpool_fwd(const void* x, int ldx, int xcoff, void* y, int ldy, int ycoff, void* idx,
+                       int B, int H, int W, int C, int K, hipStream_t stream) {
+  if (K == 5) return kodhip_maxpool5_fwd(x, ldx, xcoff, y, ldy, ycoff, idx, B, H, W, C, stream);
+  KOD_CHECK_ARG(x && y && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0, "maxpool_fwd: bad args");
+  KOD_CHECK_ARG(K >= 1 && K <= 15 && (K & 1), "maxpool_fwd: window %d (odd sizes up to 15)", K);
+  const long n = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool_k_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, xcoff, (bf16_t*)y, ldy, ycoff,
+                     (unsigned char*)idx, B, H, W, C, K);
+  KOD_LAUNCH_CHECK("maxpool_fwd");
+  return KOD_OK;
+}
+
+int kodhip_maxpool_bwd(const void* dy, int ldy, int ycoff, const void* idx, void* dx, int ldx, int xcoff,
+                       int B, int H, int W, int C, int K, const float* dx_f32, hipStream_t stream) {
+  if (K == 5) return kodhip_maxpool5_bwd(dy, ldy, ycoff, idx, dx, ldx, xcoff, B, H, W, C, dx_f32, stream);
+  KOD_CHECK_ARG(dy && dx && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && xcoff % 8 == 0 && ycoff % 8 == 0, "maxpool_bwd: bad args");
+  KOD_CHECK_ARG(K >= 1 && K <= 15 && (K & 1), "maxpool_bwd: window %d (odd sizes up to 15)", K);
+  const long n = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool_k_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, (const bf16_t*)dy, ldy, ycoff, (const unsigned char*)idx,
+                     (bf16_t*)dx, ldx, xcoff, B, H, W, C, K, dx_f32);
+  KOD_LAUNCH_CHECK("maxpool_bwd");
   return KOD_OK;
 }
 

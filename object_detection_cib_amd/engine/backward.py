@@ -371,9 +371,9 @@ class BackwardMixin:
                 pool_i -= 1
                 h, w = H // op.src.stride, W // op.src.stride
                 # src and dst are slices of the same (already initialised) concat gradient buffer
-                chk(lib.kodhip_maxpool5_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
-                                            self.pool_idx[pool_i].data_ptr(), self._ptr(op.src, True),
-                                            op.src.buf.C, op.src.coff, B, h, w, op.src.C, f32("pool", op, op.src)[1], s), "maxpool_bwd")
+                chk(lib.kodhip_maxpool_bwd(self._ptr(op.dst, True), op.dst.buf.C, op.dst.coff,
+                                           self.pool_idx[pool_i].data_ptr(), self._ptr(op.src, True),
+                                           op.src.buf.C, op.src.coff, B, h, w, op.src.C, op.k, f32("pool", op, op.src)[1], s), "maxpool_bwd")
             else:
                 group = [op.unit]
                 # SyncBN: short_conv (reached first in reverse order) and its main_conv share one exchange - main's

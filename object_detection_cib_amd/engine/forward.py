@@ -313,9 +313,9 @@ class ForwardMixin:
                     apply_stage(u)
             elif op.kind == "pool":
                 h, w = H // op.src.stride, W // op.src.stride
-                chk(lib.kodhip_maxpool5_fwd(self._ptr(op.src), op.src.buf.C, op.src.coff, self._ptr(op.dst),
-                                            op.dst.buf.C, op.dst.coff, self.pool_idx[pool_i].data_ptr(),
-                                            B, h, w, op.src.C, s), "maxpool")
+                chk(lib.kodhip_maxpool_fwd(self._ptr(op.src), op.src.buf.C, op.src.coff, self._ptr(op.dst),
+                                           op.dst.buf.C, op.dst.coff, self.pool_idx[pool_i].data_ptr(),
+                                           B, h, w, op.src.C, op.k, s), "maxpool")
                 pool_i += 1
             elif op.kind == "up":
                 h, w = H // op.src.stride, W // op.src.stride

@@ -75,6 +75,7 @@ class Op:
     unit: object = None
     src: Optional[View] = None
     dst: Optional[View] = None
+    k: int = 5           # pool: window (K x K / stride 1 / pad K // 2)
 
 
 @dataclass
@@ -140,27 +141,33 @@ class _Builder:
             cur = out
         self.run(last, self.full(cat), dst)
 
-    def sppf(self, name, src: Optional[View], dst: View, cin, cout, mid_channels_scale: float = 0.5, use_conv_first: bool = True):
-        """SPPFBottleneck (sppf.py:14-84), kernel 5: conv2(cat[x, p(x), p(p(x)), p(p(p(x)))]), x = conv1(in).
-        use_conv_first=False (sppf.py:37-39): no conv1, the module's input IS the first slice of the concat buffer
-        (src = None: the caller takes the returned view as its input)."""
+    def sppf(self, name, src: Optional[View], dst: View, cin, cout, mid_channels_scale: float = 0.5, use_conv_first: bool = True,
+             kernel_sizes=5):
+        """SPPFBottleneck (sppf.py:14-84): conv2(cat[x, pools...]), x = conv1(in).  kernel_sizes: an int k = the cascade
+        cat[x, p(x), p(p(x)), p(p(p(x)))] of k x k pools (sppf.py:49-55,74-77); a sequence = parallel pools cat[x, p_k0(x),
+        p_k1(x), ...] (sppf.py:56-63,78-82) - run as a cascade of the first size where the sequence is one (k, 2k - 1,
+        3k - 2, ...: a stride-1 max-pool of k applied j times IS the max-pool of j (k - 1) + 1, values and gradient routing
+        alike; the SPP sequence (5, 9, 13)), else each pool reads x.  use_conv_first=False (sppf.py:37-39): no conv1, the
+        module's input IS the first slice of the concat buffer (src = None: the caller takes the returned view as its input)."""
         pre = name + "." if name else ""
         name = name or "_"
         mid = int(cin * mid_channels_scale) if use_conv_first else cin
+        plan = sppf_pool_plan(kernel_sizes)                 # [(source slice, window)] per pool; slice q + 1 is its output
+        n = len(plan) + 1
         s1 = self.unit(f"{pre}conv1", cin, mid) if use_conv_first else None
-        s2 = self.unit(f"{pre}conv2", 4 * mid, cout)
+        s2 = self.unit(f"{pre}conv2", n * mid, cout)
         stride = src.stride if src is not None else dst.stride
-        scat = self.buf(f"{name}.cat", stride, 4 * mid)
+        scat = self.buf(f"{name}.cat", stride, n * mid)
         if s1 is not None:
             self.run(s1, src, View(scat, 0, mid))
-        for q in range(3):
-            self.g.ops.append(Op("pool", None, View(scat, q * mid, mid), View(scat, (q + 1) * mid, mid)))
+        for q, (sq, k) in enumerate(plan):
+            self.g.ops.append(Op("pool", None, View(scat, sq * mid, mid), View(scat, (q + 1) * mid, mid), k))
         self.run(s2, self.full(scat), dst)
         return View(scat, 0, mid)
 
 
 def _backbone(b: _Builder, g: Graph, pre: str, stages, widen_factor: float, deepen_factor: float, stage_dst: dict,
-              expand_ratio: float = 0.5):
+              expand_ratio: float = 0.5, spp_kernel_sizes=5):
     """Yolov5Backbone (backbones/yolov5.py:85-132): 6x6/s2/p2 stem + stages (3x3/s2 conv, CSPLayer, SPPF on `use_spp`).
     stage_dst: {stage index (1-based): View the stage writes its output into} (else a buffer of its own).
     Returns the stage outputs."""
@@ -182,9 +189,9 @@ def _backbone(b: _Builder, g: Graph, pre: str, stages, widen_factor: float, deep
         dst = stage_dst.get(i) or b.full(b.buf(f"{sname}.1.out", stride, cout))
         b.csp(f"{sname}.1", x, dst, cout, cout, make_round(nb, deepen_factor), ident, expand_ratio)
         cur = dst
-        if spp:                                        # SPPFBottleneck (sppf.py:14-84), kernel 5
+        if spp:                                        # SPPFBottleneck (sppf.py:14-84; backbones/yolov5.py:68-76 spp_kernel_sizes)
             P5 = b.full(b.buf(f"{sname}.2.out", stride, cout))
-            b.sppf(f"{sname}.2", cur, P5, cout, cout)
+            b.sppf(f"{sname}.2", cur, P5, cout, cout, kernel_sizes=spp_kernel_sizes)
             cur = P5
         outs.append(cur)
     return outs
@@ -269,27 +276,42 @@ def build_csp_layer_graph(cin: int, cout: int, expand_ratio: float = 0.5, add_id
     return g
 
 
-def build_sppf_graph(cin: int, cout: int, mid_channels_scale: float = 0.5, use_conv_first: bool = True) -> Graph:
-    """SPPFBottleneck (sppf.py:14-84): kernel size 5 in cascade - which is also what the parallel pools of sizes
-    (5, 9, 13) compute (a stride-1 max-pool of 5 applied j times is a max-pool of 4 j + 1) - with or without the
-    leading 1x1 conv."""
+def sppf_pool_plan(kernel_sizes):
+    """[(index of the concat slice the pool reads, window)] for SPPFBottleneck's kernel_sizes (sppf.py:27-83)."""
+    def ok(k):
+        if not (isinstance(k, int) and 1 <= k <= 15 and k % 2 == 1):
+            raise ValueError(f"SPPF window {k!r}: odd sizes 1 .. 15 (stride-1 pools that keep the image size)")
+        return k
+    if isinstance(kernel_sizes, int):
+        return [(q, ok(kernel_sizes)) for q in range(3)]                     # the cascade
+    ks = [ok(int(k)) for k in kernel_sizes]
+    if not ks:
+        raise ValueError("SPPF needs at least one window")
+    if ks[0] > 1 and all(k == (j + 1) * (ks[0] - 1) + 1 for j, k in enumerate(ks)):
+        return [(q, ks[0]) for q in range(len(ks))]                          # parallel pools that ARE a cascade of the first
+    return [(0, k) for k in ks]                                              # parallel pools of x
+
+
+def build_sppf_graph(cin: int, cout: int, mid_channels_scale: float = 0.5, use_conv_first: bool = True, kernel_sizes=5) -> Graph:
+    """SPPFBottleneck (sppf.py:14-84) in every form: one window size in cascade or a sequence of parallel pools (see
+    _Builder.sppf), with or without the leading 1x1 conv."""
     g = Graph(0, 0)
     b = _Builder(g)
     y = b.full(b.buf("out", 1, cout))
     if use_conv_first:
         x = b.full(b.buf("in", 1, cin))
-        b.sppf("", x, y, cin, cout, mid_channels_scale)
+        b.sppf("", x, y, cin, cout, mid_channels_scale, kernel_sizes=kernel_sizes)
     else:
-        x = b.sppf("", None, y, cin, cout, mid_channels_scale, use_conv_first=False)
+        x = b.sppf("", None, y, cin, cout, mid_channels_scale, use_conv_first=False, kernel_sizes=kernel_sizes)
     g.inputs, g.outputs = [x], [y]
     return g
 
 
-def build_backbone_graph(stages, widen_factor: float = 1.0, deepen_factor: float = 1.0) -> Graph:
+def build_backbone_graph(stages, widen_factor: float = 1.0, deepen_factor: float = 1.0, spp_kernel_sizes=5) -> Graph:
     """Yolov5Backbone (backbones/yolov5.py:85-132): image -> the four stage outputs."""
     g = Graph(0, 0)
     b = _Builder(g)
-    g.outputs = _backbone(b, g, "", [tuple(s) for s in stages], widen_factor, deepen_factor, {})
+    g.outputs = _backbone(b, g, "", [tuple(s) for s in stages], widen_factor, deepen_factor, {}, spp_kernel_sizes=spp_kernel_sizes)
     return g
 
 

@@ -26,9 +26,7 @@ class Yolov5Backbone(GraphModule):
                  deepen_factor: float = 1.0, widen_factor: float = 1.0, spp_kernel_sizes: int | Sequence[int] = 5):
         super().__init__()
         check_norm_act(norm_layer, activation_layer)
-        if spp_kernel_sizes != 5:
-            raise NotImplementedError("the HIP SPPF implements kernel size 5")
-        self._init_graph(build_backbone_graph([tuple(s) for s in stages], widen_factor, deepen_factor), norm_layer)
+        self._init_graph(build_backbone_graph([tuple(s) for s in stages], widen_factor, deepen_factor, spp_kernel_sizes), norm_layer)
 
     def forward(self, x: torch.Tensor) -> list:
         return self._run([x])[1]

@@ -222,4 +222,7 @@ def protocol_side_channel():
 def sppf_cases():
     """name -> (cin, cout, kernel_sizes, use_conv_first, B, H, W, seed): SPPFBottleneck's three forms (sppf.py:27-83)"""
     return {"k5": (16, 24, 5, True, 2, 12, 10, 31), "k5_9_13": (16, 24, (5, 9, 13), True, 2, 12, 10, 32),
-            "k5_9_13_noconv": (8, 24, (5, 9, 13), False, 2, 12, 10, 33)}
+            "k5_9_13_noconv": (8, 24, (5, 9, 13), False, 2, 12, 10, 33),
+            # other windows (round 6): a cascade of 3 x 3 pools, parallel pools that are no cascade, one 7 x 7 window without conv1
+            "k3": (16, 24, 3, True, 2, 12, 10, 34), "k3_7": (16, 24, (3, 7), True, 2, 12, 10, 35),
+            "k7_noconv": (8, 24, (7,), False, 2, 12, 10, 36)}

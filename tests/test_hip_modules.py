@@ -126,10 +126,23 @@ def test_sppf_bottleneck():
     # more often than fp32 ones, so a 5x5 max-pool routes some gradients to another pixel than the fp32 oracle does (the pool
     # backward itself is pinned against torch on identical bf16 inputs in test_hip_ops): a wider bar on what passes the pools
     _compare(hip, ref, [x], ftol=2e-2, gtol=1.5e-1, in_gtol=2e-1)
-    with pytest.raises(NotImplementedError):
-        SPPFBottleneck(64, 64, kernel_sizes=(3, 5, 7))             # other windows than 5 / (5, 9, 13) are not built
-    with pytest.raises(NotImplementedError):
-        SPPFBottleneck(64, 64, kernel_sizes=9)
+    with pytest.raises(ValueError):
+        SPPFBottleneck(64, 64, kernel_sizes=4)                     # even windows change the image size: refused like a bad config
+    with pytest.raises(ValueError):
+        SPPFBottleneck(64, 64, kernel_sizes=(3, 17))
+
+
+@pytest.mark.parametrize("ks,first", [(3, True), ((3, 7), True), ((7,), False), (9, True), ((3, 5, 7), True)])
+def test_sppf_other_windows(ks, first):
+    """SPPFBottleneck with windows other than 5 (kod/nn/layers/sppf.py:27-67 takes any size or sequence): cascades of k x k
+    pools, parallel pools that are no cascade ((3, 7): both read x and their gradients meet in x's slice), one window
+    without the leading conv, and a sequence that IS a cascade ((3, 5, 7) = three 3 x 3 pools) - against the oracle module,
+    whose forms 'k3', 'k3_7', 'k7_noconv' are pinned to the reference by tests/golden/sppf.npz."""
+    cin = 128 if first else 64
+    x = torch.randn(3, cin, 16, 16, generator=torch.Generator().manual_seed(21))
+    torch.manual_seed(22); hip = SPPFBottleneck(cin, 128, kernel_sizes=ks, use_conv_first=first, norm_layer=Yolov5BatchNorm2d)
+    torch.manual_seed(22); ref = N.SPPF(cin, 128, ks, first)
+    _compare(hip, ref, [x], ftol=2e-2, gtol=1.5e-1, in_gtol=2e-1)
 
 
 @pytest.mark.parametrize("first", [True, False])

@@ -431,6 +431,32 @@ def test_maxpool_chain_and_upsample():
     _close(nchw(dx), xr.grad + 1, 1e-2, 2e-2, "upsample grad (accumulate)")
 
 
+@pytest.mark.parametrize("K,shape", [(3, (2, 16, 9, 11)), (7, (2, 8, 12, 10)), (9, (1, 24, 20, 20)), (13, (2, 8, 6, 17)), (1, (1, 8, 4, 4)),
+                                     (5, (2, 16, 9, 11))])
+def test_maxpool_any_window_vs_torch(K, shape):
+    """kodhip_maxpool_fwd / _bwd (SPPFBottleneck's kernel_sizes other than 5, kod/nn/layers/sppf.py:27-67): values, the
+    argmax routing of the gradient (ties: bf16 values from a small set - torch's first maximum wins) and the accumulation
+    into an existing gradient, against torch.nn.MaxPool2d(K, 1, K // 2) on the same bf16 values; K = 5 dispatches to the
+    tuned kernels and must agree the same way."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(K)
+    x = bf(torch.randint(-5, 6, (B, C, H, W), generator=g).float() * 0.5)
+    xr = x.clone().requires_grad_(True)
+    y = torch.nn.MaxPool2d(K, 1, K // 2)(xr)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    lib = _lib.lib()
+    xb, yb = nhwc(x), torch.zeros((B, H, W, C), dtype=torch.bfloat16, device="cuda")
+    idx = torch.zeros((B, H, W, C), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.kodhip_maxpool_fwd(xb.data_ptr(), C, 0, yb.data_ptr(), C, 0, idx.data_ptr(), B, H, W, C, K, stream()), "pool")
+    assert torch.equal(nchw(yb), y.detach())
+    base = bf(torch.randn(B, C, H, W, generator=g))
+    dxb = nhwc(base)
+    _lib.check(lib.kodhip_maxpool_bwd(nhwc(dy).data_ptr(), C, 0, idx.data_ptr(), dxb.data_ptr(), C, 0, B, H, W, C, K, None, stream()), "pool bwd")
+    _close(nchw(dxb), base + xr.grad, 2e-2, 1e-2 * (base + xr.grad).abs().max().item(), f"pool {K} gradient")
+    assert lib.kodhip_maxpool_fwd(xb.data_ptr(), C, 0, yb.data_ptr(), C, 0, idx.data_ptr(), B, H, W, C, 4, stream()) != 0     # even window: refused
+
+
 @pytest.mark.parametrize("nesterov,dampening,maximize", [(True, 0.0, False), (False, 0.0, False), (False, 0.3, False),
                                                          (False, 0.0, True), (False, 0.25, True)])
 def test_sgd_nesterov(nesterov, dampening, maximize):
