@@ -821,21 +821,33 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
             for (int e = 0; e < 8; ++e) { sg_sc[e] = a.seg_aff[sgi][cl + e]; sg_sh[e] = a.seg_aff[sgi][a.seg_C[sgi] + cl + e]; }
           }
       }
+      // stride-2 data gradients scatter their rows: (image, row, column) of this thread's first row by float-reciprocal
+      // division, then advanced by RPP per pass (round 6: two integer divisions per pass - ~ 60 VALU instructions, 8 passes
+      // per tile - in launches whose SIMDs are ~ 50 % VALU-busy, profiles/r06_s2_pmc.txt)
+      int pb = 0, poy = 0, pox = 0;
+      if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
+        if (a.out_mul != 1) {
+          int prem;
+          fast_divmod(m0 + r0 < a.M ? m0 + r0 : 0, HWo, a.rcp_hwo, pb, prem);
+          fast_divmod(prem, a.Wo, a.rcp_wo, poy, pox);
+        }
+      }
 #pragma unroll
       for (int p = 0; p < BM / RPP; ++p) {
         int row = r0 + p * RPP;
         int m = m0 + row;
+        if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
+          if (p > 0 && a.out_mul != 1) {
+            pox += RPP;
+            while (pox >= a.Wo) { pox -= a.Wo; if (++poy == a.Ho) { poy = 0; ++pb; } }
+          }
+        }
         if (m < a.M && col_ok) {
           bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS_ROW + c * 8);
           size_t opix = (size_t)m;
           if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
-            if (a.out_mul != 1) {
-              int b = m / HWo;
-              int rem = m - b * HWo;
-              int oy = rem / a.Wo;
-              int ox = rem - oy * a.Wo;
-              opix = ((size_t)b * a.out_H + oy * a.out_mul) * a.out_W + ox * a.out_mul + pix_off;
-            }
+            if (a.out_mul != 1)        // (pixel counts fit 31 bits: fill_common)
+              opix = (size_t)(uint32_t)((pb * a.out_H + poy * a.out_mul) * a.out_W + pox * a.out_mul + pix_off);
           }
           bf16_t* dst = a.y + opix * a.ldy + a.ycoff + nch;
           if constexpr (MODE == MODE_PLAIN || MODE == MODE_PLAIN_BN) {
