@@ -224,6 +224,19 @@ int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout,
                              const float* shift, const float* coef, void* dI, int ldi, int dicoff, int di_accum,
                              long M, int C, kodStream_t stream);
 
+/* The same three elementwise passes for the other activations the reference's layer signatures admit
+ * (kod/nn/layers/csp.py:16-46: `activation_layer: Callable[..., nn.Module]`; its configs use SiLUInplace only):
+ * act = 0 SiLU (dispatches to the entries above), 1 ReLU, 2 LeakyReLU(slope), 3 Hardswish, 4 identity (activation_layer=None);
+ * torch's conventions at the kinks.  A network built with one of them runs the BatchNorm-backward reduction as its own pass. */
+int kodhip_bn_act_apply(const void* y, int ldy, const float* scale, const float* shift, const void* residual, int ldr, int rcoff,
+                        void* out, int ldo, int ocoff, long M, int C, int act, float slope, kodStream_t stream);
+int kodhip_bn_act_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, int ldy, const float* scale, const float* shift,
+                            const float* coef, void* dI, int ldi, int dicoff, int di_accum, long M, int C, int act, float slope,
+                            kodStream_t stream);
+int kodhip_bn_act_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, int ldy, const float* scale, const float* shift,
+                             const float* mean, const float* rstd, float* partials, long M, int C, int act, float slope,
+                             kodStream_t stream);
+
 /* ---- SPPF max-pool, nearest upsample (kod/nn/layers/sppf.py:46-50,73-76,
  *      kod/nn/necks/yolov5_pafpn.py:144-146,182-184) ------------------------------------------------- */
 /* idx: [B][H][W][C] bytes, the winning tap of every output (an opaque code: written by _fwd, read by _bwd of the same

@@ -78,6 +78,9 @@ SIGNATURES = {
     "kodhip_bn_silu_bwd_reduce": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, i64, i32, vp]),
     "kodhip_bn_bwd_coeffs": (i32, [vp, vp, f64, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "kodhip_bn_silu_bwd_apply": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i64, i32, vp]),
+    "kodhip_bn_act_apply": (i32, [vp, i32, vp, vp, vp, i32, i32, vp, i32, i32, i64, i32, i32, f32, vp]),
+    "kodhip_bn_act_bwd_reduce": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, f32, vp]),
+    "kodhip_bn_act_bwd_apply": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i64, i32, i32, f32, vp]),
     "kodhip_maxpool5_fwd": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "kodhip_maxpool5_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "kodhip_maxpool_fwd": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),

@@ -421,6 +421,121 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const bf16_t* d
   }
 }
 
+// ---------------------------------------------------------------- activations other than SiLU
+// The reference's layers take any activation callable (kod/nn/layers/csp.py:16-46, sppf.py:14-27, networks/yolov5.py:40-50);
+// its configs only ever use SiLUInplace, which the tuned kernels above (and the fused epilogues in conv_igemm.hip /
+// conv_wgrad.hip) implement.  These three plain passes carry the other elementwise activations torch offers for the slot -
+// ReLU, LeakyReLU(slope), Hardswish, Identity (activation_layer=None) - with torch's conventions at the kinks
+// (aten/native/cpu/Activation.cpp: relu' (0) = 0, leaky_relu' uses x > 0, hardswish' = 0 up to -3, x / 3 + 0.5 inside (-3, 3), 1 from 3 on);
+// a network built with one of them runs its BatchNorm-backward reduction as its own pass (no fused epilogues).
+enum { ACT_SILU = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_HARDSWISH = 3, ACT_IDENTITY = 4 };
+template <int ACT> __device__ __forceinline__ float kod_act(float z, float slope) {
+  if (ACT == ACT_RELU) return z > 0.f ? z : 0.f;
+  if (ACT == ACT_LEAKY) return z > 0.f ? z : z * slope;
+  if (ACT == ACT_HARDSWISH) return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+  return z;
+}
+template <int ACT> __device__ __forceinline__ float kod_act_bwd(float g, float z, float slope) {
+  if (ACT == ACT_RELU) return z > 0.f ? g : 0.f;
+  if (ACT == ACT_LEAKY) return z > 0.f ? g : g * slope;
+  if (ACT == ACT_HARDSWISH) return z <= -3.f ? 0.f : (z < 3.f ? g * ((z / 3.f) + 0.5f) : g);     // (torch 2.x: 0 at -3, g at 3)
+  return g;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_apply_kernel(const bf16_t* y, int ldy, const float* scale, const float* shift,
+                                                           const bf16_t* res, int ldr, int rcoff, bf16_t* out, int ldo, int ocoff,
+                                                           long M, int C, int rpb, float slope) {
+  const int CC = C >> 3, cc = threadIdx.x % CC, rl = threadIdx.x / CC;
+  if (rl >= rpb) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; }
+  for (long m = (long)blockIdx.x * rpb + rl; m < M; m += (long)gridDim.x * rpb) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * ldy + cc * 8);
+    bf16x8 r = {}, o;
+    if (res) r = *reinterpret_cast<const bf16x8*>(res + m * ldr + rcoff + cc * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = kod_act<ACT>(__builtin_fmaf((float)v[e], sc[e], sh[e]), slope);
+      o[e] = (bf16_t)(res ? a + (float)r[e] : a);
+    }
+    *reinterpret_cast<bf16x8*>(out + m * ldo + ocoff + cc * 8) = o;
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, bf16_t* y, int ldy,
+                                                               const float* scale, const float* shift, const float* coef,
+                                                               bf16_t* dI, int ldi, int dicoff, int di_accum, long M, int C, int rpb,
+                                                               float slope) {
+  const int CC = C >> 3, cc = threadIdx.x % CC, rl = threadIdx.x / CC;
+  if (rl >= rpb) return;
+  float sc[8], sh[8], k1[8], k2[8], k3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = cc * 8 + e;
+    sc[e] = scale[c]; sh[e] = shift[c]; k1[e] = coef[c]; k2[e] = coef[C + c]; k3[e] = coef[2 * C + c];
+  }
+  for (long m = (long)blockIdx.x * rpb + rl; m < M; m += (long)gridDim.x * rpb) {
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * ldy + cc * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float yv = (float)v[e];
+      const float dz = kod_act_bwd<ACT>((float)g[e], __builtin_fmaf(yv, sc[e], sh[e]), slope);
+      o[e] = (bf16_t)__builtin_fmaf(k1[e], dz, __builtin_fmaf(k2[e], yv, k3[e]));
+    }
+    *reinterpret_cast<bf16x8*>(y + m * ldy + cc * 8) = o;
+    if (dI) {
+      bf16x8 gi = g;
+      if (di_accum) {
+        const bf16x8 old = *reinterpret_cast<const bf16x8*>(dI + m * ldi + dicoff + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gi[e] = (bf16_t)((float)gi[e] + (float)old[e]);
+      }
+      *reinterpret_cast<bf16x8*>(dI + m * ldi + dicoff + cc * 8) = gi;
+    }
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const bf16_t* dA, int lda, int dacoff, const bf16_t* y, int ldy,
+                                                                const float* scale, const float* shift, const float* mean,
+                                                                const float* rstd, float* part, long M, int C, int rpb, float slope) {
+  extern __shared__ float sm[];   // [rpb][CC][16]
+  const int CC = C >> 3, cc = threadIdx.x % CC, rl = threadIdx.x / CC;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+  if (rl < rpb) {
+    float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; mu[e] = mean[cc * 8 + e]; rs[e] = rstd[cc * 8 + e]; }
+    for (long m = (long)blockIdx.x * rpb + rl; m < M; m += (long)gridDim.x * rpb) {
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(dA + m * lda + dacoff + cc * 8);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * ldy + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yv = (float)v[e];
+        const float dz = kod_act_bwd<ACT>((float)g[e], __builtin_fmaf(yv, sc[e], sh[e]), slope);
+        s0[e] += dz;
+        s1[e] += dz * (yv - mu[e]) * rs[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sm[(rl * CC + cc) * 16 + e] = s0[e]; sm[(rl * CC + cc) * 16 + 8 + e] = s1[e]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CC * 16; i += blockDim.x) {          // fixed-order reduction over the row lanes
+    const int c8 = i >> 4, e = i & 15;
+    float s = 0.f;
+    for (int r = 0; r < rpb; ++r) s += sm[(r * CC + c8) * 16 + e];
+    part[((size_t)(e >> 3) * C + c8 * 8 + (e & 7)) * gridDim.x + blockIdx.x] = s;
+  }
+}
+
 // grads from the LOCAL sums; coefficients from the (all-reduced) sums:
 //   dY = k1*dz + k2*y + k3,  k1 = g*rstd, k2 = -g*rstd^2*S1/n, k3 = -g*rstd*S0/n + g*rstd^2*mean*S1/n
 __global__ void bn_bwd_coeffs_kernel(const double* sums_local, const double* sums_global, double count,
@@ -722,6 +837,60 @@ int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout,
   if (tu == 8) KOD_BAPPLY(8); else if (tu == 2) KOD_BAPPLY(2); else if (tu == 4) KOD_BAPPLY(4); else KOD_BAPPLY(1);
 #undef KOD_BAPPLY
   KOD_LAUNCH_CHECK("bn_silu_bwd_apply");
+  return KOD_OK;
+}
+
+// ---- the same three passes for an activation other than SiLU (see bn_act_apply_kernel): act = 0 SiLU (the tuned kernels
+// above), 1 ReLU, 2 LeakyReLU(slope), 3 Hardswish, 4 identity (activation_layer=None).  Arguments as in the SiLU entries.
+#define KOD_ACT_DISPATCH(KERNEL, ...)                                                             \
+  switch (act) {                                                                                  \
+    case ACT_RELU: hipLaunchKernelGGL(KERNEL<ACT_RELU>, __VA_ARGS__); break;                      \
+    case ACT_LEAKY: hipLaunchKernelGGL(KERNEL<ACT_LEAKY>, __VA_ARGS__); break;                    \
+    case ACT_HARDSWISH: hipLaunchKernelGGL(KERNEL<ACT_HARDSWISH>, __VA_ARGS__); break;            \
+    default: hipLaunchKernelGGL(KERNEL<ACT_IDENTITY>, __VA_ARGS__); break;                        \
+  }
+
+int kodhip_bn_act_apply(const void* y, int ldy, const float* scale, const float* shift, const void* residual, int ldr, int rcoff,
+                        void* out, int ldo, int ocoff, long M, int C, int act, float slope, hipStream_t stream) {
+  if (act == ACT_SILU) return kodhip_bn_silu_apply(y, ldy, scale, shift, residual, ldr, rcoff, out, ldo, ocoff, M, C, stream);
+  KOD_CHECK_ARG(act >= 1 && act <= 4, "bn_act_apply: activation code %d", act);
+  KOD_CHECK_ARG(y && scale && shift && out && M > 0, "bn_act_apply: bad args");
+  KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldo % 8 == 0 && ocoff % 8 == 0 && ocoff + C <= ldo && ldy % 8 == 0 && ldy >= C, "bn_act_apply: bad channel geometry");
+  KOD_CHECK_ARG(!residual || (ldr % 8 == 0 && rcoff % 8 == 0 && rcoff + C <= ldr), "bn_act_apply: bad residual slice");
+  Geo g = geo(M, C, apply_grid_cap(M, C));
+  KOD_ACT_DISPATCH(bn_act_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, ldy, scale, shift, (const bf16_t*)residual,
+                   ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb, slope)
+  KOD_LAUNCH_CHECK("bn_act_apply");
+  return KOD_OK;
+}
+
+int kodhip_bn_act_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, int ldy, const float* scale, const float* shift,
+                            const float* coef, void* dI, int ldi, int dicoff, int di_accum, long M, int C, int act, float slope,
+                            hipStream_t stream) {
+  if (act == ACT_SILU) return kodhip_bn_silu_bwd_apply(dA, lda, dacoff, y_inout, ldy, scale, shift, coef, dI, ldi, dicoff, di_accum, M, C, stream);
+  KOD_CHECK_ARG(act >= 1 && act <= 4, "bn_act_bwd_apply: activation code %d", act);
+  KOD_CHECK_ARG(dA && y_inout && scale && shift && coef && M > 0, "bn_act_bwd_apply: bad args");
+  KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda && ldy % 8 == 0 && ldy >= C, "bn_act_bwd_apply: bad geometry");
+  KOD_CHECK_ARG(!dI || (ldi % 8 == 0 && dicoff % 8 == 0 && dicoff + C <= ldi), "bn_act_bwd_apply: bad identity slice");
+  Geo g = geo(M, C, apply_grid_cap(M, C));
+  KOD_ACT_DISPATCH(bn_act_bwd_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)dA, lda, dacoff, (bf16_t*)y_inout, ldy,
+                   scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb, slope)
+  KOD_LAUNCH_CHECK("bn_act_bwd_apply");
+  return KOD_OK;
+}
+
+int kodhip_bn_act_bwd_reduce(const void* dA, int lda, int dacoff, const void* y, int ldy, const float* scale, const float* shift,
+                             const float* mean, const float* rstd, float* partials, long M, int C, int act, float slope,
+                             hipStream_t stream) {
+  if (act == ACT_SILU) return kodhip_bn_silu_bwd_reduce(dA, lda, dacoff, y, ldy, scale, shift, mean, rstd, partials, M, C, stream);
+  KOD_CHECK_ARG(act >= 1 && act <= 4, "bn_act_bwd_reduce: activation code %d", act);
+  KOD_CHECK_ARG(dA && y && scale && shift && mean && rstd && partials && M > 0, "bn_act_bwd_reduce: bad args");
+  KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda && ldy % 8 == 0 && ldy >= C, "bn_act_bwd_reduce: bad geometry");
+  Geo g = geo(M, C, bwd_reduce_blocks(M, C));
+  const size_t shm = (size_t)g.rpb * (C / 8) * 16 * sizeof(float);
+  KOD_ACT_DISPATCH(bn_act_bwd_reduce_kernel, dim3(g.grid), dim3(g.threads), shm, stream, (const bf16_t*)dA, lda, dacoff, (const bf16_t*)y, ldy,
+                   scale, shift, mean, rstd, partials, M, C, g.rpb, slope)
+  KOD_LAUNCH_CHECK("bn_act_bwd_reduce");
   return KOD_OK;
 }
 

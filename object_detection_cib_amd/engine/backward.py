@@ -261,9 +261,9 @@ class BackwardMixin:
                 if not st.fused_red:
                     aff, dA = st.aff.data_ptr(), u.dst
                     e0 = self._t0()
-                    chk(lib.kodhip_bn_silu_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
-                                                      aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
-                                                      st.bpart.data_ptr(), st.M, C_, s), u.name)
+                    chk(lib.kodhip_bn_act_bwd_reduce(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
+                                                     aff, aff + 4 * C_, aff + 8 * C_, aff + 12 * C_,
+                                                     st.bpart.data_ptr(), st.M, C_, self.act_kind, self.act_slope, s), u.name)
                     self._t1(e0, "bn_bwd_reduce", 4.0 * st.M * C_, name=u.name)
             e0 = self._t0()
             if sync and self.peer is not None:
@@ -443,11 +443,11 @@ class BackwardMixin:
             return
         racc = acc_flag(res) if res else 0
         e0 = self._t0()
-        chk(lib.kodhip_bn_silu_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
-                                         aff, aff + 4 * C_, st.coef.data_ptr(),
-                                         self._ptr(res, True) if res else None,
-                                         res.buf.C if res else 0, res.coff if res else 0,
-                                         racc, st.M, C_, s), u.name)
+        chk(lib.kodhip_bn_act_bwd_apply(self._ptr(dA, True), dA.buf.C, dA.coff, st.raw.data_ptr(), st.raw_ld,
+                                        aff, aff + 4 * C_, st.coef.data_ptr(),
+                                        self._ptr(res, True) if res else None,
+                                        res.buf.C if res else 0, res.coff if res else 0,
+                                        racc, st.M, C_, self.act_kind, self.act_slope, s), u.name)
         self._t1(e0, "bn_silu_bwd_apply", (6.0 + ((4.0 if racc else 2.0) if res else 0.0)) * st.M * C_, name=u.name)
         self._fork_point()
         # st.raw now holds dY

@@ -49,6 +49,7 @@ class Engine(ArenaMixin, BufferMixin, ForwardMixin, BackwardMixin):
         self.max_shape_sets = self.opt.max_shape_sets
         self.training_ready = False
         self.bn_eps, self.bn_momentum = BN_EPS, BN_MOMENTUM     # the network's BatchNorm2d constants (set by the nn.Module that owns the engine)
+        self.act_kind, self.act_slope = 0, 0.0                  # the units' activation (csrc/bn_act.hip ACT_*; 0 = SiLU), see set_activation
         self.sync_bn = False
         self.process_group = None
         self.world_size = 1
@@ -82,3 +83,12 @@ class Engine(ArenaMixin, BufferMixin, ForwardMixin, BackwardMixin):
         # (bench.py stamp_report): stamp_names[i] <-> stamp_buf[i]
         self.stamp_buf, self.stamp_names = None, []
         self.stamps_on = os.environ.get("KODHIP_DEBUG_STAMPS", "0") == "1"
+
+    def set_activation(self, kind: int, slope: float = 0.0):
+        """The conv units' activation (nn/graph_module.activation_code), to be set before the arenas are built.  Anything but
+        SiLU runs on the plain elementwise passes (kodhip_bn_act_*): the fused forms that carry SiLU's arithmetic - the
+        BatchNorm-backward reduction in the data gradients' epilogue, the fused stem backward, the pair apply - are off."""
+        import dataclasses
+        self.act_kind, self.act_slope = int(kind), float(slope)
+        if self.act_kind != 0:
+            self.opt = dataclasses.replace(self.opt, bn_reduce_fused=False, stem_bwd_fused=False, pair_fwd=0)

@@ -231,10 +231,10 @@ class ForwardMixin:
             sc_p, sh_p = (aff, aff + 4 * C_) if training else eval_aff[u.name]
             res = u.residual
             e0 = self._t0()
-            chk(lib.kodhip_bn_silu_apply(st.raw.data_ptr(), st.raw_ld, sc_p, sh_p,
-                                         self._ptr(res) if res else None, res.buf.C if res else 0,
-                                         res.coff if res else 0,
-                                         self._ptr(u.dst), u.dst.buf.C, u.dst.coff, st.M, C_, s), u.name)
+            chk(lib.kodhip_bn_act_apply(st.raw.data_ptr(), st.raw_ld, sc_p, sh_p,
+                                        self._ptr(res) if res else None, res.buf.C if res else 0,
+                                        res.coff if res else 0,
+                                        self._ptr(u.dst), u.dst.buf.C, u.dst.coff, st.M, C_, self.act_kind, self.act_slope, s), u.name)
             self._t1(e0, "bn_silu_apply", (6.0 if res else 4.0) * st.M * C_, name=u.name)
 
         # A CSP layer's short_conv (conv -> statistics -> apply) depends only on the layer input and is needed only by

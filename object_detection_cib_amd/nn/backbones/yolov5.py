@@ -25,8 +25,8 @@ class Yolov5Backbone(GraphModule):
     def __init__(self, norm_layer: Callable[..., nn.Module], activation_layer: Callable[..., nn.Module], stages: list,
                  deepen_factor: float = 1.0, widen_factor: float = 1.0, spp_kernel_sizes: int | Sequence[int] = 5):
         super().__init__()
-        check_norm_act(norm_layer, activation_layer)
-        self._init_graph(build_backbone_graph([tuple(s) for s in stages], widen_factor, deepen_factor, spp_kernel_sizes), norm_layer)
+        act = check_norm_act(norm_layer, activation_layer)
+        self._init_graph(build_backbone_graph([tuple(s) for s in stages], widen_factor, deepen_factor, spp_kernel_sizes), norm_layer, activation=act)
 
     def forward(self, x: torch.Tensor) -> list:
         return self._run([x])[1]

@@ -50,14 +50,36 @@ def batchnorm_constants(norm_layer):
     return float(probe.eps), float(probe.momentum)
 
 
+ACT_SILU, ACT_RELU, ACT_LEAKY, ACT_HARDSWISH, ACT_IDENTITY = 0, 1, 2, 3, 4      # csrc/bn_act.hip
+
+
+def activation_code(activation_layer):
+    """(code, negative slope) of the elementwise activation an `activation_layer` callable builds (torchvision's
+    Conv2dNormActivation semantics: None = no activation).  SiLU - the reference's only configured choice - runs on the
+    tuned kernels and fused epilogues; ReLU / LeakyReLU / Hardswish / identity on the plain passes (csrc/bn_act.hip
+    bn_act_*); anything else is refused rather than silently replaced."""
+    if activation_layer is None:
+        return ACT_IDENTITY, 0.0
+    probe = activation_layer()
+    if isinstance(probe, nn.SiLU) or type(probe).__name__ in ("SiLU", "SiLUInplace"):
+        return ACT_SILU, 0.0
+    if isinstance(probe, nn.LeakyReLU):
+        return ACT_LEAKY, float(probe.negative_slope)
+    if isinstance(probe, nn.ReLU):
+        return ACT_RELU, 0.0
+    if isinstance(probe, nn.Hardswish):
+        return ACT_HARDSWISH, 0.0
+    if isinstance(probe, nn.Identity):
+        return ACT_IDENTITY, 0.0
+    raise ValueError("the HIP path implements SiLU, ReLU, LeakyReLU, Hardswish and Identity / None activations "
+                     f"(got {type(probe).__name__})")
+
+
 def check_norm_act(norm_layer, activation_layer):
-    """BatchNorm2d (any eps / momentum, see batchnorm_constants) + SiLU; anything else is refused rather than silently
-    replaced."""
+    """BatchNorm2d (any eps / momentum, see batchnorm_constants) + one of the activations of activation_code(); anything
+    else is refused rather than silently replaced.  Returns (activation code, slope)."""
     batchnorm_constants(norm_layer)
-    if activation_layer is not None:
-        probe = activation_layer()
-        if not isinstance(probe, nn.SiLU) and type(probe).__name__ not in ("SiLU", "SiLUInplace"):
-            raise ValueError("the HIP path implements SiLU only")
+    return activation_code(activation_layer)
 
 
 def add_unit_parameters(root: nn.Module, graph: Graph, norm_layer):
@@ -108,9 +130,11 @@ class _GraphFn(torch.autograd.Function):
 class GraphModule(nn.Module):
     """Base of the sub-network modules: parameters as torch holders, execution through an Engine over `self.graph`."""
 
-    def _init_graph(self, graph: Graph, norm_layer, use_yv5_init: bool = True, prior_probability: float = 0.01):
+    def _init_graph(self, graph: Graph, norm_layer, use_yv5_init: bool = True, prior_probability: float = 0.01,
+                    activation=(ACT_SILU, 0.0)):
         from .networks.yolov5 import Yolov5BatchNorm2d
         self.graph = graph
+        self._act = tuple(activation)           # (code, slope) from check_norm_act / activation_code
         self._bn_eps, self._bn_momentum = batchnorm_constants(norm_layer)
         add_unit_parameters(self, graph, norm_layer or Yolov5BatchNorm2d)
         if graph.heads:
@@ -127,6 +151,7 @@ class GraphModule(nn.Module):
                 raise RuntimeError(f"{type(self).__name__} (HIP) must be on an MI355X: call .cuda() first; no CPU fallback")
             eng = Engine(self.graph, self._engine_params(), dict(self.named_buffers()), self.engine_options)
             eng.bn_eps, eng.bn_momentum = getattr(self, "_bn_eps", BN_EPS), getattr(self, "_bn_momentum", BN_MOMENTUM)
+            eng.set_activation(*getattr(self, "_act", (ACT_SILU, 0.0)))
             eng._build_arenas(dev)
             self._engine, self._engine_device = eng, dev
         return self._engine

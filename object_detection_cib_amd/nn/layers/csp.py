@@ -17,9 +17,9 @@ class CSPBlock(GraphModule):
     def __init__(self, in_channels: int, out_channels: int, expand_ratio: float = 0.5, add_identity: bool = True,
                  norm_layer: Callable[..., nn.Module] = nn.BatchNorm2d, activation_layer: Callable[..., nn.Module] = SiLUInplace):
         super().__init__()
-        check_norm_act(norm_layer, activation_layer)
+        act = check_norm_act(norm_layer, activation_layer)
         self.add_identity = add_identity and in_channels == out_channels
-        self._init_graph(build_csp_block_graph(in_channels, out_channels, expand_ratio, add_identity), norm_layer)
+        self._init_graph(build_csp_block_graph(in_channels, out_channels, expand_ratio, add_identity), norm_layer, activation=act)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._run([x])[1][0]
@@ -33,8 +33,8 @@ class CSPLayer(GraphModule):
                  num_blocks: int = 1, norm_layer: Callable[..., nn.Module] = nn.BatchNorm2d,
                  activation_layer: Callable[..., nn.Module] = SiLUInplace):
         super().__init__()
-        check_norm_act(norm_layer, activation_layer)
-        self._init_graph(build_csp_layer_graph(in_channels, out_channels, expand_ratio, add_identity, num_blocks), norm_layer)
+        act = check_norm_act(norm_layer, activation_layer)
+        self._init_graph(build_csp_layer_graph(in_channels, out_channels, expand_ratio, add_identity, num_blocks), norm_layer, activation=act)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._run([x])[1][0]

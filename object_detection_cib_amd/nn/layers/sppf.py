@@ -22,9 +22,9 @@ class SPPFBottleneck(GraphModule):
                  mid_channels_scale: float = 0.5, norm_layer: Callable[..., nn.Module] = nn.BatchNorm2d,
                  activation_layer: Callable[..., nn.Module] = SiLUInplace):
         super().__init__()
-        check_norm_act(norm_layer, activation_layer)
+        act = check_norm_act(norm_layer, activation_layer)
         self.kernel_sizes = kernel_sizes
-        self._init_graph(build_sppf_graph(in_channels, out_channels, mid_channels_scale, use_conv_first, kernel_sizes), norm_layer)
+        self._init_graph(build_sppf_graph(in_channels, out_channels, mid_channels_scale, use_conv_first, kernel_sizes), norm_layer, activation=act)
         if not use_conv_first:
             self.conv1 = None                       # (the attribute exists and is None, sppf.py:39)
 

@@ -18,10 +18,10 @@ class Yolov5PAFPN(GraphModule):
                  activation_layer: Callable[..., nn.Module], num_blocks: int = 3, expand_ratio: float = 0.5,
                  deepen_factor: float = 1.0, widen_factor: float = 1.0):
         super().__init__()
-        check_norm_act(norm_layer, activation_layer)
+        act = check_norm_act(norm_layer, activation_layer)
         self.in_channels_list = in_channels_list
         self.widen_factor, self.deepen_factor, self.num_blocks = widen_factor, deepen_factor, num_blocks
-        self._init_graph(build_pafpn_graph(in_channels_list, num_blocks, expand_ratio, deepen_factor, widen_factor), norm_layer)
+        self._init_graph(build_pafpn_graph(in_channels_list, num_blocks, expand_ratio, deepen_factor, widen_factor), norm_layer, activation=act)
 
     def forward(self, inputs: Sequence[torch.Tensor]) -> tuple:
         assert len(inputs) == len(self.in_channels_list)

@@ -20,6 +20,7 @@ import torch.nn as nn
 from ...engine.graph import build_graph, P5_STAGES  # noqa: F401
 from ...engine.executor import Engine, BN_EPS, BN_MOMENTUM
 from ..heads.types import DetectionHeadResult
+from ..layers.activations import SiLUInplace
 
 Yolov5BatchNorm2d = partial(nn.BatchNorm2d, eps=BN_EPS, momentum=BN_MOMENTUM)     # networks/yolov5.py:24
 
@@ -67,15 +68,14 @@ class Yolov5Network(nn.Module):
         num_anchors_per_cell: int,
         num_classes: int,
         norm_layer: Callable[..., nn.Module] = Yolov5BatchNorm2d,
-        activation_layer: Callable[..., nn.Module] = None,
+        activation_layer: Callable[..., nn.Module] = SiLUInplace,
         widen_factor: float = 1.0,
         deepen_factor: float = 1.0,
     ):
         super().__init__()
-        from ..graph_module import batchnorm_constants      # any BatchNorm2d eps / momentum; other normalisations are refused
-        self._bn_eps, self._bn_momentum = batchnorm_constants(norm_layer)
-        if activation_layer is not None and type(activation_layer()).__name__ not in ("SiLU", "SiLUInplace"):
-            raise ValueError("the HIP path implements SiLU only")
+        from ..graph_module import batchnorm_constants, activation_code
+        self._bn_eps, self._bn_momentum = batchnorm_constants(norm_layer)      # any BatchNorm2d eps / momentum; other normalisations are refused
+        self._act = activation_code(activation_layer)      # SiLU (the reference's default) | ReLU | LeakyReLU | Hardswish | Identity / None
         self.num_classes = num_classes
         self.num_anchors_per_cell = num_anchors_per_cell
         self.widen_factor, self.deepen_factor = widen_factor, deepen_factor
@@ -107,6 +107,7 @@ class Yolov5Network(nn.Module):
                 raise RuntimeError("Yolov5Network (HIP) must be on an MI355X: call .cuda() first; no CPU fallback")
             eng = Engine(self.graph, dict(self.named_parameters()), dict(self.named_buffers()), self.engine_options)
             eng.bn_eps, eng.bn_momentum = self._bn_eps, self._bn_momentum
+            eng.set_activation(*self._act)
             eng._build_arenas(dev)
             self._engine, self._engine_device = eng, dev
         return self._engine

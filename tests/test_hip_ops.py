@@ -431,6 +431,53 @@ def test_maxpool_chain_and_upsample():
     _close(nchw(dx), xr.grad + 1, 1e-2, 2e-2, "upsample grad (accumulate)")
 
 
+@pytest.mark.parametrize("act,slope", [(1, 0.0), (2, 0.1), (3, 0.0), (4, 0.0), (0, 0.0)])
+def test_bn_act_passes_vs_torch(act, slope):
+    """kodhip_bn_act_apply / _bwd_reduce / _bwd_apply (activations other than SiLU: 1 ReLU, 2 LeakyReLU, 3 Hardswish,
+    4 identity; 0 dispatches to the SiLU kernels) against torch autograd of act(y * scale + shift) (+ residual) on
+    bf16-rounded tensors with values on the activations' kinks (0, -3, 3)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(40 + act)
+    M, C = 3000, 32
+    fn = {0: F.silu, 1: F.relu, 2: lambda t: F.leaky_relu(t, slope), 3: F.hardswish, 4: lambda t: t}[act]
+    y = bf(torch.randn(M, C, generator=g) * 2)
+    y[::7] = 0.0; y[1::11] = 3.0; y[2::13] = -3.0
+    res = bf(torch.randn(M, C, generator=g))
+    scale, shift = torch.ones(C), torch.zeros(C)
+    scale[::2] = 1.5; shift[::3] = 0.5
+    lib = _lib.lib()
+    yb, rb = y.to(torch.bfloat16).cuda(), res.to(torch.bfloat16).cuda()
+    out = torch.zeros((M, C), dtype=torch.bfloat16, device="cuda")
+    sc, sh = scale.cuda(), shift.cuda()
+    _lib.check(lib.kodhip_bn_act_apply(yb.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), rb.data_ptr(), C, 0, out.data_ptr(), C, 0, M, C,
+                                       act, slope, stream()), "apply")
+    yr = y.clone().requires_grad_(True)
+    z = yr * scale + shift
+    a = fn(z)
+    _close(out.float().cpu(), (a + res).detach(), 1e-2, 1e-2, "act(bn(y)) + residual")
+    # backward: dz = dA * act'(z); sums and dY = k1 dz + k2 y + k3
+    dA = bf(torch.randn(M, C, generator=g))
+    a.backward(dA)
+    dz = yr.grad / scale                                     # d loss / d z
+    mean, rstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    T = lib.kodhip_bn_bwd_slots(M, C)
+    part = torch.zeros(2 * C * T, device="cuda")
+    dAb = dA.to(torch.bfloat16).cuda()
+    mean_d, rstd_d = mean.cuda(), rstd.cuda()
+    _lib.check(lib.kodhip_bn_act_bwd_reduce(dAb.data_ptr(), C, 0, yb.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), mean_d.data_ptr(),
+                                            rstd_d.data_ptr(), part.data_ptr(), M, C, act, slope, stream()), "reduce")
+    p2 = part.view(2, C, T).sum(-1).cpu()
+    _close(p2[0], dz.sum(0), 2e-3, 2e-3 * dz.abs().sum(0).max().item(), "sum dz")
+    _close(p2[1], (dz * (y - mean) * rstd).sum(0), 2e-3, 2e-3 * (dz * (y - mean) * rstd).abs().sum(0).max().item(), "sum dz xhat")
+    coef = torch.cat([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1])
+    ybw = yb.clone()
+    coef_d = coef.cuda()
+    _lib.check(lib.kodhip_bn_act_bwd_apply(dAb.data_ptr(), C, 0, ybw.data_ptr(), C, sc.data_ptr(), sh.data_ptr(), coef_d.data_ptr(),
+                                           None, 0, 0, 0, M, C, act, slope, stream()), "bwd apply")
+    want = coef[:C] * dz + coef[C:2 * C] * y + coef[2 * C:]
+    _close(ybw.float().cpu(), want, 1e-2, 2e-2, "dY")
+
+
 @pytest.mark.parametrize("K,shape", [(3, (2, 16, 9, 11)), (7, (2, 8, 12, 10)), (9, (1, 24, 20, 20)), (13, (2, 8, 6, 17)), (1, (1, 8, 4, 4)),
                                      (5, (2, 16, 9, 11))])
 def test_maxpool_any_window_vs_torch(K, shape):

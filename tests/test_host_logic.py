@@ -341,8 +341,12 @@ def test_submodule_classes_mirror_reference_parameters_and_refuse_cpu():
     assert (blk._bn_eps, blk._bn_momentum) == (1e-5, 0.1)
     with pytest.raises(ValueError):
         CSPBlock(32, 32, norm_layer=lambda c: torch.nn.GroupNorm(4, c))
+    # activations: SiLU (the reference's default), ReLU, LeakyReLU(slope), Hardswish, Identity / None; anything else raises
+    assert CSPBlock(32, 32)._act == (0, 0.0) and CSPBlock(32, 32, activation_layer=torch.nn.ReLU)._act == (1, 0.0)
+    assert CSPBlock(32, 32, activation_layer=lambda: torch.nn.LeakyReLU(0.2))._act == (2, 0.2)
+    assert CSPBlock(32, 32, activation_layer=torch.nn.Hardswish)._act[0] == 3 and CSPBlock(32, 32, activation_layer=None)._act[0] == 4
     with pytest.raises(ValueError):
-        CSPBlock(32, 32, activation_layer=torch.nn.ReLU)
+        CSPBlock(32, 32, activation_layer=torch.nn.GELU)
 
 
 def test_descriptor_producer_process_equals_in_process_protocol():
