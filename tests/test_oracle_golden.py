@@ -343,6 +343,7 @@ def test_color_transform_restatements_against_independent_implementations():
     definition in float64, CLAHE's properties (identity on flat images up to the Lab round trip, monotone look-up tables,
     reflect-padded tiles for sizes that are no multiple of 8) and the 8-bit Lab round trip (grey ramp within one level,
     OpenCV's documented values for the primaries)."""
+    pytest.importorskip("PIL")
     from PIL import Image, ImageFilter
     rng = np.random.default_rng(3)
     img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
