@@ -36,8 +36,9 @@ class _Composite(torch.Tensor):
 
 
 class TrainSampleAugmentor(object):
-    def __init__(self, aug_params: AugParams, rng_seed: int = 51, device="cuda"):
+    def __init__(self, aug_params: AugParams, rng_seed: int = 51, device="cuda", albumentations_global_random: bool = False):
         self.aug_params = aug_params
+        self.albu13 = bool(albumentations_global_random)        # follow albumentations 1.3.x's draws on python's global generator (host_protocol.augment_into)
         self.rng: np.random.Generator = np.random.default_rng(rng_seed)
         import random
         self.color_rng = random.Random(rng_seed)          # the colour Compose's own stream (host_protocol.color_gate)
@@ -64,7 +65,7 @@ class TrainSampleAugmentor(object):
         descs = np.zeros((1, 2), dtype=SAMPLE_DESC)
         canvas.fill(descs[0, 0])
         bb, lb, out = augment_into(descs[0, 0], self.aug_params, self.rng, np.asarray(input_data.bboxes),
-                                   np.asarray(input_data.labels), canvas.size, border, color_rng=self.color_rng)
+                                   np.asarray(input_data.labels), canvas.size, border, color_rng=self.color_rng, albu13=self.albu13)
         mix = np.array([[-1.0, 0.0]], dtype=np.float32)
         img, _, _ = compose(canvas.pool, descs, mix, canvas.tab, out, canvas.stager)
         return AugmentedSample(image=_Composite.wrap(img[0], canvas, descs[0, 0].copy(), out), bboxes=bb, labels=lb)

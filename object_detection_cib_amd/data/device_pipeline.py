@@ -178,14 +178,14 @@ class DeviceTrainPipeline:
 
     def __init__(self, images: Sequence[np.ndarray], boxes: Sequence[np.ndarray], labels: Sequence[np.ndarray],
                  target_image_size: int, device, aug_params: AugParams = AugParams(), mixup_prob: float = 0.0,
-                 rng_seed: int = 51, image_repeat_factors=None, sampler_indices=None):
+                 rng_seed: int = 51, image_repeat_factors=None, sampler_indices=None, albumentations_global_random: bool = False):
         _lib.require_gpu()
         assert desc_bytes() == SAMPLE_DESC.itemsize, (desc_bytes(), SAMPLE_DESC.itemsize)
         self.S = int(target_image_size)
         self.device = torch.device(device)
         self.pool = ImagePool(images, self.device)
         self.host = HostProtocol(self.pool.shapes, self.pool.offsets, boxes, labels, target_image_size, aug_params,
-                                 mixup_prob, rng_seed, image_repeat_factors, sampler_indices)
+                                 mixup_prob, rng_seed, image_repeat_factors, sampler_indices, albumentations_global_random)
         self.tab = torch.from_numpy(bilinear_table()).to(self.device)
         self._stager = _Stager(self.device)
 
@@ -202,7 +202,8 @@ class DeviceTrainPipeline:
         """Constructor arguments of an equivalent HostProtocol (picklable): what data/producer.py starts its worker with."""
         h = self.host
         return dict(shapes=h.shapes, offsets=h.offsets, boxes=h.boxes, labels=h.labels, target_image_size=h.S,
-                    aug_params=h.aug, mixup_prob=h.mixup_prob, image_repeat_factors=h.weights, sampler_indices=h.sampler_indices)
+                    aug_params=h.aug, mixup_prob=h.mixup_prob, image_repeat_factors=h.weights, sampler_indices=h.sampler_indices,
+                    albumentations_global_random=h.albu13)
 
     def compose_host_batch(self, descs: np.ndarray, mix: np.ndarray, out_f32: bool = True, out_pairs: bool = False, pairs_out=None):
         """The device half alone: descriptors (from this process or from a producer process) -> (f32 | None, pairs | None).

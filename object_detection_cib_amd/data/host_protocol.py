@@ -159,11 +159,14 @@ def color_gate(g: "_random.Random", p: float = 0.01):
 
 
 def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas: int, border, always_warp: bool = False,
-                 color_rng=None):
+                 color_rng=None, albu13: bool = False):
     """TrainSampleAugmentor.__call__ (default.py:440-488) for one sample: consumes the augmentor's generator in the
     reference's order (8 affine draws, 3 HSV draws, 1 flip draw), writes the pixel-side parameters (inverse affine
     matrix, colour-stage draws, HSV LUTs, flip flag) into the compositing descriptor and returns the transformed boxes /
-    labels and the output image side.  color_rng: the colour stage's generator (needed when aug.image_color_transforms)."""
+    labels and the output image side.  color_rng: the colour stage's generator (needed when aug.image_color_transforms).
+    albu13: model albumentations 1.3.x, whose Compose / transform gates draw on python's GLOBAL generator - the colour
+    stage then draws there (color_rng is ignored) and the ToFloat / ToTensorV2 Compose at the end of the call makes three
+    draws (tests/golden/protocol.npz case 'albu13')."""
     ap = aug.affine_params
     desc["persp"] = 0
     if not always_warp and ap.degrees == 0.0 and ap.translate == 0.0 and ap.scale == 0.0 and ap.shear == 0.0 and ap.perspective == 0.0:
@@ -187,8 +190,8 @@ def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas:
             bb, lb = nb[keep], lb[keep]
     desc["color"], desc["blur_k"], desc["median_k"], desc["clahe_clip"], desc["pre"] = 0, 0, 0, 0.0, 0
     if aug.image_color_transforms:                       # default.py:460-461: between the warp and the HSV jitter
-        assert color_rng is not None, "image_color_transforms=True needs the colour stage's generator"
-        desc["color"], desc["blur_k"], desc["median_k"], desc["clahe_clip"] = color_gate(color_rng)
+        assert albu13 or color_rng is not None, "image_color_transforms=True needs the colour stage's generator"
+        desc["color"], desc["blur_k"], desc["median_k"], desc["clahe_clip"] = color_gate(_random if albu13 else color_rng)
     hp = aug.hsv_params
     if hp.hue == 0.0 and hp.saturation == 0.0 and hp.value == 0.0:
         desc["hsv_on"] = 0
@@ -207,6 +210,9 @@ def augment_into(desc, aug: AugParams, rng: np.random.Generator, bb, lb, canvas:
         f[:, 0] = wo - 1 - bb[:, 2]
         bb = f
     desc["canvas"] = canvas
+    if albu13:                                            # default.py:433-438,482: tensor_transform's Compose, ToFloat, ToTensorV2 gates
+        for _ in range(3):
+            _random.random()
     return bb, lb, wo
 
 
@@ -219,8 +225,13 @@ class HostProtocol:
     kod/lightning/data_module.py:135-144) so that its 8 - 9 ms per batch of 64 leave the training step's process."""
 
     def __init__(self, shapes, offsets, boxes, labels, target_image_size: int, aug_params: AugParams = AugParams(),
-                 mixup_prob: float = 0.0, rng_seed: int = 51, image_repeat_factors=None, sampler_indices=None):
+                 mixup_prob: float = 0.0, rng_seed: int = 51, image_repeat_factors=None, sampler_indices=None,
+                 albumentations_global_random: bool = False):
         self.S = int(target_image_size)
+        # which albumentations generation to follow (the reference does not pin it): False = every Compose on a generator
+        # of its own (>= 1.4: only the colour stage's draws exist for anyone else, on self.color_rng); True = 1.3.x, whose
+        # gates draw on python's global generator and so shift the index draws that follow
+        self.albu13 = bool(albumentations_global_random)
         self.shapes, self.offsets = list(shapes), np.asarray(offsets, dtype=np.int64)
         self.boxes, self.labels = list(boxes), list(labels)
         self.aug = aug_params
@@ -246,7 +257,8 @@ class HostProtocol:
             d["x1b"], d["y1b"] = b
         # always_warp: a batch is S x S, so the affine stage (which crops the 2S canvas to S) runs even when no jitter
         # is configured (the reference would hand 2S x 2S images to the collate function in that case)
-        bb, lb, _ = augment_into(desc, self.aug, self.rng, bb, lb, 2 * S, border, always_warp=True, color_rng=self.color_rng)
+        bb, lb, _ = augment_into(desc, self.aug, self.rng, bb, lb, 2 * S, border, always_warp=True, color_rng=self.color_rng,
+                                 albu13=self.albu13)
         return bb, lb
 
     def batch(self, batch_indices: Sequence[int]):

@@ -321,13 +321,15 @@ def augment_hsv_u8(img: np.ndarray, r3: np.ndarray) -> np.ndarray:
 # ----------------------------------------------------------------------------- whole-sample protocol
 def augment_sample(canvas, boxes, labels, border, S, rng: np.random.Generator, hsv=(0.015, 0.7, 0.4),
                    flip_prob=0.5, translate=0.1, scale=0.5, degrees=0.0, shear=0.0, perspective=0.0, log=None,
-                   color=None):
+                   color=None, albu13=None):
     """TrainSampleAugmentor.__call__ (default.py:440-488).  Draw order of the augmentor's generator: 8 affine uniforms,
     3 HSV uniforms (one call), 1 flip draw - the flip draw only when flip_prob > 0 (AugParams.should_flip short-circuits,
     default.py:98-99).  color: None, or the generator (`random.Random`) of the image_color_transforms stage
     (default.py:420-432,460-461; the reference's default, configs/data/augmentations/aug_params.yaml:15) - the
     albumentations Compose between warp and HSV draws from the LIBRARY's generator, see color_gate.  log: dict that
-    receives M / LUTs / flip / colour draws."""
+    receives M / LUTs / flip / colour draws.  albu13: None, or python's global generator to model albumentations 1.3.x,
+    whose Compose / transform gates draw on it: the colour stage then uses it too (pass it as `color`), and the ToFloat /
+    ToTensorV2 Compose at the end of the call makes three draws (Compose, ToFloat, ToTensorV2)."""
     draws = affine_draws(rng, degrees=degrees, translate=translate, scale=scale, shear=shear, perspective=perspective)
     M, (wo, ho) = affine_matrix(draws, canvas.shape[1], canvas.shape[0], border)
     persp = draws[0] != 0 or draws[1] != 0                      # default.py:306-320: warpPerspective iff a perspective draw is non-zero
@@ -348,6 +350,9 @@ def augment_sample(canvas, boxes, labels, border, S, rng: np.random.Generator, h
     if flip:
         img = np.fliplr(img)
         boxes = flip_boxes(boxes, img.shape[1])
+    if albu13 is not None:
+        for _ in range(3):                                      # default.py:433-438,482: tensor_transform(image=...) under 1.3.x
+            albu13.random()
     if log is not None:
         log.update(M=M, dsize=(wo, ho), luts=luts, flip=flip, color=cdraw)
     chw = np.ascontiguousarray(img.transpose(2, 0, 1)).astype(np.float32) / np.float32(255.0)

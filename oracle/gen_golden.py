@@ -372,6 +372,7 @@ def gen_protocol():
                                  hsv_params=D.HSVParams(*hsv), flip_lr_prob=over.get("flip", 0.5),
                                  image_color_transforms=bool(over.get("color", False)))
             rec.color_rng = random.Random(synth.PROTOCOL_COLOR_SEED) if over.get("color") else None
+            rec.albu13 = bool(over.get("albu13", False))
             aug = D.TrainSampleAugmentor(params, rng_seed=51)
 
             def augmentor(sample, border=(0, 0), _aug=aug):
@@ -400,10 +401,12 @@ def gen_protocol():
             col = np.zeros((N, 2, 3), np.int64)                       # colour stage per augmentor call: ops bit mask, blur ksize, median ksize
             col_clip = np.zeros((N, 2))                               # ... CLAHE clip limit
             col_pos = np.full((N, 2), -1, np.int64)                   # ... 1 = the stage ran AFTER the warp and BEFORE the first LUT
+            n13 = np.zeros(N, np.int64)                                # albumentations-1.3 mode: gate draws on the global generator per sample
             for k in range(N):
                 rec.take()
                 smp = ds[k % n]
                 ev = rec.take()
+                n13[k] = sum(1 for e, _ in ev if e == "albu13_draw")
                 assert smp.image_info is None
                 reads = [p["index"] for e, p in ev if e == "read"]
                 idx[k, :len(reads)] = reads
@@ -450,8 +453,11 @@ def gen_protocol():
                         p + "counts": fn})
             if over.get("color"):
                 out.update({p + "color": col, p + "color_clip": col_clip, p + "color_pos": col_pos})
+            if over.get("albu13"):
+                out[p + "legacy_draws"] = n13
     finally:
         D.horizontal_flip, np.random.beta = flip_fn, beta_fn
+        rec.albu13 = False
     np.savez_compressed(os.path.join(OUT, "protocol.npz"), **out)
 
 

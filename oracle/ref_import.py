@@ -116,10 +116,14 @@ class ToTensorV2:
     import (`from albumentations.pytorch import ToTensorV2`, kod/data/augmentations/default.py), so the stand-in has to be
     in place BEFORE the first reference import, whichever generator runs first - install() puts it there."""
 
+    draw = None          # install_recording: the library-generation switch's draw hook (albumentations 1.3.x: one draw per call)
+
     def __init__(self, *a, **k):
         pass
 
     def __call__(self, **data):
+        if ToTensorV2.draw is not None:
+            ToTensorV2.draw()
         return dict(data, image=torch.from_numpy(data["image"].transpose(2, 0, 1)))
 
 
@@ -223,11 +227,26 @@ def install_recording(rec: Recorder):
 
     A = sys.modules["albumentations"]
 
+    # Library generation (the reference does not pin albumentations, requirements.txt:26).  rec.albu13 = False (default):
+    # albumentations >= 1.4 - every Compose draws on a generator of its own; only the colour stage's draws are modelled
+    # (rec.color_rng), the ToFloat / ToTensorV2 Compose consumes nothing anyone else sees.  rec.albu13 = True: albumentations
+    # 1.3.x - Compose.__call__ and every BasicTransform.__call__ draw `random.random()` on python's GLOBAL generator (one draw
+    # per Compose call + one per transform), so they interleave with DetectionDataset's index draws.
+    import random as _globalrandom
+
+    def _legacy_draw():
+        if getattr(rec, "albu13", False):
+            rec("albu13_draw")
+            _globalrandom.random()
+    ToTensorV2.draw = staticmethod(_legacy_draw)
+
     class Compose:                       # albumentations.Compose: transforms applied in order to data["image"]
         def __init__(self, transforms, *a, **k):
             self.transforms = list(transforms)
 
         def __call__(self, **data):
+            if not any(getattr(t, "colour_stage", False) for t in self.transforms):
+                _legacy_draw()           # (the colour Compose makes its Compose-level draw in ColourAwareCompose)
             for t in self.transforms:
                 data = t(**data)
             return data
@@ -237,6 +256,7 @@ def install_recording(rec: Recorder):
             self.max_value = max_value
 
         def __call__(self, **data):
+            _legacy_draw()
             rec("ToFloat", max_value=self.max_value)
             return dict(data, image=data["image"].astype("float32") / self.max_value)
 
@@ -254,7 +274,7 @@ def install_recording(rec: Recorder):
                 self.p = p
 
             def __call__(self, **data):
-                g = getattr(rec, "color_rng", None)
+                g = _globalrandom if getattr(rec, "albu13", False) else getattr(rec, "color_rng", None)
                 assert g is not None, "set Recorder.color_rng before running a configuration with image_color_transforms=True"
                 if g.random() < self.p:
                     params = draw_params(g)
@@ -268,7 +288,7 @@ def install_recording(rec: Recorder):
         def __call__(self, **data):
             if any(getattr(t, "colour_stage", False) for t in self.transforms):
                 rec("color_stage", n=len(self.transforms))
-                rec.color_rng.random()                    # Compose.__call__: need_to_run = random() < self.p (p = 1)
+                (_globalrandom if getattr(rec, "albu13", False) else rec.color_rng).random()   # Compose.__call__: need_to_run = random() < self.p (p = 1)
             return super().__call__(**data)
 
     A.Compose, A.ToFloat = ColourAwareCompose, ToFloat

@@ -201,6 +201,9 @@ PROTOCOL_CASES = {
     "persp": (0.3, False, dict(degrees=5.0, shear=2.0, perspective=0.0008)),   # cv2.warpPerspective + the boxes' perspective divide (default.py:306-313,257-260)
     # image_color_transforms=True (the reference's default, aug_params.yaml:15): the albumentations colour stage between warp and HSV
     "color": (0.3, False, dict(color=True)),
+    # the same under albumentations 1.3.x's draw protocol: every Compose / transform gate draws on python's GLOBAL generator,
+    # interleaving with DetectionDataset's index draws (oracle/ref_import.py install_recording, rec.albu13)
+    "albu13": (0.3, False, dict(color=True, albu13=True)),
 }
 PROTOCOL_S, PROTOCOL_POOL, PROTOCOL_N = 64, 12, 64
 # generator seed of the colour stage's gate in the 'color' case (the library's own stream; chosen so that each of the four

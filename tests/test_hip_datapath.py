@@ -151,6 +151,33 @@ def test_color_transforms_match_oracle(S, mixup, seed):
         assert (np.abs(plain[k] - img[k]).max() > 0) == any_fired, k
 
 
+@pytest.mark.parametrize("S,mixup,seed", [(64, 0.5, 31), (128, 0.3, 32)])
+def test_albumentations_13_draw_protocol_matches_oracle(S, mixup, seed):
+    """DeviceTrainPipeline(albumentations_global_random=True): the albumentations 1.3.x generation, whose Compose / transform
+    gates draw on python's GLOBAL generator (the colour stage's five draws and three for the ToFloat / ToTensorV2 Compose
+    per augmentor call) and so shift DetectionDataset's index draws - pixels, boxes and labels against the oracle run the
+    same way (pinned to the reference's call sequence by protocol.npz case 'albu13')."""
+    cache = _cache(12, S, seed)
+    idxs = list(range(12)) + [3, 0, 7, 11]
+    random.seed(seed); np.random.seed(seed)
+    rng = np.random.default_rng(51)
+    ref = [datapath.train_sample(cache, i, S, rng, mixup_prob=mixup, aug=dict(color=random, albu13=random)) for i in idxs]
+    random.seed(seed); np.random.seed(seed)
+    pipe = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda", AugParams(),
+                               mixup_prob=mixup, rng_seed=51, albumentations_global_random=True)
+    img, _, targets = pipe.make_batch(idxs, out_f32=True)
+    img = img.cpu().numpy()
+    for k, (rimg, rbb, rlb) in enumerate(ref):
+        np.testing.assert_array_equal(targets[k].boxes.numpy(), rbb)
+        np.testing.assert_array_equal(targets[k].labels.numpy(), rlb)
+        assert np.abs(img[k] - rimg).max() == 0.0, k
+    # and it is a different sample stream from the default generation's
+    random.seed(seed); np.random.seed(seed)
+    other = DeviceTrainPipeline([c[0] for c in cache], [c[1] for c in cache], [c[2] for c in cache], S, "cuda", AugParams(),
+                                mixup_prob=mixup, rng_seed=51).make_batch(idxs, out_f32=True)[0].cpu().numpy()
+    assert np.abs(other - img).max() > 0
+
+
 def test_full_size_properties():
     """640 px, batch 16: finite, in [0,1], deterministic, no-augmentation identity composite."""
     S = 640

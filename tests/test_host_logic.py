@@ -432,7 +432,7 @@ def test_bench_ranks_under_an_external_launcher_supervise_and_walk_the_ladder():
     assert not [ln for o in outs for ln in o[0].splitlines() if ln.startswith("{")]
 
 
-@pytest.mark.parametrize("case", ["plain", "mix03", "mix10", "rfs03", "rot", "nohsv", "persp", "color"])
+@pytest.mark.parametrize("case", ["plain", "mix03", "mix10", "rfs03", "rot", "nohsv", "persp", "color", "albu13"])
 def test_host_protocol_vs_reference_recording(case):
     """The PRODUCT's host side of the data protocol (data/host_protocol.HostProtocol: numpy only) against the recording of
     the reference's real DetectionDataset.__getitem__ + TrainSampleAugmentor (tests/golden/protocol.npz, made by
@@ -458,8 +458,11 @@ def test_host_protocol_vs_reference_recording(case):
     random.seed(2023)
     np.random.seed(2023)
     host = HostProtocol(shapes, offsets, [b for _, b, _ in pool], [l for _, _, l in pool], S, aug_params=aug,
-                        mixup_prob=mixup_prob, rng_seed=51, image_repeat_factors=w, sampler_indices=si)
-    if over.get("color"):           # the recording's colour-stage generator (the product seeds its own with rng_seed)
+                        mixup_prob=mixup_prob, rng_seed=51, image_repeat_factors=w, sampler_indices=si,
+                        albumentations_global_random=bool(over.get("albu13", False)))
+    if over.get("albu13"):          # albumentations 1.3.x: every gate on python's global generator - nothing to re-seed
+        pass
+    elif over.get("color"):         # the recording's colour-stage generator (the product seeds its own with rng_seed)
         assert host.color_rng is not None
         host.color_rng = random.Random(synth.PROTOCOL_COLOR_SEED)
     else:

@@ -234,6 +234,8 @@ def test_per_sample_protocol_vs_reference(golden, case):
         aug["hsv"] = over["hsv"]
     if over.get("color"):                 # image_color_transforms=True: the colour stage's own generator (see datapath.color_gate)
         aug["color"] = random.Random(synth.PROTOCOL_COLOR_SEED)
+    if over.get("albu13"):                # albumentations 1.3.x: every gate draws on python's global generator
+        aug["color"] = aug["albu13"] = random
     random.seed(2023)
     np.random.seed(2023)
     rng = np.random.default_rng(51)
@@ -274,7 +276,9 @@ def test_per_sample_protocol_vs_reference(golden, case):
         ob += cnt
         assert img.dtype == np.float32 and zlib.crc32(np.ascontiguousarray(img).tobytes()) == g["image_crc"][k], (case, k)
     assert ob == len(g["boxes"]) and om == len(g["mosaic_boxes"])
-    if over.get("color"):
+    if over.get("albu13"):
+        assert int(g["legacy_draws"].sum()) == 3 * int((g["color_pos"] == 1).sum())        # Compose + ToFloat + ToTensorV2 per call
+    elif over.get("color"):
         assert fired >= 4 and set(np.unique(g["color"][..., 0])) >= {0, 1, 2, 8, 12}     # every transform fired in the recording
 
 
