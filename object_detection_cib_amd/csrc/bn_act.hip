@@ -267,23 +267,38 @@ constexpr int U = 4;          // (the reduce / pair kernels; the two apply passe
 
 // ---------------------------------------------------------------- forward apply
 // out[m][ocoff + c] = silu(y[m][c]*scale[c] + shift[c]) (+ res[m][rcoff + c])
-template <int U>
-__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, int ldy, const float* scale, const float* shift,
+// Launch shape (template + launch arguments, chosen per tensor by apply_shape() below): U rows of one block-contiguous chunk
+// in flight per thread (rows m0, m0 + rpb, ...: a block reads U * rpb * C * 2 contiguous bytes per operand), blocks of up to
+// MAXT threads, and - LDSK - the per-channel constants staged through LDS once per block instead of read from global memory
+// by every thread: with many short blocks the constant loads otherwise outnumber the payload's (4 + 2 vector memory
+// instructions per row here, 10 + 3 in the backward pass) and the pass becomes address-unit-bound
+// (tools/micro/stream_apply.hip, profiles/r06_stream_apply.txt).
+template <int U, bool LDSK, int MAXT>
+__global__ __launch_bounds__(MAXT) void bn_silu_apply_kernel(const bf16_t* y, int ldy, const float* scale, const float* shift,
                                      const bf16_t* res, int ldr, int rcoff,
                                      bf16_t* out, int ldo, int ocoff, long M, int C, int rows_per_block_iter) {
+  extern __shared__ float kconst[];           // LDSK: [scale C | shift C]
   const int CC = C >> 3;
   const int cc = threadIdx.x % CC;
   const int rl = threadIdx.x / CC;
-  if (rl >= rows_per_block_iter) return;
   float sc[8], sh[8];
+  if (LDSK) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { kconst[c] = scale[c]; kconst[C + c] = shift[c]; }
+    __syncthreads();
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; }
-  const long stride = (long)gridDim.x * rows_per_block_iter;
-  for (long m0 = (long)blockIdx.x * rows_per_block_iter + rl; m0 < M; m0 += stride * U) {
+    for (int e = 0; e < 8; ++e) { sc[e] = kconst[cc * 8 + e]; sh[e] = kconst[C + cc * 8 + e]; }
+  }
+  if (rl >= rows_per_block_iter) return;
+  if (!LDSK) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; }
+  }
+  const long step = (long)gridDim.x * rows_per_block_iter * U;
+  for (long m0 = (long)blockIdx.x * rows_per_block_iter * U + rl; m0 < M; m0 += step) {
     bf16x8 v[U], r[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long m = m0 + u * stride;
+      const long m = m0 + (long)u * rows_per_block_iter;
       if (m < M) {
         v[u] = kod_load_once<bf16x8>(y + m * ldy + cc * 8);
         if (res) r[u] = *reinterpret_cast<const bf16x8*>(res + m * ldr + rcoff + cc * 8);
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, int
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long m = m0 + u * stride;
+      const long m = m0 + (long)u * rows_per_block_iter;
       if (m >= M) break;
       bf16x8 o;
       if (res) {
@@ -312,7 +327,11 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const bf16_t* y, int
           o[e] = (bf16_t)(z * kod_sigmoid_l2(KOD_NEG_LOG2E * z));
         }
       }
+#ifdef KOD_BN_NTST
+      __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(out + m * ldo + ocoff + cc * 8));
+#else
       *reinterpret_cast<bf16x8*>(out + m * ldo + ocoff + cc * 8) = o;
+#endif
     }
   }
 }
@@ -555,28 +574,39 @@ __global__ void bn_bwd_coeffs_kernel(const double* sums_local, const double* sum
 }
 
 // dY (bf16, written in place over y) ; optional identity gradient: dI[m][c] (+)= dA[m][c]
-template <int U>
-__global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, bf16_t* y, int ldy,
+template <int U, bool LDSK, int MAXT>
+__global__ __launch_bounds__(MAXT) void bn_silu_bwd_apply_kernel(const bf16_t* dA, int lda, int dacoff, bf16_t* y, int ldy,
                                          const float* scale, const float* shift, const float* coef,
                                          bf16_t* dI, int ldi, int dicoff, int di_accum,
                                          long M, int C, int rpb) {
+  extern __shared__ float kconst[];           // LDSK: [scale C | shift C | k1 C | k2 C | k3 C]
   const int CC = C >> 3;
   const int cc = threadIdx.x % CC;
   const int rl = threadIdx.x / CC;
-  if (rl >= rpb) return;
   float sc[8], sh[8], k1[8], k2[8], k3[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    int c = cc * 8 + e;
-    sc[e] = scale[c]; sh[e] = shift[c]; k1[e] = coef[c]; k2[e] = coef[C + c]; k3[e] = coef[2 * C + c];
+  if (LDSK) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      kconst[c] = scale[c]; kconst[C + c] = shift[c];
+      kconst[2 * C + c] = coef[c]; kconst[3 * C + c] = coef[C + c]; kconst[4 * C + c] = coef[2 * C + c];
+    }
+    __syncthreads();
   }
-  const long stride = (long)gridDim.x * rpb;
+  if (rl >= rpb) return;
+  if (!LDSK) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int c = cc * 8 + e;
+      sc[e] = scale[c]; sh[e] = shift[c]; k1[e] = coef[c]; k2[e] = coef[C + c]; k3[e] = coef[2 * C + c];
+    }
+  }
+  int ko = cc * 8;
+  const long step = (long)gridDim.x * rpb * U;
   const bool acc = dI && di_accum;
-  for (long m0 = (long)blockIdx.x * rpb + rl; m0 < M; m0 += stride * U) {
+  for (long m0 = (long)blockIdx.x * rpb * U + rl; m0 < M; m0 += step) {
     bf16x8 g[U], v[U], old[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long m = m0 + u * stride;
+      const long m = m0 + (long)u * rpb;
       if (m < M) {
         g[u] = kod_load_once<bf16x8>(dA + m * lda + dacoff + cc * 8);
         v[u] = kod_load_once<bf16x8>(y + m * ldy + cc * 8);
@@ -585,16 +615,30 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long m = m0 + u * stride;
+      const long m = m0 + (long)u * rpb;
       if (m >= M) break;
       bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float yv = (float)v[u][e];
-        const float z = __builtin_fmaf(yv, sc[e], sh[e]);
-        const float sg = kod_sigmoid_l2(KOD_NEG_LOG2E * z);
-        const float dz = kod_silu_bwd((float)g[u][e], z, sg);
-        o[e] = (bf16_t)__builtin_fmaf(k1[e], dz, __builtin_fmaf(k2[e], yv, k3[e]));
+      for (int h = 0; h < 2; ++h) {
+        if (LDSK) {
+          // the forty per-thread constants are read from LDS where they are used, four channels at a time, instead of being
+          // held in registers across the loop: 8 waves per SIMD instead of 6 keep enough bytes in flight for the HBM latency
+          // (the opaque offset keeps the compiler from hoisting the reads back out of the loop)
+          asm volatile("" : "+v"(ko));
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(&kconst[ko + 4 * h]), a1 = *reinterpret_cast<const f32x4*>(&kconst[C + ko + 4 * h]);
+          const f32x4 a2 = *reinterpret_cast<const f32x4*>(&kconst[2 * C + ko + 4 * h]), a3 = *reinterpret_cast<const f32x4*>(&kconst[3 * C + ko + 4 * h]);
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(&kconst[4 * C + ko + 4 * h]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sc[4 * h + e] = a0[e]; sh[4 * h + e] = a1[e]; k1[4 * h + e] = a2[e]; k2[4 * h + e] = a3[e]; k3[4 * h + e] = a4[e]; }
+        }
+#pragma unroll
+        for (int e = 4 * h; e < 4 * h + 4; ++e) {
+          const float yv = (float)v[u][e];
+          const float z = __builtin_fmaf(yv, sc[e], sh[e]);
+          const float sg = kod_sigmoid_l2(KOD_NEG_LOG2E * z);
+          const float dz = kod_silu_bwd((float)g[u][e], z, sg);
+          o[e] = (bf16_t)__builtin_fmaf(k1[e], dz, __builtin_fmaf(k2[e], yv, k3[e]));
+        }
       }
       *reinterpret_cast<bf16x8*>(y + m * ldy + cc * 8) = o;
       if (dI) {
@@ -609,27 +653,60 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const bf16_t* dA
   }
 }
 
-// Launch shape of the two apply passes, measured per tensor size in round 5 (tools/bench_bn.py, profiles/r05_bn_apply_sweep.txt):
-// ONE row in flight per thread and many blocks beat four rows per thread and 4 096 blocks on every size (the chip holds the
-// bytes in flight as resident waves instead of as registers: 6.5 M x 32 forward 191 -> 149 us, 1.6 M x 64 backward 134 ->
-// 111 us, 25 600 x 256 7.6 -> 6.2 us); tensors of >= 128 MB take 16 384 blocks, smaller ones 4 096 (more only adds ramp).
-static int bn_knob_u() { const char* e = getenv("KODHIP_BN_U"); const int u = e ? atoi(e) : 1; return (u == 2 || u == 4 || u == 8) ? u : 1; }
-static int bn_knob_grid() { const char* f = getenv("KODHIP_BN_GRID"); return f ? atoi(f) : 0; }
-static int apply_grid_cap(long M, int C) { return (M * C * 2 >= (128l << 20)) ? 16384 : 4096; }
+// Launch shape of the two apply passes.  Round 5 (profiles/r05_bn_apply_sweep.txt): one row per thread and many blocks beat four
+// grid-strided rows per thread.  Round 6, on tensors as cold as they are inside a step (tools/micro/stream_apply.hip,
+// profiles/r06_stream_apply.txt; tools/bench_bn.py, profiles/r06_bn_apply_sweep.txt): the passes were bounded by the bytes in
+// flight, and what held those down was the register cost of the per-thread constants (74 registers = 6 waves per SIMD in the
+// backward pass) and, with short blocks, the constant loads outnumbering the payload's.  Backward, <= 64 channels: constants in
+// LDS, read where they are used (50 registers), one row per thread, one chunk per block - 419 MB 235 -> 188 us (5.4 -> 6.7 TB/s),
+// 210 MB 114 -> 96 us; wider tensors have too few rows per block to pay for staging the constants and take two
+// block-adjacent rows per thread with the constants in registers (59 -> 53 us at 409 600 x 128).  Forward (16 constants, 62
+// registers either way): two block-adjacent rows per thread, at most 32 768 blocks: - 5 % over the nine sizes.
+struct ApplyShape { int threads, u, lds, cap; };
+static int bn_knob(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+static ApplyShape apply_shape(long M, int C, bool backward) {
+  // A/B knobs, read once (thread-safe: function-local static initialisers); 0 / unset = the measured default
+  static const int ku = bn_knob("KODHIP_BN_U"), kg = bn_knob("KODHIP_BN_GRID"), kb = bn_knob("KODHIP_BN_BLOCK"), kl = bn_knob("KODHIP_BN_LDS");
+  (void)M;
+  ApplyShape a;
+  if (backward && C <= 64) { a.lds = 1; a.u = 1; a.threads = 256; a.cap = 1 << 30; }
+  else { a.lds = 0; a.u = 2; a.threads = 256; a.cap = 32768; }
+  if (ku == 1 || ku == 2 || ku == 4) a.u = ku;
+  if (kb == 256 || kb == 512 || kb == 1024) a.threads = kb;
+  if (kl) a.lds = kl > 0 ? 1 : 0;          // KODHIP_BN_LDS = 1 | -1
+  if (kg) a.cap = kg;
+  if (a.threads > 256 && a.u > 2) a.u = 2;  // four rows in flight need more than the 128 registers a 1024-thread block may use
+  return a;
+}
 
 struct Geo { int threads, rpb, grid; };
-Geo geo(long M, int C, int max_blocks) {
+Geo geo(long M, int C, int max_blocks, int max_threads = 256, int U = 1) {
   int CC = C / 8;
-  int rpb = 256 / CC;
+  int rpb = max_threads / CC;
+  // whole 128-byte lines per block chunk where the width allows it (48 channels: 40 rows = 3 840 B instead of 42 = 4 032 B)
+  int q = 1;
+  while ((q * C * 2) % 128) q *= 2;
+  if (rpb >= q) rpb -= rpb % q;
   if (rpb < 1) rpb = 1;
   Geo g;
   g.rpb = rpb;
   g.threads = ((rpb * CC + 63) / 64) * 64;
-  long blocks = (M + rpb - 1) / rpb;
+  long blocks = (M + (long)rpb * U - 1) / ((long)rpb * U);
   g.grid = (int)(blocks < max_blocks ? blocks : max_blocks);
   if (g.grid < 1) g.grid = 1;
   return g;
 }
+
+// (rows in flight, constants through LDS, block size class) -> template instance; `a` and `g` in scope
+#define KOD_APPLY_DISPATCH(L)                                                                              \
+  do {                                                                                                     \
+    const bool big = g.threads > 256;                                                                      \
+    if (a.u == 4) { if (a.lds) L(4, true, 256); else L(4, false, 256); }                                   \
+    else if (a.u == 2) { if (big) { if (a.lds) L(2, true, 1024); else L(2, false, 1024); }                 \
+                         else { if (a.lds) L(2, true, 256); else L(2, false, 256); } }                     \
+    else { if (big) { if (a.lds) L(1, true, 1024); else L(1, false, 1024); }                               \
+           else { if (a.lds) L(1, true, 256); else L(1, false, 256); } }                                   \
+  } while (0)
 
 }  // namespace
 
@@ -758,14 +835,12 @@ int kodhip_bn_silu_apply(const void* y, int ldy, const float* scale, const float
   KOD_CHECK_ARG(y && scale && shift && out && M > 0, "bn_silu_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldo % 8 == 0 && ocoff % 8 == 0 && ocoff + C <= ldo, "bn_silu_apply: bad channel geometry");
   KOD_CHECK_ARG(!residual || (ldr % 8 == 0 && rcoff % 8 == 0 && rcoff + C <= ldr), "bn_silu_apply: bad residual slice");
-  // A/B knobs, read once (thread-safe: function-local static initialisers): rows in flight per thread (KODHIP_BN_U = 1 | 2 | 4 | 8;
-  // anything else means 1), grid cap (KODHIP_BN_GRID)
-  static const int tu = bn_knob_u(), tg = bn_knob_grid();
-  Geo g = geo(M, C, tg ? tg : apply_grid_cap(M, C));
+  const ApplyShape a = apply_shape(M, C, false);
+  Geo g = geo(M, C, a.cap, a.threads, a.u);
   KOD_CHECK_ARG(ldy % 8 == 0 && ldy >= C, "bn_silu_apply: bad row stride of y");
-#define KOD_APPLY(UU) hipLaunchKernelGGL(bn_silu_apply_kernel<UU>, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, ldy, scale, shift, \
-                     (const bf16_t*)residual, ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb)
-  if (tu == 8) KOD_APPLY(8); else if (tu == 2) KOD_APPLY(2); else if (tu == 4) KOD_APPLY(4); else KOD_APPLY(1);
+#define KOD_APPLY(UU, LL, TT) hipLaunchKernelGGL((bn_silu_apply_kernel<UU, LL, TT>), dim3(g.grid), dim3(g.threads), LL ? 2 * C * sizeof(float) : 0, stream, \
+                     (const bf16_t*)y, ldy, scale, shift, (const bf16_t*)residual, ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb)
+  KOD_APPLY_DISPATCH(KOD_APPLY);
 #undef KOD_APPLY
   KOD_LAUNCH_CHECK("bn_silu_apply");
   return KOD_OK;
@@ -829,12 +904,12 @@ int kodhip_bn_silu_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout,
   KOD_CHECK_ARG(dA && y_inout && scale && shift && coef && M > 0, "bn_silu_bwd_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda, "bn_silu_bwd_apply: bad geometry");
   KOD_CHECK_ARG(!dI || (ldi % 8 == 0 && dicoff % 8 == 0 && dicoff + C <= ldi), "bn_silu_bwd_apply: bad identity slice");
-  static const int tu = bn_knob_u(), tg = bn_knob_grid();
-  Geo g = geo(M, C, tg ? tg : apply_grid_cap(M, C));
+  const ApplyShape a = apply_shape(M, C, true);
+  Geo g = geo(M, C, a.cap, a.threads, a.u);
   KOD_CHECK_ARG(ldy % 8 == 0 && ldy >= C, "bn_silu_bwd_apply: bad row stride of y");
-#define KOD_BAPPLY(UU) hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<UU>, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)dA, lda, dacoff, \
-                     (bf16_t*)y_inout, ldy, scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb)
-  if (tu == 8) KOD_BAPPLY(8); else if (tu == 2) KOD_BAPPLY(2); else if (tu == 4) KOD_BAPPLY(4); else KOD_BAPPLY(1);
+#define KOD_BAPPLY(UU, LL, TT) hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<UU, LL, TT>), dim3(g.grid), dim3(g.threads), LL ? 5 * C * sizeof(float) : 0, stream, \
+                     (const bf16_t*)dA, lda, dacoff, (bf16_t*)y_inout, ldy, scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb)
+  KOD_APPLY_DISPATCH(KOD_BAPPLY);
 #undef KOD_BAPPLY
   KOD_LAUNCH_CHECK("bn_silu_bwd_apply");
   return KOD_OK;
@@ -857,7 +932,7 @@ int kodhip_bn_act_apply(const void* y, int ldy, const float* scale, const float*
   KOD_CHECK_ARG(y && scale && shift && out && M > 0, "bn_act_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && ldo % 8 == 0 && ocoff % 8 == 0 && ocoff + C <= ldo && ldy % 8 == 0 && ldy >= C, "bn_act_apply: bad channel geometry");
   KOD_CHECK_ARG(!residual || (ldr % 8 == 0 && rcoff % 8 == 0 && rcoff + C <= ldr), "bn_act_apply: bad residual slice");
-  Geo g = geo(M, C, apply_grid_cap(M, C));
+  Geo g = geo(M, C, (M * C * 2 >= (128l << 20)) ? 16384 : 4096);
   KOD_ACT_DISPATCH(bn_act_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)y, ldy, scale, shift, (const bf16_t*)residual,
                    ldr, rcoff, (bf16_t*)out, ldo, ocoff, M, C, g.rpb, slope)
   KOD_LAUNCH_CHECK("bn_act_apply");
@@ -872,7 +947,7 @@ int kodhip_bn_act_bwd_apply(const void* dA, int lda, int dacoff, void* y_inout, 
   KOD_CHECK_ARG(dA && y_inout && scale && shift && coef && M > 0, "bn_act_bwd_apply: bad args");
   KOD_CHECK_ARG(C % 8 == 0 && C <= 2048 && lda % 8 == 0 && dacoff % 8 == 0 && dacoff + C <= lda && ldy % 8 == 0 && ldy >= C, "bn_act_bwd_apply: bad geometry");
   KOD_CHECK_ARG(!dI || (ldi % 8 == 0 && dicoff % 8 == 0 && dicoff + C <= ldi), "bn_act_bwd_apply: bad identity slice");
-  Geo g = geo(M, C, apply_grid_cap(M, C));
+  Geo g = geo(M, C, (M * C * 2 >= (128l << 20)) ? 16384 : 4096);
   KOD_ACT_DISPATCH(bn_act_bwd_apply_kernel, dim3(g.grid), dim3(g.threads), 0, stream, (const bf16_t*)dA, lda, dacoff, (bf16_t*)y_inout, ldy,
                    scale, shift, coef, (bf16_t*)dI, ldi, dicoff, di_accum, M, C, g.rpb, slope)
   KOD_LAUNCH_CHECK("bn_act_bwd_apply");

@@ -17,7 +17,7 @@ from typing import Dict
 NATIVE_KNOBS = ("KODHIP_NO_FAST", "KODHIP_FORCE_BM", "KODHIP_FORCE_BN", "KODHIP_S2_SEPARATE", "KODHIP_S2_FOLD_MAXC",
                 "KODHIP_S2_INTERLEAVE", "KODHIP_ROW3", "KODHIP_ROW3_MODES", "KODHIP_WGRAD_DMA", "KODHIP_WGRAD_SLOTS", "KODHIP_WGRAD_ROW3", "KODHIP_STEM_ROW", "KODHIP_STEM_BWD_BLOCKS", "KODHIP_STEM_BWD_TW", "KODHIP_STEM_BWD_STREAM",
                 "KODHIP_PLAN_WIDE96", "KODHIP_WGRAD_TN192", "KODHIP_WGRAD_LINEAR", "KODHIP_WGRAD_ROW3_SLOTS", "KODHIP_DEBUG_STAMPS", "KODHIP_S2F_SKIP", "KODHIP_S2F_BN_CAP",
-                "KODHIP_LIB", "KODHIP_WG_CUMASK")
+                "KODHIP_LIB", "KODHIP_WG_CUMASK", "KODHIP_BN_U", "KODHIP_BN_GRID", "KODHIP_BN_BLOCK", "KODHIP_BN_LDS")
 
 
 def _flag(name: str, default: bool) -> bool:

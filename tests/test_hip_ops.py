@@ -331,10 +331,13 @@ def test_head_conv_fwd_bwd():
     _close(gw.cpu(), refw, 1e-2, 1e-2 * refw.abs().max().item(), "head wgrad")
 
 
-@pytest.mark.parametrize("C,res", [(32, False), (64, True), (48, True), (256, False)])
-def test_bn_silu_fwd_bwd(C, res):
+@pytest.mark.parametrize("C,res,hw", [(32, False, (10, 6)), (64, True, (10, 6)), (48, True, (10, 6)), (256, False, (10, 6)),
+                                      # many block chunks with a ragged last one in every launch shape of the apply passes (constants in
+                                      # LDS / in registers, one / two rows per thread, line-aligned chunks at 48 and 96 channels)
+                                      (32, True, (37, 29)), (48, False, (37, 29)), (96, True, (23, 31)), (128, True, (23, 31))])
+def test_bn_silu_fwd_bwd(C, res, hw):
     g = torch.Generator().manual_seed(C)
-    B, H, W = 3, 10, 6
+    B, (H, W) = 3, hw
     M = B * H * W
     y = bf(torch.randn(B, C, H, W, generator=g) * 2 + 0.5)
     gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
